@@ -1,0 +1,384 @@
+"""
+oracle/oracle.py -- numpy + plain-C restatement of the BLUEST sample-allocation hot path.
+
+TEST INFRASTRUCTURE ONLY.  Importable only from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; bluest_amd/ never imports it (tests/test_no_oracle_in_product.py enforces that).
+Parity status: PINNED by tests/golden/*.npz, generated from the real reference by oracle/gen_golden.py.
+
+Layers restated (paths relative to /root/reference/):
+  L0  bluest/cmisc.cpp            -> liboracle_bluest.so (oracle/bluest_oracle.c), wrapped below
+  L1  bluest/misc.py:453-495,600-629 -> get_nnz_rows_cols, get_phi_full, variance_full, variance_GH_full, ...
+  L2  bluest/sap.py:52-143        -> OracleSAP
+  L3  bluest/mosap.py:20-100      -> OracleMOSAP
+      bluest/spg.py:3-132         -> linesearch, spg
+Third-party arithmetic on the path is the same numpy.linalg the reference calls (pinv/solve); the C file
+carries its own Jacobi/LU stand-ins so the pure-C baseline needs no LAPACK.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_f64p = ctypes.POINTER(ctypes.c_double)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def build(force=False):
+    """Compile liboracle_bluest.so (gcc) and, when the reference tree is present, oracle/_ref."""
+    so = os.path.join(_HERE, "liboracle_bluest.so")
+    src = os.path.join(_HERE, "bluest_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle_bluest.so"], stdout=subprocess.DEVNULL)
+    if os.path.exists("/root/reference/bluest/cmisc.cpp"):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle_bluest.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = ctypes.CDLL(so)
+        _LIB.orc_sym_pinv.restype = ctypes.c_int
+        _LIB.orc_solve.restype = ctypes.c_int
+        _LIB.orc_variance.restype = ctypes.c_int
+        _LIB.orc_variance_GH.restype = ctypes.c_int
+    return _LIB
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_f64p)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    return a, a.ctypes.data_as(_i64p)
+
+
+# --------------------------------------------------------------------------------------------------
+# L0 wrappers: same call shapes as bluest/misc.py:600-629
+# --------------------------------------------------------------------------------------------------
+
+def assemble_psi(N, k, Lk, groupsk, invcovsk):
+    """bluest/misc.py:600-604 -> cmisc.cpp:10-23"""
+    psi = np.zeros((N * N, Lk), order="C")
+    g, gp = _i(np.asarray(groupsk).ravel(order="C"))
+    ic, icp = _f(invcovsk)
+    lib().orc_assemble_psi(psi.ctypes.data_as(_f64p), int(N), int(k), ctypes.c_int64(Lk), gp, icp)
+    return psi
+
+
+def objectiveK(N, k, Lk, mk, groupsk, invcovsk):
+    """what bluest/misc.py:612-616 intends (the reference wrapper omits N and raises TypeError); cmisc.cpp:25-40"""
+    PHI = np.zeros((N * N,))
+    g, gp = _i(np.asarray(groupsk).ravel(order="C"))
+    ic, icp = _f(invcovsk)
+    mk = np.ascontiguousarray(mk)
+    if np.issubdtype(mk.dtype, np.integer):
+        mm, mp = _i(mk)
+        lib().orc_objectiveK_i64(PHI.ctypes.data_as(_f64p), int(N), int(k), ctypes.c_int64(Lk), mp, gp, icp)
+    else:
+        mm, mp = _f(mk)
+        lib().orc_objectiveK_f64(PHI.ctypes.data_as(_f64p), int(N), int(k), ctypes.c_int64(Lk), mp, gp, icp)
+    return PHI
+
+
+def gradK(k, Lk, groupsk, invcovsk, invPHI):
+    """bluest/misc.py:618-622 -> cmisc.cpp:58-72 (uses invPHI[0])"""
+    grad = np.zeros((Lk,))
+    g, gp = _i(np.asarray(groupsk).ravel(order="C"))
+    ic, icp = _f(invcovsk)
+    v, vp = _f(invPHI[0])
+    lib().orc_gradK(grad.ctypes.data_as(_f64p), int(k), ctypes.c_int64(Lk), gp, icp, vp)
+    return grad
+
+
+def cleanupK(k, Lk, groupsk, invcovsk, invPHI):
+    """bluest/misc.py:606-610 -> cmisc.cpp:42-56 (with the `=` quirk of line 51)"""
+    N = invPHI.shape[0]
+    X = np.zeros((N, Lk), order="C")
+    g, gp = _i(np.asarray(groupsk).ravel(order="C"))
+    ic, icp = _f(invcovsk)
+    v, vp = _f(invPHI[0])
+    lib().orc_cleanupK(X.ctypes.data_as(_f64p), int(k), ctypes.c_int64(Lk), gp, icp, vp)
+    return X
+
+
+def hessKQ(k, q, Lk, Lq, groupsk, groupsq, invcovsk, invcovsq, invPHI):
+    """bluest/misc.py:624-629 -> cmisc.cpp:74-97"""
+    N = invPHI.shape[0]
+    hess = np.zeros((Lk, Lq), order="C")
+    gk, gkp = _i(np.asarray(groupsk).ravel(order="C"))
+    gq, gqp = _i(np.asarray(groupsq).ravel(order="C"))
+    ick, ickp = _f(invcovsk)
+    icq, icqp = _f(invcovsq)
+    P, Pp = _f(np.asarray(invPHI).ravel(order="C"))
+    lib().orc_hessKQ(hess.ctypes.data_as(_f64p), int(N), int(k), int(q), ctypes.c_int64(Lk), ctypes.c_int64(Lq),
+                     gkp, gqp, ickp, icqp, Pp)
+    return hess
+
+
+# --------------------------------------------------------------------------------------------------
+# L1: bluest/misc.py:453-495
+# --------------------------------------------------------------------------------------------------
+
+def get_nnz_rows_cols(m, groups, cumsizes):
+    """bluest/misc.py:453-457"""
+    K = len(cumsizes) - 1
+    ms = [m[cumsizes[k]:cumsizes[k + 1]] for k in range(K)]
+    out = np.unique(np.concatenate([groups[k][abs(ms[k]) > 1.0e-6].flatten() for k in range(K)]))
+    return out.reshape((len(out), 1)), out.reshape((1, len(out)))
+
+
+def get_phi_full(m, psi, delta=0.0):
+    """bluest/misc.py:459-461"""
+    N = int(round(np.sqrt(psi.shape[0])))
+    return delta * np.eye(N) + (psi @ m).reshape((N, N))
+
+
+def variance_full(m, psi, groups, cumsizes, delta=0.0):
+    """bluest/misc.py:463-477"""
+    if abs(m).max() < 0.05:
+        return np.inf
+    PHI = get_phi_full(m, psi, delta=delta)
+    idx = get_nnz_rows_cols(m, groups, cumsizes)
+    PHI = PHI[idx]
+    assert idx[0].min() == 0  # misc.py:470
+    return np.linalg.solve(PHI, np.eye(len(idx[0]), 1).flatten())[0]
+
+
+def variance_GH_full(m, psi, groups, sizes, invcovs, delta=0.0, nohess=False):
+    """bluest/misc.py:479-505"""
+    K = len(groups)
+    L = len(m)
+    cumsizes = np.cumsum(sizes)
+    if abs(m).max() < 0.05:
+        return np.inf, np.inf * np.ones((L,))
+    PHI = get_phi_full(m, psi, delta=delta)
+    invPHI = np.linalg.pinv(PHI)
+    idx = get_nnz_rows_cols(m, groups, cumsizes)
+    var = np.linalg.pinv(PHI[idx])[0, 0]
+    grad = -np.concatenate([gradK(k, sizes[k], groups[k - 1], invcovs[k - 1], invPHI) for k in range(1, K + 1)])
+    if nohess:
+        return var, grad, None
+    hess = np.zeros((L, L))
+    for k in range(1, K + 1):
+        for q in range(1, K + 1):
+            hess[cumsizes[k - 1]:cumsizes[k], :][:, cumsizes[q - 1]:cumsizes[q]] = hessKQ(
+                k, q, sizes[k], sizes[q], groups[k - 1], groups[q - 1], invcovs[k - 1], invcovs[q - 1], invPHI)
+    hess += hess.T
+    return var, grad, hess
+
+
+# --------------------------------------------------------------------------------------------------
+# L2: bluest/sap.py:52-143
+# --------------------------------------------------------------------------------------------------
+
+class OracleSAP(object):
+    """bluest/sap.py:52-143 (constructor + get_variance_functions), numpy.linalg.pinv per group as at :74."""
+
+    def __init__(self, C, K, groups, costs):
+        self.C = C
+        self.N = C.shape[0]
+        self.K = K
+        self.costs = costs
+        invcovs = [[] for k in range(K)]
+        sizes = [0] + [len(groupsk) for groupsk in groups]
+        groups = list(groups)
+        for k in range(1, K + 1):
+            gk = np.array(groups[k - 1], dtype=np.int64).reshape((-1, k))
+            groups[k - 1] = gk
+            if len(gk) > 0:
+                sub = C[gk[:, :, None], gk[:, None, :]]          # (Lk,k,k) = C[idx.T, idx] per group (sap.py:72-74)
+                invcovs[k - 1] = np.concatenate([np.linalg.pinv(sub[i]).ravel() for i in range(len(gk))])
+            else:
+                invcovs[k - 1] = np.array([])
+        self.sizes = sizes
+        self.groups = groups
+        self.invcovs = invcovs
+        self.cumsizes = np.cumsum(sizes)
+        self.L = int(self.cumsizes[-1])
+        allg = [g for gk in groups for g in gk]
+        self.ES = [np.array([int(i in g) for g in allg]) for i in range(self.N)]   # sap.py:89-94
+        self.e = self.ES[0]
+        self.psi = np.hstack([assemble_psi(self.N, k, sizes[k], groups[k - 1], invcovs[k - 1])
+                              for k in range(1, K + 1) if len(groups[k - 1]) > 0])  # sap.py:129
+
+    def get_phi(self, m, delta=0):
+        return get_phi_full(m, self.psi, delta=delta)
+
+    def variance(self, m, delta=0):
+        return variance_full(m, self.psi, self.groups, self.cumsizes, delta=delta)
+
+    def variance_GH(self, m, delta=0, nohess=False):
+        return variance_GH_full(m, self.psi, self.groups, self.sizes, self.invcovs, delta=delta, nohess=nohess)
+
+    # ---- flat views for the pure-C twins -------------------------------------------------------
+    def flat(self):
+        sizes = np.asarray(self.sizes, dtype=np.int64)
+        groups = np.concatenate([g.ravel() for g in self.groups]).astype(np.int64)
+        invcovs = np.concatenate([np.asarray(ic, dtype=np.float64).ravel() for ic in self.invcovs])
+        return sizes, groups, invcovs
+
+    def c_variance(self, m, delta=0.0, dense=False):
+        """pure-C twin of variance (LU solve); dense=True uses the dense psi GEMV as the reference executes"""
+        sizes, groups, invcovs = self.flat()
+        m, mp = _f(m)
+        var = ctypes.c_double(0.0)
+        psi_p = self.psi.ctypes.data_as(_f64p) if dense else None
+        rc = lib().orc_variance(mp, psi_p, int(self.N), int(self.K), sizes.ctypes.data_as(_i64p),
+                                groups.ctypes.data_as(_i64p), invcovs.ctypes.data_as(_f64p),
+                                ctypes.c_double(delta), ctypes.byref(var))
+        return rc, var.value
+
+    def c_variance_GH(self, m, delta=0.0, dense=False):
+        """pure-C twin of variance_GH(nohess=True) (Jacobi pinv)"""
+        sizes, groups, invcovs = self.flat()
+        m, mp = _f(m)
+        var = ctypes.c_double(0.0)
+        grad = np.zeros(self.L)
+        v = np.zeros(self.N)
+        PHI = np.zeros((self.N, self.N))
+        psi_p = self.psi.ctypes.data_as(_f64p) if dense else None
+        rc = lib().orc_variance_GH(mp, psi_p, int(self.N), int(self.K), sizes.ctypes.data_as(_i64p),
+                                   groups.ctypes.data_as(_i64p), invcovs.ctypes.data_as(_f64p),
+                                   ctypes.c_double(delta), ctypes.byref(var), grad.ctypes.data_as(_f64p),
+                                   v.ctypes.data_as(_f64p), PHI.ctypes.data_as(_f64p))
+        return rc, var.value, grad, v, PHI
+
+
+def c_group_pinv(C, k, groupsk):
+    """pure-C twin of sap.py:69-79 for one group size (Jacobi pinv)"""
+    C, Cp = _f(C)
+    g, gp = _i(np.asarray(groupsk).ravel())
+    Lk = len(g) // k
+    out = np.zeros(Lk * k * k)
+    lib().orc_group_pinv(Cp, int(C.shape[0]), int(k), ctypes.c_int64(Lk), gp, out.ctypes.data_as(_f64p))
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# L3: bluest/mosap.py:20-100 (hash-based mapping instead of the O(L_k^2) search at :54-65; same result)
+# --------------------------------------------------------------------------------------------------
+
+class OracleMOSAP(object):
+    def __init__(self, C, K, Ks, groups, multi_groups, costs, multi_costs):
+        self.n_outputs = len(C)
+        self.N = C[0].shape[0]
+        self.K = K
+        self.Ks = Ks
+        self.costs = costs
+        self.groups = [np.array(g, dtype=np.int64).reshape((-1, k + 1)) for k, g in enumerate(groups)]
+        self.SAPS = [OracleSAP(C[n], Ks[n], multi_groups[n], multi_costs[n]) for n in range(self.n_outputs)]
+        self.sizes = [0] + [len(g) for g in self.groups]
+        self.cumsizes = np.cumsum(self.sizes)
+        self.L = int(self.cumsizes[-1])
+        pos = {}
+        for k, gk in enumerate(self.groups):
+            for j, g in enumerate(gk):
+                pos[tuple(int(x) for x in g)] = int(self.cumsizes[k]) + j
+        self.mappings = [np.array([pos[tuple(int(x) for x in g)] for gk in self.SAPS[n].groups for g in gk],
+                                  dtype=np.int64) for n in range(self.n_outputs)]
+        allg = [g for gk in self.groups for g in gk]
+        self.e = np.array([int(0 in g) for g in allg], dtype=np.int64)
+
+    def variances(self, m, delta=0):
+        """bluest/mosap.py:86-89"""
+        return [self.SAPS[n].variance(m[self.mappings[n]], delta=delta) for n in range(self.n_outputs)]
+
+    def variance_GH(self, m, nohess=False, delta=0):
+        """bluest/mosap.py:91-100"""
+        out = [self.SAPS[n].variance_GH(m[self.mappings[n]], nohess=nohess, delta=delta)
+               for n in range(self.n_outputs)]
+        return [o[0] for o in out], [o[1] for o in out], [o[2] for o in out]
+
+
+# --------------------------------------------------------------------------------------------------
+# bluest/spg.py:3-132, restated
+# --------------------------------------------------------------------------------------------------
+
+def linesearch(feval, x, f, g, d, last_fval, max_fevals, count):
+    """bluest/spg.py:3-37: nonmonotone Armijo with safeguarded quadratic interpolation"""
+    sigma_min, sigma_max, gamma = 0.1, 0.9, 1.0e-4
+    fmax = max(last_fval)
+    gdotd = g @ d
+    alpha = 1.0
+    xnew = x + alpha * d
+    fnew = feval(xnew)
+    count += 1
+    while fnew > fmax + gamma * alpha * gdotd and count < max_fevals:
+        if alpha <= sigma_min:
+            alpha *= 0.5
+        else:
+            alpha_t = -0.5 * (alpha ** 2) * gdotd / (fnew - f - alpha * gdotd)
+            if alpha_t < sigma_min or alpha_t > sigma_max * alpha:
+                alpha_t = 0.5 * alpha
+            alpha = alpha_t
+        xnew = x + alpha * d
+        fnew = feval(xnew)
+        count += 1
+    info = 0 if fnew <= fmax + gamma * alpha * gdotd else 2
+    return count, fnew, xnew, info, alpha
+
+
+def spg(feval, geval, proj, x, eps=1.0e-4, maxit=200, max_fevals=10 ** 5, lmbda_min=1e-30, lmbda_max=1e30,
+        Hlength=10, trace=None):
+    """bluest/spg.py:39-132.  `trace`, if a list, receives (it, f, gpmax, lmbda, alpha) per iteration."""
+    it = 0
+    count = 0
+    last_fval = -np.inf * np.ones((Hlength,))
+    x = proj(x)
+    f = feval(x)
+    g = geval(x)
+    count += 1
+    last_fval[0] = f
+    gp = proj(x - g) - x
+    gpmax = abs(gp).max()
+    lmbda = min(lmbda_max, max(lmbda_min, 1.0 / gpmax)) if gpmax > 1.0e-15 else 0.0
+    if trace is not None:
+        trace.append((it, f, gpmax, lmbda, 0.0))
+    while gpmax > eps and it < maxit and count < max_fevals:
+        it += 1
+        d = proj(x - lmbda * g) - x
+        count, fnew, xnew, info, alpha = linesearch(feval, x, f, g, d, last_fval, max_fevals, count)
+        if info == 2:
+            return {"x": x, "f": f, "gpmax": gpmax, "it": it, "count": count, "solver_info": 2}
+        f = fnew
+        last_fval[it % Hlength] = f
+        gnew = geval(xnew)
+        s = xnew - x
+        y = gnew - g
+        sdots = s @ s
+        sdoty = s @ y
+        x = xnew
+        g = gnew
+        gp = proj(x - g) - x
+        gpmax = abs(gp).max()
+        lmbda = lmbda_max if sdoty <= 0 else min(lmbda_max, max(lmbda_min, sdots / sdoty))
+        if trace is not None:
+            trace.append((it, f, gpmax, lmbda, alpha))
+    info = 0 if gpmax <= eps else (1 if it >= maxit else 2)
+    return {"x": x, "f": f, "gpmax": gpmax, "it": it, "count": count, "solver_info": info}
+
+
+def simplex_projection(v, z=1.0):
+    """Euclidean projection onto {x >= 0, sum x = z} (sort-and-threshold; shift by max(v) first, the
+    projection is shift-invariant and SPG feeds values of magnitude lmbda_max=1e30).  No reference
+    counterpart: this is the build-defined `proj` for the new solver="spg"."""
+    v = np.asarray(v, dtype=np.float64)
+    u = v - v.max()
+    s = np.sort(u)[::-1]
+    css = np.cumsum(s) - z
+    k = np.arange(1, len(s) + 1)
+    cond = s - css / k > 0
+    rho = k[cond][-1]
+    tau = css[cond][-1] / rho
+    return np.maximum(u - tau, 0.0)

@@ -1,0 +1,207 @@
+"""
+CPU tests (-m "not gpu"): pin the oracle (oracle/oracle.py + oracle/bluest_oracle.c) against the golden vectors
+produced by the real reference (oracle/gen_golden.py).  Tolerance: 1e-13 relative on the numpy
+restatement; 1e-9..1e-11 on the pure-C Jacobi/LU twins for quantities that go through a pseudo-inverse of an
+ill-conditioned matrix (documented per test).
+"""
+import numpy as np
+import pytest
+
+from bluest_amd import synth
+from conftest import golden, rel_err
+
+
+def _split(prefix, G):
+    return {k[len(prefix):]: v for k, v in G.items() if k.startswith(prefix)}
+
+
+def test_cmisc_known_answers(oracle):
+    """every native function of cmisc.cpp:99-110 against the compiled reference's outputs"""
+    G = golden("cmisc_known_answers.npz")
+    N = int(G["N"])
+    for k, q in ((1, 2), (2, 3), (3, 3), (4, 2)):
+        g = _split("k%dq%d_" % (k, q), G)
+        Lk, Lq = len(g["gk"]), len(g["gq"])
+        assert rel_err(oracle.assemble_psi(N, k, Lk, g["gk"], g["ick"]), g["psi"]) == 0.0
+        assert rel_err(oracle.objectiveK(N, k, Lk, g["mk"], g["gk"], g["ick"]), g["PHI"]) < 1e-15
+        assert rel_err(oracle.objectiveK(N, k, Lk, g["mki"], g["gk"], g["ick"]), g["PHIi"]) < 1e-15
+        assert rel_err(oracle.gradK(k, Lk, g["gk"], g["ick"], g["P"]), g["grad"]) < 1e-14
+        assert rel_err(oracle.cleanupK(k, Lk, g["gk"], g["ick"], g["P"]), g["X"]) < 1e-15
+        assert rel_err(oracle.hessKQ(k, q, Lk, Lq, g["gk"], g["gq"], g["ick"], g["icq"], g["P"]), g["hess"]) < 1e-13
+
+
+CASES = ("base", "sparse", "drop_last_model", "only_first3", "int64")
+
+
+def _check_sap_file(oracle, fname, tol=1e-13):
+    G = golden(fname)
+    n, kmax, n_out = int(G["n"]), int(G["kmax"]), int(G["n_out"])
+    prob = synth.problem(n, kmax, n_out)
+    for o in range(n_out):
+        sap = oracle.OracleSAP(prob["C"][o], kmax, prob["groups"], prob["costs"])
+        if o == 0:
+            ic = np.concatenate(sap.invcovs)
+            if "invcovs_o0" in G:
+                assert rel_err(ic, G["invcovs_o0"]) < 1e-14
+            else:
+                assert rel_err(ic[::101], G["invcovs_o0_sub"]) < 1e-14
+                assert abs(np.linalg.norm(ic) / G["invcovs_o0_norm"] - 1) < 1e-14
+            if "psi_o0" in G:
+                assert rel_err(sap.psi, G["psi_o0"]) < 1e-14
+        for name in CASES:
+            m = prob["m"][o] if name == "base" else G["o%d_%s_m" % (o, name)]
+            mf = m.astype(np.float64)
+            for delta in ((0.0, 1e-6) if name in ("base", "drop_last_model") else (0.0,)):
+                tag = "o%d_%s_" % (o, name) + ("d%g_" % delta if delta else "")
+                assert abs(sap.variance(mf, delta=delta) / G[tag + "V"] - 1) < tol
+                V, grad, _ = sap.variance_GH(mf, delta=delta, nohess=True)
+                assert abs(V / G[tag + "Vgh"] - 1) < tol
+                assert rel_err(sap.get_phi(mf, delta=delta), G[tag + "PHI"]) < tol
+                if tag + "grad" in G:
+                    assert rel_err(grad, G[tag + "grad"]) < tol
+                else:
+                    assert rel_err(grad[::97], G[tag + "grad_sub"]) < tol
+                    assert abs(np.linalg.norm(grad) / G[tag + "grad_norm"] - 1) < tol
+                if tag + "hess" in G:
+                    assert rel_err(sap.variance_GH(mf, delta=delta)[2], G[tag + "hess"]) < 1e-12
+        # all-tiny allocation -> inf (misc.py:464,484)
+        assert np.isinf(sap.variance(0.01 * np.ones(sap.L))) and np.isinf(G["o%d_tiny_V" % o])
+        Vt, gt = sap.variance_GH(0.01 * np.ones(sap.L), nohess=True)[:2]
+        assert np.isinf(Vt) and np.isinf(gt).all() and bool(G["o%d_tiny_grad_isinf" % o])
+        # int64 allocation through the sparse native loop (cmisc.cpp:105) == dense psi@m
+        mi = G["o%d_int64_m" % o]
+        PHI = np.zeros(n * n)
+        for k in range(1, kmax + 1):
+            PHI += oracle.objectiveK(n, k, sap.sizes[k], mi[sap.cumsizes[k - 1]:sap.cumsizes[k]],
+                                     sap.groups[k - 1], sap.invcovs[k - 1])
+        assert rel_err(PHI.reshape(n, n), G["o%d_int64_PHI_native" % o]) < 1e-14
+
+
+@pytest.mark.parametrize("fname", ["sap_n5_all.npz", "sap_n6_all.npz", "sap_n12_all.npz"])
+def test_sap_small(oracle, fname):
+    _check_sap_file(oracle, fname)
+
+
+def test_sap_n20_k5_o8(oracle):
+    _check_sap_file(oracle, "sap_n20_k5_o8.npz")
+
+
+def test_model0_unsampled_asserts(oracle):
+    """misc.py:470: variance() raises AssertionError when no sampled group contains model 0"""
+    prob = synth.problem(5, 3, 1)
+    sap = oracle.OracleSAP(prob["C"][0], 3, prob["groups"], prob["costs"])
+    m = prob["m"][0].copy()
+    m[sap.e == 1] = 0.0
+    with pytest.raises(AssertionError):
+        sap.variance(m)
+    rc, _ = sap.c_variance(m)
+    assert rc == 2
+
+
+def test_pure_c_twins(oracle):
+    """the plain-C evaluation (Jacobi pinv / LU solve, no LAPACK) agrees with the numpy restatement; this is the
+    code timed as bench.py's cpu_baseline"""
+    for n, kmax in ((6, 6), (12, 5)):
+        prob = synth.problem(n, kmax, 1)
+        sap = oracle.OracleSAP(prob["C"][0], kmax, prob["groups"], prob["costs"])
+        m = prob["m"][0]
+        for dense in (False, True):
+            rc, V = sap.c_variance(m, dense=dense)
+            assert rc == 0 and abs(V / sap.variance(m) - 1) < 1e-11
+            rc, V, grad, v, PHI = sap.c_variance_GH(m, dense=dense)
+            Vr, gr, _ = sap.variance_GH(m, nohess=True)
+            assert rc == 0 and abs(V / Vr - 1) < 1e-10
+            assert rel_err(grad, gr) < 1e-10
+            assert rel_err(PHI, sap.get_phi(m)) < 1e-14
+        for k in (1, 2, 3, kmax):
+            assert rel_err(oracle.c_group_pinv(prob["C"][0], k, sap.groups[k - 1]), sap.invcovs[k - 1]) < 1e-11
+
+
+def test_mosap_ragged(oracle):
+    """multi-output with different group sets per output (mosap.py:54-67 mappings, :86-100 fan-out)"""
+    G = golden("mosap_n6_o3_ragged.npz")
+    n, n_out, kmax = int(G["n"]), int(G["n_out"]), int(G["kmax"])
+    prob = synth.problem(n, kmax, n_out)
+    groups = [G["g_k%d" % k] for k in range(1, kmax + 1)]
+    multi_groups = [[G["mg%d_k%d" % (o, k)] for k in range(1, kmax + 1)] for o in range(n_out)]
+    w = prob["w"]
+    mos = oracle.OracleMOSAP(prob["C"], kmax, [kmax] * n_out, groups, multi_groups, synth.group_costs(groups, w),
+                             [synth.group_costs(mg, w) for mg in multi_groups])
+    for o in range(n_out):
+        assert (mos.mappings[o] == G["map%d" % o]).all()
+    assert (mos.e == G["e"]).all()
+    assert rel_err(mos.variances(G["m"]), G["Vs"]) < 1e-13
+    Vgh, grads, _ = mos.variance_GH(G["m"], nohess=True)
+    assert rel_err(Vgh, G["Vgh"]) < 1e-13
+    for o in range(n_out):
+        assert rel_err(grads[o], G["grad%d" % o]) < 1e-13
+
+
+def test_hh_paper_known_answer(oracle):
+    """Hodgkin-Huxley paper fixture: stored allocation -> errors/eps and total cost.
+    cond(C) is 1e9..5e10 here, so V is compared at 1e-6 (pinv of ill-conditioned blocks), the cost exactly."""
+    G = golden("hh_paper_known_answer.npz")
+    n, n_out, kmax = int(G["n"]), int(G["n_out"]), int(G["kmax"])
+    groups = synth.all_groups(n, kmax)
+    costs = synth.group_costs(groups, G["costs"])
+    Cs = [G["C%d" % o] for o in range(n_out)]
+    mos = oracle.OracleMOSAP(Cs, kmax, [kmax] * n_out, groups, [groups] * n_out, costs, [costs] * n_out)
+    samples = G["samples"]
+    Vs = np.array(mos.variances(samples.astype(np.float64)))
+    assert rel_err(Vs, G["Vs"]) < 1e-6
+    eps = np.sqrt(np.array([C[0, 0] for C in Cs])) / 1000
+    assert np.allclose(np.sqrt(Vs) / eps, [0.8906, 1.00004, 0.9479, 0.5477, 0.5583], rtol=2e-4)
+    assert abs(float(samples @ costs) - float(G["total_cost"])) < 1e-9 * float(G["total_cost"])
+    assert abs(float(G["total_cost"]) - 60626.8057) < 1e-3
+
+
+@pytest.mark.parametrize("fname", ["spg_traj_n6.npz", "spg_traj_n12_k4.npz"])
+def test_spg_trajectory(oracle, fname):
+    """oracle spg()+callbacks reproduce the reference spg() run call by call (every f evaluated, every |g|)"""
+    G = golden(fname)
+    n, kmax = int(G["n"]), int(G["kmax"])
+    prob = synth.problem(n, kmax, 1)
+    sap = oracle.OracleSAP(prob["C"][0], kmax, prob["groups"], prob["costs"])
+    scale = prob["budget"] / prob["costs"]
+    fvals, gnorms = [], []
+
+    def feval(x):
+        try:
+            f = sap.variance(scale * x)
+        except AssertionError:
+            f = np.inf
+        fvals.append(f)
+        return f
+
+    def geval(x):
+        g = scale * sap.variance_GH(scale * x, nohess=True)[1]
+        gnorms.append(np.linalg.norm(g))
+        return g
+
+    res = oracle.spg(feval, geval, oracle.simplex_projection, np.ones(sap.L) / sap.L, eps=float(G["eps"]),
+                     maxit=int(G["maxit"]), max_fevals=10 ** 5)
+    assert res["it"] == int(G["it"]) and res["count"] == int(G["count"]) and res["solver_info"] == int(G["solver_info"])
+    assert len(fvals) == len(G["fvals"])
+    fin = np.isfinite(G["fvals"])
+    assert (np.isfinite(fvals) == fin).all()
+    assert rel_err(np.array(fvals)[fin], G["fvals"][fin]) < 1e-9
+    assert rel_err(gnorms, G["gnorms"]) < 1e-7
+    assert abs(res["f"] / float(G["f"]) - 1) < 1e-9
+    assert rel_err(res["x"], G["x"]) < 1e-6
+
+
+def test_simplex_projection_properties(oracle):
+    rng = np.random.RandomState(3)
+    for scale in (1.0, 1e-8, 1e30):
+        v = scale * rng.randn(1000)
+        x = oracle.simplex_projection(v)
+        assert x.min() >= 0 and abs(x.sum() - 1) < 1e-12
+        # idempotent, shift-invariant
+        assert np.allclose(oracle.simplex_projection(x), x, atol=1e-15)
+        if scale <= 1:
+            assert np.allclose(oracle.simplex_projection(v + 7.0 * scale), x, atol=1e-12)
+    # optimality: x = max(v - tau, 0) for one tau
+    v = rng.randn(50)
+    x = oracle.simplex_projection(v)
+    tau = (v - x)[x > 0]
+    assert np.ptp(tau) < 1e-12 and (v[x == 0] <= tau[0] + 1e-12).all()

@@ -1,0 +1,42 @@
+"""
+Build libbluest_hip.so (hand-written HIP for gfx950) in-tree with hipcc.  No GPU is needed to build.
+
+    python -m bluest_amd.build [--force]
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "bluest_hip.hip")
+HDR = os.path.join(ROOT, "include", "bluest_hip.h")
+LIB = os.path.join(HERE, "libbluest_hip.so")
+ARCH = "gfx950"
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin/hipcc)")
+
+
+def up_to_date():
+    return os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(SRC), os.path.getmtime(HDR))
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return LIB
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+           "-o", LIB, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

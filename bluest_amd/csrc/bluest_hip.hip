@@ -1,0 +1,1415 @@
+// bluest_hip.hip -- MI355X (gfx950 / CDNA4) kernels + C-ABI for BLUEST's sample-allocation hot path.
+//
+// What is computed (reference files bluest/*.py, bluest/cmisc.cpp; cited per function in include/bluest_hip.h):
+//   Phi_o(m) = sum_i m_i R_i^T C_i^-1 R_i      (misc.py:459-461, cmisc.cpp:25-40)
+//   V_o      = (Phi_o[idx,idx]^-1)_00          (misc.py:463-477, :490)
+//   grad_o,i = -v[g_i]^T C_i^-1 v[g_i]         (misc.py:493, cmisc.cpp:58-72), v = row 0 of pinv(Phi_o)
+// for every output o of a multi-output problem and a batch of candidate allocations m, all float64.
+//
+// Design: everything here is HBM/L2-streaming integer+f64 work with ~0.2 flop/byte, so there
+// is no MFMA; the levers are coalescing, bytes per entry and launch count.
+//   * Phi pass : destination-major symmetric CSR of psi, cut into wave-sized chunks; one wavefront streams one
+//                chunk with 16-byte loads and gathers m from L2; fixed-order butterfly sum => bit-reproducible
+//                (no float atomics).  Chunk partials are folded per row in a fixed order.
+//   * solve    : one wavefront per (candidate, output): row fold -> LDS, sampled-model masks by ballot,
+//                in-LDS Cholesky restricted to the sampled models, two triangular solves.
+//   * grad pass: group-major tiles of 64 groups, lane = group, packed-symmetric inverse stored entry-major so
+//                every wave-instruction reads 512 contiguous bytes.
+//   * simplex projection: one 1024-thread workgroup, values cached in registers, Michelot/Newton iteration on
+//                the threshold with wavefront shuffles + LDS reductions.
+// No CPU fallback exists in this file.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bluest_hip.h"
+
+// ------------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                        \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess)                                                                                \
+            return fail(BLUEST_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,     \
+                        __LINE__);                                                                           \
+    } while (0)
+
+static int require_gpu()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(BLUEST_ERR_NOGPU, "no HIP device visible (hipGetDeviceCount: %s); libbluest_hip has no CPU path",
+                    e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    }
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_abi_version(void) { return BLUEST_ABI_VERSION; }
+extern "C" const char *bluest_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int bluest_device_count(int *count)
+{
+    if (!count) return fail(BLUEST_ERR_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_device_name(char *buf, int buflen)
+{
+    if (!buf || buflen <= 0) return fail(BLUEST_ERR_ARG, "bad buffer");
+    int rc = require_gpu();
+    if (rc) return rc;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, dev));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return BLUEST_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host<->device staging for the "hd" pointers of Part 1
+// ------------------------------------------------------------------------------------------------------
+static bool is_device_ptr(const void *p)
+{
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+template <typename T>
+struct Staged {  // device view of a host-or-device array; copies back on finish() if writable
+    T *dev = nullptr;
+    T *host = nullptr;
+    size_t count = 0;
+    bool owned = false;
+    int init(const T *p, size_t n, bool copy_in)
+    {
+        count = n;
+        if (n == 0) { dev = nullptr; return BLUEST_OK; }
+        if (is_device_ptr(p)) { dev = const_cast<T *>(p); return BLUEST_OK; }
+        host = const_cast<T *>(p);
+        owned = true;
+        HIP_TRY(hipMalloc((void **)&dev, n * sizeof(T)));
+        if (copy_in) HIP_TRY(hipMemcpy(dev, p, n * sizeof(T), hipMemcpyHostToDevice));
+        return BLUEST_OK;
+    }
+    int finish(bool copy_out)
+    {
+        if (owned && copy_out && count) HIP_TRY(hipMemcpy(host, dev, count * sizeof(T), hipMemcpyDeviceToHost));
+        return BLUEST_OK;
+    }
+    ~Staged() { if (owned && dev) (void)hipFree(dev); }
+};
+
+// ------------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------------
+#define WAVE 64
+
+__device__ __forceinline__ double wave_sum(double x)
+{   // fixed xor-butterfly: every lane ends with the same, order-independent-of-timing sum
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, WAVE);
+    return x;
+}
+__device__ __forceinline__ double wave_max(double x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fmax(x, __shfl_xor(x, off, WAVE));
+    return x;
+}
+__device__ __forceinline__ long long wave_sum_ll(long long x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, WAVE);
+    return x;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Part 1 kernels -- reference layout (int64 groups (Lk,k), f64 invcov (Lk,k,k) row-major)
+// ------------------------------------------------------------------------------------------------------
+
+// cmisc.cpp:10-23.  thread = group i; column i of psi is written with stride Lk => coalesced across lanes.
+__global__ void k_assemble_psi(double *__restrict__ psi, int N, int k, int64_t Lk, const int64_t *__restrict__ g,
+                               const double *__restrict__ ic)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Lk) return;
+    const int64_t *gi = g + i * k;
+    const double *ici = ic + i * (int64_t)k * k;
+    for (int j = 0; j < k; j++) {
+        const int64_t gj = gi[j];
+        for (int l = 0; l < k; l++) psi[Lk * (N * gj + gi[l]) + i] += ici[k * j + l];
+    }
+}
+
+// cmisc.cpp:25-40.  Each workgroup accumulates its slice of groups into an LDS copy of Phi with LDS f64 atomics
+// (ds_add_f64), then writes it as one slab; k_fold_slabs adds the slabs to PHI in a fixed order.
+template <typename MT>
+__global__ void k_objectiveK(double *__restrict__ slabs, int N, int k, int64_t Lk, const MT *__restrict__ mk,
+                             const int64_t *__restrict__ g, const double *__restrict__ ic)
+{
+    extern __shared__ __attribute__((aligned(16))) double sphi[];
+    const int NN = N * N;
+    for (int t = threadIdx.x; t < NN; t += blockDim.x) sphi[t] = 0.0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < Lk; i += (int64_t)gridDim.x * blockDim.x) {
+        const double mi = (double)mk[i];
+        const int64_t *gi = g + i * k;
+        const double *ici = ic + i * (int64_t)k * k;
+        for (int j = 0; j < k; j++) {
+            const int gj = (int)gi[j];
+            for (int l = 0; l < k; l++) atomicAdd(&sphi[N * gj + (int)gi[l]], mi * ici[k * j + l]);
+        }
+    }
+    __syncthreads();
+    double *out = slabs + (int64_t)blockIdx.x * NN;
+    for (int t = threadIdx.x; t < NN; t += blockDim.x) out[t] = sphi[t];
+}
+
+__global__ void k_fold_slabs(double *__restrict__ PHI, const double *__restrict__ slabs, int NN, int nslabs)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= NN) return;
+    double s = 0.0;
+    for (int b = 0; b < nslabs; b++) s += slabs[(int64_t)b * NN + t];
+    PHI[t] += s;
+}
+
+// cmisc.cpp:58-72.  thread = group.
+__global__ void k_gradK(double *__restrict__ grad, int k, int64_t Lk, const int64_t *__restrict__ g,
+                        const double *__restrict__ ic, const double *__restrict__ v, int n_models)
+{
+    __shared__ double sv[BLUEST_MAX_MODELS * 4];
+    for (int t = threadIdx.x; t < n_models; t += blockDim.x) sv[t] = v[t];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Lk) return;
+    const int64_t *gi = g + i * k;
+    const double *ici = ic + i * (int64_t)k * k;
+    double acc = 0.0;
+    for (int j = 0; j < k; j++) {
+        const double vj = sv[gi[j]];
+        for (int l = 0; l < k; l++) acc += vj * ici[k * j + l] * sv[gi[l]];
+    }
+    grad[i] += acc;
+}
+
+// cmisc.cpp:42-56 with the `=` of line 51: the last l written wins, i.e. l = k-1 (a later j with the same
+// model would overwrite too, exactly as the sequential reference does).
+__global__ void k_cleanupK(double *__restrict__ X, int k, int64_t Lk, const int64_t *__restrict__ g,
+                           const double *__restrict__ ic, const double *__restrict__ v)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Lk) return;
+    const int64_t *gi = g + i * k;
+    const double *ici = ic + i * (int64_t)k * k;
+    for (int j = 0; j < k; j++)
+        for (int l = 0; l < k; l++) X[Lk * gi[j] + i] = ici[k * j + l] * v[gi[l]];
+}
+
+// cmisc.cpp:74-97 factored: a_k(ik)_j = sum_l v[gk_l] Ck[l,j]  (k doubles per group), then
+// hess[ik,iq] += sum_{j,j'} a_k(ik)_j invPHI[gk_j, gq_j'] a_q(iq)_j'.
+__global__ void k_hess_avec(double *__restrict__ a, int k, int64_t Lk, const int64_t *__restrict__ g,
+                            const double *__restrict__ ic, const double *__restrict__ v)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Lk) return;
+    const int64_t *gi = g + i * k;
+    const double *ici = ic + i * (int64_t)k * k;
+    for (int j = 0; j < k; j++) {
+        double s = 0.0;
+        for (int l = 0; l < k; l++) s += v[gi[l]] * ici[k * l + j];
+        a[i * k + j] = s;
+    }
+}
+__global__ void k_hessKQ(double *__restrict__ hess, int N, int k, int q, int64_t Lk, int64_t Lq,
+                         const int64_t *__restrict__ gk, const int64_t *__restrict__ gq,
+                         const double *__restrict__ ak, const double *__restrict__ aq,
+                         const double *__restrict__ invPHI)
+{
+    const int64_t iq = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ik = blockIdx.y;
+    if (iq >= Lq || ik >= Lk) return;
+    double s = 0.0;
+    for (int j = 0; j < k; j++) {
+        const double akj = ak[ik * k + j];
+        const double *row = invPHI + (int64_t)N * gk[ik * k + j];
+        for (int jq = 0; jq < q; jq++) s += akj * row[gq[iq * q + jq]] * aq[iq * q + jq];
+    }
+    hess[ik * Lq + iq] += s;
+}
+
+// sap.py:69-79: pinv(C[g,g]) per group by cyclic Jacobi (symmetric eigen-decomposition), thread = group.
+// Matches numpy.linalg.pinv for symmetric input: drop |lambda| <= 1e-15*max|lambda|.
+template <int K>
+__device__ __forceinline__ void sym_pinv_jacobi(double (&A)[K * K], double (&V)[K * K], double *__restrict__ out)
+{
+#pragma unroll
+    for (int i = 0; i < K; i++)
+#pragma unroll
+        for (int j = 0; j < K; j++) V[i * K + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0, diag = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            diag += A[i * K + i] * A[i * K + i];
+#pragma unroll
+            for (int j = i + 1; j < K; j++) off += A[i * K + j] * A[i * K + j];
+        }
+        if (off <= 1e-60 * (diag + off) || off == 0.0) break;
+#pragma unroll
+        for (int p = 0; p < K - 1; p++)
+#pragma unroll
+            for (int q = p + 1; q < K; q++) {
+                const double apq = A[p * K + q];
+                if (apq != 0.0) {
+                    const double theta = (A[q * K + q] - A[p * K + p]) / (2.0 * apq);
+                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                    for (int r = 0; r < K; r++) {
+                        const double arp = A[r * K + p], arq = A[r * K + q];
+                        A[r * K + p] = c * arp - s * arq;
+                        A[r * K + q] = s * arp + c * arq;
+                    }
+#pragma unroll
+                    for (int r = 0; r < K; r++) {
+                        const double apr = A[p * K + r], aqr = A[q * K + r];
+                        A[p * K + r] = c * apr - s * aqr;
+                        A[q * K + r] = s * apr + c * aqr;
+                    }
+#pragma unroll
+                    for (int r = 0; r < K; r++) {
+                        const double vrp = V[r * K + p], vrq = V[r * K + q];
+                        V[r * K + p] = c * vrp - s * vrq;
+                        V[r * K + q] = s * vrp + c * vrq;
+                    }
+                }
+            }
+    }
+    double wmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < K; i++) wmax = fmax(wmax, fabs(A[i * K + i]));
+    const double cut = 1e-15 * wmax;
+#pragma unroll
+    for (int i = 0; i < K; i++)
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            double s = 0.0;
+#pragma unroll
+            for (int e = 0; e < K; e++) {
+                const double w = A[e * K + e];
+                const double inv = (fabs(w) > cut) ? 1.0 / w : 0.0;
+                s += V[i * K + e] * inv * V[j * K + e];
+            }
+            out[i * K + j] = s;
+        }
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void k_group_pinv(const double *__restrict__ C, int N, int64_t Lk, const int64_t *__restrict__ g,
+                             double *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Lk) return;
+    double A[K * K], V[K * K];
+    const int64_t *gi = g + i * K;
+#pragma unroll
+    for (int j = 0; j < K; j++)
+#pragma unroll
+        for (int l = 0; l < K; l++) {
+            const int64_t a = gi[j], b = gi[l];
+            A[j * K + l] = 0.5 * (C[a * N + b] + C[b * N + a]);
+        }
+    sym_pinv_jacobi<K>(A, V, out + i * (int64_t)K * K);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Part 2 -- plan kernels
+// ------------------------------------------------------------------------------------------------------
+
+struct RowDesc {      // one symmetric destination (a <= b) of one output
+    int32_t first_chunk;
+    int32_t n_chunks;
+    int16_t out, a, b, pad;
+};
+
+struct TileDesc {     // 64 groups of equal size k of one output, for the gradient pass
+    int64_t val_off;  // doubles: packed-symmetric entries, [k(k+1)/2][64]
+    int64_t idx_off;  // bytes:   model indices, [k][64]
+    int64_t grad_off; // position of the tile's first group inside the concatenated gradient
+    int32_t n_valid;  // groups in this tile (<= 64)
+    int16_t k, out;
+};
+
+// Phi pass: one wavefront per chunk of CH = 256*iters entries; lane l owns entries [4l, 4l+4) of each 256-block.
+__global__ __launch_bounds__(256) void k_phi_chunks(const double *__restrict__ vals, const int32_t *__restrict__ cols,
+                                                    int iters, int64_t n_chunks, const double *__restrict__ m,
+                                                    int64_t m_stride, int n_cand, double2 *__restrict__ partial)
+{
+    const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (chunk >= n_chunks) return;
+    const int64_t base = chunk * (int64_t)iters * 256 + lane * 4;
+    for (int c = 0; c < n_cand; c++) {
+        const double *mc = m + (int64_t)c * m_stride;
+        double s = 0.0, amax = 0.0;
+        for (int it = 0; it < iters; it++) {
+            const double2 v01 = *reinterpret_cast<const double2 *>(vals + base + it * 256);
+            const double2 v23 = *reinterpret_cast<const double2 *>(vals + base + it * 256 + 2);
+            const int4 cc = *reinterpret_cast<const int4 *>(cols + base + it * 256);
+            const double m0 = mc[cc.x], m1 = mc[cc.y], m2 = mc[cc.z], m3 = mc[cc.w];
+            s = fma(v01.x, m0, s);
+            s = fma(v01.y, m1, s);
+            s = fma(v23.x, m2, s);
+            s = fma(v23.y, m3, s);
+            amax = fmax(fmax(amax, fmax(fabs(m0), fabs(m1))), fmax(fabs(m2), fabs(m3)));
+        }
+        s = wave_sum(s);
+        amax = wave_max(amax);
+        if (lane == 0) partial[(int64_t)c * n_chunks + chunk] = make_double2(s, amax);
+    }
+}
+
+#define LDA (BLUEST_MAX_MODELS + 1)
+struct SolveLds {
+    double phi[BLUEST_MAX_MODELS * BLUEST_MAX_MODELS];  // full symmetric Phi (no delta)
+    double ar[BLUEST_MAX_MODELS * LDA];                 // compacted matrix / Cholesky factor
+    double amax[BLUEST_MAX_MODELS];                     // per model: max |m_i| over groups containing it
+    double rhs[BLUEST_MAX_MODELS];
+    double sol[BLUEST_MAX_MODELS];
+};
+
+// fold chunk partials of output `o`, candidate `c` into lds.phi / lds.amax (one wavefront)
+__device__ __forceinline__ void fold_rows(SolveLds &lds, int N, const RowDesc *__restrict__ rows, int row_begin,
+                                          int n_rows, const double2 *__restrict__ partial, int lane)
+{
+    for (int r = lane; r < n_rows; r += WAVE) {
+        const RowDesc rd = rows[row_begin + r];
+        const double2 *p = partial + rd.first_chunk;
+        double s = 0.0, am = 0.0;
+        int c = 0;
+        for (; c + 4 <= rd.n_chunks; c += 4) {   // 4 loads in flight, summed in chunk order
+            const double2 p0 = p[c], p1 = p[c + 1], p2 = p[c + 2], p3 = p[c + 3];
+            s += p0.x; s += p1.x; s += p2.x; s += p3.x;
+            am = fmax(fmax(am, fmax(p0.y, p1.y)), fmax(p2.y, p3.y));
+        }
+        for (; c < rd.n_chunks; c++) { const double2 p0 = p[c]; s += p0.x; am = fmax(am, p0.y); }
+        lds.phi[rd.a * N + rd.b] = s;
+        lds.phi[rd.b * N + rd.a] = s;
+        if (rd.a == rd.b) lds.amax[rd.a] = am;
+    }
+}
+
+// Cholesky of the leading nr x nr block of lds.ar (row stride LDA), left-looking by columns, lane = row.
+// Returns false if a pivot is not positive.
+__device__ __forceinline__ bool chol_inplace(SolveLds &lds, int nr, int lane)
+{
+    bool ok = true;
+    for (int j = 0; j < nr; j++) {
+        double s = 0.0;
+        if (lane >= j && lane < nr) {
+            s = lds.ar[lane * LDA + j];
+            for (int c = 0; c < j; c++) s = fma(-lds.ar[lane * LDA + c], lds.ar[j * LDA + c], s);
+        }
+        const double piv = __shfl(s, j, WAVE);
+        if (!(piv > 0.0) || !isfinite(piv)) { ok = false; break; }
+        const double d = sqrt(piv);
+        if (lane == j) lds.ar[j * LDA + j] = d;
+        else if (lane > j && lane < nr) lds.ar[lane * LDA + j] = s / d;
+        __syncthreads();
+    }
+    return ok;
+}
+
+// solve (L L^T) x = e_pos using the factor in lds.ar; result in lds.sol[0..nr)
+__device__ __forceinline__ void chol_solve_unit(SolveLds &lds, int nr, int pos, int lane)
+{
+    double r = (lane == pos) ? 1.0 : 0.0;
+    // forward: L y = e_pos
+    for (int c = 0; c < nr; c++) {
+        double yc = 0.0;
+        if (lane == c) { yc = r / lds.ar[c * LDA + c]; lds.sol[c] = yc; }
+        yc = __shfl(yc, c, WAVE);
+        if (lane > c && lane < nr) r = fma(-lds.ar[lane * LDA + c], yc, r);
+    }
+    __syncthreads();
+    r = (lane < nr) ? lds.sol[lane] : 0.0;
+    // backward: L^T x = y
+    for (int c = nr - 1; c >= 0; c--) {
+        double xc = 0.0;
+        if (lane == c) { xc = r / lds.ar[c * LDA + c]; }
+        xc = __shfl(xc, c, WAVE);
+        if (lane == c) lds.sol[c] = xc;
+        if (lane < c) r = fma(-lds.ar[c * LDA + lane], xc, r);
+    }
+    __syncthreads();
+}
+
+// Given lds.phi / lds.amax (and `big` = max|m| >= 0.05), produce V, v, status for one (candidate, output).
+__device__ __forceinline__ void solve_core(SolveLds &lds, int N, double delta, bool s1, bool s2, bool big,
+                                           double *__restrict__ var_out, double *__restrict__ v_out,
+                                           int32_t *__restrict__ status_out, int lane)
+{
+    // mask1: models touched by a group with |m| > 1e-6 (misc.py:453-457) -> V; mask2: support of Phi+delta*I -> v
+    const unsigned long long mask1 = __ballot(lane < N && s1);
+    const unsigned long long mask2 = (delta != 0.0) ? __ballot(lane < N) : __ballot(lane < N && s2);
+    int status = BLUEST_EVAL_OK;
+    double V = 0.0;
+    double vmine = 0.0;  // v[lane]
+    if (!big) {
+        status = BLUEST_EVAL_INF;
+        V = INFINITY;
+    } else {
+        if (!(mask1 & 1ull)) status = BLUEST_EVAL_NO_MODEL0;
+        const int npass = (mask1 == mask2) ? 1 : 2;
+        for (int pass = 0; pass < npass; pass++) {
+            const unsigned long long mask = (pass == 0) ? mask1 : mask2;
+            const int nr = __popcll(mask);
+            const bool mine = lane < N && ((mask >> lane) & 1ull);
+            const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+            __syncthreads();
+            if (mine) {
+                int cb = 0;
+                for (int b = 0; b < N; b++)
+                    if ((mask >> b) & 1ull) {
+                        double x = lds.phi[lane * N + b];
+                        if (b == lane) x += delta;
+                        lds.ar[pos * LDA + cb] = x;
+                        cb++;
+                    }
+            }
+            __syncthreads();
+            if (nr == 0) { if (pass == 0) V = NAN; continue; }
+            const bool ok = chol_inplace(lds, nr, lane);
+            __syncthreads();
+            if (!ok) {
+                if (status == BLUEST_EVAL_OK) status = BLUEST_EVAL_SINGULAR;
+                if (pass == 0) V = NAN;
+                if (pass == npass - 1) vmine = NAN;
+                continue;
+            }
+            if (pass == 0) {
+                chol_solve_unit(lds, nr, 0, lane);  // e_0 of the restricted system (misc.py:472,490)
+                V = lds.sol[0];
+                if (npass == 1) {  // same block serves v: row 0 of pinv(Phi) is this solution iff model 0 is in it
+                    vmine = (mine && (mask & 1ull)) ? lds.sol[pos] : 0.0;
+                }
+            } else {
+                if (mask & 1ull) {
+                    chol_solve_unit(lds, nr, 0, lane);
+                    vmine = mine ? lds.sol[pos] : 0.0;
+                } else {
+                    vmine = 0.0;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (lane < N) v_out[lane] = vmine;
+    if (lane == 0) { *var_out = V; *status_out = status; }
+}
+
+// fused: fold chunk partials + solve.  grid = (n_out, n_cand), block = 64.
+__global__ __launch_bounds__(64) void k_solve_from_chunks(int N, int n_out, const RowDesc *__restrict__ rows,
+                                                          const int32_t *__restrict__ out_row_begin,
+                                                          const double2 *__restrict__ partial, int64_t n_chunks,
+                                                          double delta, double *__restrict__ var,
+                                                          double *__restrict__ v, int32_t *__restrict__ status)
+{
+    __shared__ SolveLds lds;
+    const int o = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
+    if (lane < N) lds.amax[lane] = 0.0;
+    for (int t = lane; t < N * N; t += WAVE) lds.phi[t] = 0.0;
+    __syncthreads();
+    fold_rows(lds, N, rows, out_row_begin[o], out_row_begin[o + 1] - out_row_begin[o],
+              partial + (int64_t)c * n_chunks, lane);
+    __syncthreads();
+    const double am = (lane < N) ? lds.amax[lane] : 0.0;
+    const bool big = wave_max(am) >= 0.05;
+    const int64_t e = (int64_t)c * n_out + o;
+    solve_core(lds, N, delta, am > 1.0e-6, am > 0.0, big, var + e, v + e * N, status + e, lane);
+}
+
+// multi-GPU path, phase A tail: fold chunk partials into an all-reduce-able record.
+__global__ __launch_bounds__(64) void k_fold_to_record(int N, int n_out, const RowDesc *__restrict__ rows,
+                                                       const int32_t *__restrict__ out_row_begin,
+                                                       const double2 *__restrict__ partial, int64_t n_chunks,
+                                                       double *__restrict__ rec)
+{
+    __shared__ SolveLds lds;
+    const int o = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
+    if (lane < N) lds.amax[lane] = 0.0;
+    for (int t = lane; t < N * N; t += WAVE) lds.phi[t] = 0.0;
+    __syncthreads();
+    fold_rows(lds, N, rows, out_row_begin[o], out_row_begin[o + 1] - out_row_begin[o],
+              partial + (int64_t)c * n_chunks, lane);
+    __syncthreads();
+    const int reclen = N * N + 2 * N + 1;
+    double *r = rec + ((int64_t)c * n_out + o) * reclen;
+    for (int t = lane; t < N * N; t += WAVE) r[t] = lds.phi[t];
+    const double am = (lane < N) ? lds.amax[lane] : 0.0;
+    if (lane < N) { r[N * N + lane] = (am > 1.0e-6) ? 1.0 : 0.0; r[N * N + N + lane] = (am > 0.0) ? 1.0 : 0.0; }
+    const double big = wave_max(am);
+    if (lane == 0) r[N * N + 2 * N] = (big >= 0.05) ? 1.0 : 0.0;
+}
+
+// multi-GPU path, phase B: solve from an (all-reduced) record.
+__global__ __launch_bounds__(64) void k_solve_from_record(int N, int n_out, const double *__restrict__ rec,
+                                                          double delta, double *__restrict__ var,
+                                                          double *__restrict__ v, int32_t *__restrict__ status)
+{
+    __shared__ SolveLds lds;
+    const int o = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
+    const int reclen = N * N + 2 * N + 1;
+    const double *r = rec + ((int64_t)c * n_out + o) * reclen;
+    for (int t = lane; t < N * N; t += WAVE) lds.phi[t] = r[t];
+    __syncthreads();
+    const bool s1 = lane < N && r[N * N + lane] > 0.0;
+    const bool s2 = lane < N && r[N * N + N + lane] > 0.0;
+    const bool big = r[N * N + 2 * N] > 0.0;
+    const int64_t e = (int64_t)c * n_out + o;
+    solve_core(lds, N, delta, s1, s2, big, var + e, v + e * N, status + e, lane);
+}
+
+// gradient pass: one wavefront per tile, lane = group.  q = sum_j v_j (s_jj v_j + 2 sum_{l>j} s_jl v_l).
+template <int K>
+__device__ __forceinline__ void grad_tile(const TileDesc &td, const double *__restrict__ tvals,
+                                          const uint8_t *__restrict__ tidx, const double *__restrict__ v,
+                                          const int32_t *__restrict__ status, int N, int n_out, int n_cand,
+                                          double *__restrict__ grad, int64_t grad_stride, int lane)
+{
+    const double *vals = tvals + td.val_off + lane;
+    const uint8_t *idx = tidx + td.idx_off + lane;
+    int gi[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) gi[j] = idx[j * 64];
+    double s[K * (K + 1) / 2];
+#pragma unroll
+    for (int e = 0; e < K * (K + 1) / 2; e++) s[e] = vals[e * 64];
+    for (int c = 0; c < n_cand; c++) {
+        const int64_t eo = (int64_t)c * n_out + td.out;
+        const double *vc = v + eo * N;
+        double vj[K];
+#pragma unroll
+        for (int j = 0; j < K; j++) vj[j] = vc[gi[j]];
+        double q = 0.0;
+        int e = 0;
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            double t = 0.0;
+#pragma unroll
+            for (int l = j + 1; l < K; l++) t = fma(s[e + (l - j)], vj[l], t);
+            t = fma(s[e], vj[j], 2.0 * t);
+            q = fma(vj[j], t, q);
+            e += K - j;
+        }
+        if (lane < td.n_valid)
+            grad[(int64_t)c * grad_stride + td.grad_off + lane] = (status[eo] == BLUEST_EVAL_INF) ? INFINITY : -q;
+    }
+}
+
+// generic k (9..16): entries re-read per candidate, no big register arrays
+__device__ __forceinline__ void grad_tile_generic(const TileDesc &td, const double *__restrict__ tvals,
+                                                  const uint8_t *__restrict__ tidx, const double *__restrict__ v,
+                                                  const int32_t *__restrict__ status, int N, int n_out, int n_cand,
+                                                  double *__restrict__ grad, int64_t grad_stride, int lane)
+{
+    const int K = td.k;
+    const double *vals = tvals + td.val_off + lane;
+    const uint8_t *idx = tidx + td.idx_off + lane;
+    for (int c = 0; c < n_cand; c++) {
+        const int64_t eo = (int64_t)c * n_out + td.out;
+        const double *vc = v + eo * N;
+        double q = 0.0;
+        int e = 0;
+        for (int j = 0; j < K; j++) {
+            const double vjj = vc[idx[j * 64]];
+            double t = 0.0;
+            for (int l = j + 1; l < K; l++) t = fma(vals[(e + (l - j)) * 64], vc[idx[l * 64]], t);
+            t = fma(vals[e * 64], vjj, 2.0 * t);
+            q = fma(vjj, t, q);
+            e += K - j;
+        }
+        if (lane < td.n_valid)
+            grad[(int64_t)c * grad_stride + td.grad_off + lane] = (status[eo] == BLUEST_EVAL_INF) ? INFINITY : -q;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_grad_tiles(const TileDesc *__restrict__ tiles, int64_t n_tiles,
+                                                    const double *__restrict__ tvals,
+                                                    const uint8_t *__restrict__ tidx, const double *__restrict__ v,
+                                                    const int32_t *__restrict__ status, int N, int n_out, int n_cand,
+                                                    double *__restrict__ grad, int64_t grad_stride)
+{
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= n_tiles) return;
+    const TileDesc td = tiles[t];
+#define GT(KK) case KK: grad_tile<KK>(td, tvals, tidx, v, status, N, n_out, n_cand, grad, grad_stride, lane); break;
+    switch (td.k) {
+        GT(1) GT(2) GT(3) GT(4) GT(5) GT(6) GT(7) GT(8)
+        default: grad_tile_generic(td, tvals, tidx, v, status, N, n_out, n_cand, grad, grad_stride, lane);
+    }
+#undef GT
+}
+
+// out[c][j] = scale[j] * sum_o coef[c][o] * grad_o[c][invmap_o[j]]
+__global__ void k_combine_grad(const double *__restrict__ grad, int64_t grad_stride, const int64_t *__restrict__ goff,
+                               const int32_t *__restrict__ invmap, int64_t L, int n_out,
+                               const double *__restrict__ coef, const double *__restrict__ scale, int n_cand,
+                               double *__restrict__ out, int64_t out_stride)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (j >= L || c >= n_cand) return;
+    double s = 0.0;
+    for (int o = 0; o < n_out; o++) {
+        const int32_t li = invmap[(int64_t)o * L + j];
+        if (li >= 0) s = fma(coef[(int64_t)c * n_out + o], grad[(int64_t)c * grad_stride + goff[o] + li], s);
+    }
+    out[(int64_t)c * out_stride + j] = scale ? scale[j] * s : s;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Part 3 -- simplex projection (single workgroup of 1024 threads)
+// ------------------------------------------------------------------------------------------------------
+struct ProjLds {
+    double dsum[16];
+    double dmax[16];
+    long long cnt[16];
+};
+
+__device__ __forceinline__ double block_max(double x, ProjLds &s, int tid)
+{
+    x = wave_max(x);
+    __syncthreads();
+    if ((tid & 63) == 0) s.dmax[tid >> 6] = x;
+    __syncthreads();
+    double r = s.dmax[0];
+    const int nw = blockDim.x >> 6;
+    for (int w = 1; w < nw; w++) r = fmax(r, s.dmax[w]);
+    return r;
+}
+__device__ __forceinline__ void block_sum_cnt(double &x, long long &n, ProjLds &s, int tid)
+{
+    x = wave_sum(x);
+    n = wave_sum_ll(n);
+    __syncthreads();
+    if ((tid & 63) == 0) { s.dsum[tid >> 6] = x; s.cnt[tid >> 6] = n; }
+    __syncthreads();
+    double r = s.dsum[0];
+    long long c = s.cnt[0];
+    const int nw = blockDim.x >> 6;
+    for (int w = 1; w < nw; w++) { r += s.dsum[w]; c += s.cnt[w]; }
+    x = r;
+    n = c;
+}
+
+// ITEMS > 0: u cached in registers (L <= 1024*ITEMS); ITEMS == 0: u recomputed from x,g every pass.
+template <int ITEMS>
+__global__ __launch_bounds__(1024) void k_simplex(const double *__restrict__ x, const double *__restrict__ g,
+                                                  double lambda, double z, int64_t L, double *__restrict__ p,
+                                                  double *__restrict__ d, double *__restrict__ stats)
+{
+    __shared__ ProjLds s;
+    const int tid = threadIdx.x;
+    constexpr int R = ITEMS > 0 ? ITEMS : 1;
+    double u[R];
+    auto load_u = [&](int64_t i) -> double { return g ? fma(-lambda, g[i], x[i]) : x[i]; };
+
+    double umax = -INFINITY;
+    if (ITEMS > 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int64_t i = (int64_t)r * 1024 + tid;
+            u[r] = (i < L) ? load_u(i) : -INFINITY;
+            umax = fmax(umax, u[r]);
+        }
+    } else {
+        for (int64_t i = tid; i < L; i += 1024) umax = fmax(umax, load_u(i));
+    }
+    umax = block_max(umax, s, tid);
+    if (ITEMS > 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++) u[r] -= umax;   // shift-invariance: all values <= 0, threshold in [-z, 0)
+    }
+    double tau = -z;
+    long long prev = -1;
+    for (int iter = 0; iter < 200; iter++) {
+        double sum = 0.0;
+        long long cnt = 0;
+        if (ITEMS > 0) {
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (u[r] > tau) { sum += u[r]; cnt++; }
+        } else {
+            for (int64_t i = tid; i < L; i += 1024) {
+                const double ui = load_u(i) - umax;
+                if (ui > tau) { sum += ui; cnt++; }
+            }
+        }
+        block_sum_cnt(sum, cnt, s, tid);
+        if (cnt == prev || cnt == 0) break;
+        prev = cnt;
+        tau = (sum - z) / (double)cnt;
+    }
+    double gd = 0.0, dmax = 0.0;
+    long long npos = 0;
+    auto emit = [&](int64_t i, double ui) {
+        const double pi = fmax(ui - tau, 0.0);
+        const double di = pi - x[i];
+        if (p) p[i] = pi;
+        if (d) d[i] = di;
+        if (g) gd = fma(g[i], di, gd);
+        dmax = fmax(dmax, fabs(di));
+        npos += (pi > 0.0);
+    };
+    if (ITEMS > 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int64_t i = (int64_t)r * 1024 + tid;
+            if (i < L) emit(i, u[r]);
+        }
+    } else {
+        for (int64_t i = tid; i < L; i += 1024) emit(i, load_u(i) - umax);
+    }
+    block_sum_cnt(gd, npos, s, tid);
+    dmax = block_max(dmax, s, tid);
+    if (tid == 0 && stats) {
+        stats[0] = gd;
+        stats[1] = dmax;
+        stats[2] = tau;
+        stats[3] = (double)npos;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Part 1 host entry points
+// ------------------------------------------------------------------------------------------------------
+static int check_cmisc_args(int N, int k, int64_t Lk)
+{
+    if (N <= 0 || N > 4096) return fail(BLUEST_ERR_ARG, "N=%d out of range", N);
+    if (k <= 0 || k > 64) return fail(BLUEST_ERR_ARG, "k=%d out of range", k);
+    if (Lk < 0) return fail(BLUEST_ERR_ARG, "Lk=%lld negative", (long long)Lk);
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_assemble_psi(double *psi, int N, int k, int64_t Lk, const int64_t *g, const double *ic)
+{
+    int rc = require_gpu(); if (rc) return rc;
+    rc = check_cmisc_args(N, k, Lk); if (rc) return rc;
+    if (Lk == 0) return BLUEST_OK;
+    if (!psi || !g || !ic) return fail(BLUEST_ERR_ARG, "null pointer");
+    Staged<double> s_psi, s_ic; Staged<int64_t> s_g;
+    if ((rc = s_psi.init(psi, (size_t)N * N * Lk, true))) return rc;
+    if ((rc = s_g.init(g, (size_t)Lk * k, true))) return rc;
+    if ((rc = s_ic.init(ic, (size_t)Lk * k * k, true))) return rc;
+    hipLaunchKernelGGL(k_assemble_psi, dim3((unsigned)((Lk + 255) / 256)), dim3(256), 0, 0, s_psi.dev, N, k, Lk, s_g.dev, s_ic.dev);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return s_psi.finish(true);
+}
+
+template <typename MT>
+static int objectiveK_impl(double *PHI, int N, int k, int64_t Lk, const MT *mk, const int64_t *g, const double *ic)
+{
+    int rc = require_gpu(); if (rc) return rc;
+    rc = check_cmisc_args(N, k, Lk); if (rc) return rc;
+    if (N > 128) return fail(BLUEST_ERR_ARG, "N=%d > 128 unsupported by the LDS-privatised Phi kernel", N);
+    if (Lk == 0) return BLUEST_OK;
+    if (!PHI || !mk || !g || !ic) return fail(BLUEST_ERR_ARG, "null pointer");
+    Staged<double> s_phi, s_ic; Staged<int64_t> s_g; Staged<MT> s_m;
+    if ((rc = s_phi.init(PHI, (size_t)N * N, true))) return rc;
+    if ((rc = s_m.init(mk, (size_t)Lk, true))) return rc;
+    if ((rc = s_g.init(g, (size_t)Lk * k, true))) return rc;
+    if ((rc = s_ic.init(ic, (size_t)Lk * k * k, true))) return rc;
+    const int NN = N * N;
+    int nblocks = (int)std::min<int64_t>((Lk + 255) / 256, 1024);
+    double *slabs = nullptr;
+    HIP_TRY(hipMalloc((void **)&slabs, (size_t)nblocks * NN * sizeof(double)));
+    hipLaunchKernelGGL((k_objectiveK<MT>), dim3(nblocks), dim3(256), NN * sizeof(double), 0, slabs, N, k, Lk, s_m.dev, s_g.dev, s_ic.dev);
+    hipLaunchKernelGGL(k_fold_slabs, dim3((NN + 255) / 256), dim3(256), 0, 0, s_phi.dev, slabs, NN, nblocks);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(slabs);
+    HIP_TRY(e);
+    return s_phi.finish(true);
+}
+
+extern "C" int bluest_objectiveK_f64(double *PHI, int N, int k, int64_t Lk, const double *mk, const int64_t *g, const double *ic)
+{ return objectiveK_impl<double>(PHI, N, k, Lk, mk, g, ic); }
+extern "C" int bluest_objectiveK_i64(double *PHI, int N, int k, int64_t Lk, const int64_t *mk, const int64_t *g, const double *ic)
+{ return objectiveK_impl<int64_t>(PHI, N, k, Lk, mk, g, ic); }
+
+extern "C" int bluest_gradK(double *grad, int k, int64_t Lk, const int64_t *g, const double *ic, const double *v, int n_models)
+{
+    int rc = require_gpu(); if (rc) return rc;
+    rc = check_cmisc_args(n_models, k, Lk); if (rc) return rc;
+    if (n_models > BLUEST_MAX_MODELS * 4) return fail(BLUEST_ERR_ARG, "n_models=%d > %d", n_models, BLUEST_MAX_MODELS * 4);
+    if (Lk == 0) return BLUEST_OK;
+    if (!grad || !g || !ic || !v) return fail(BLUEST_ERR_ARG, "null pointer");
+    Staged<double> s_grad, s_ic, s_v; Staged<int64_t> s_g;
+    if ((rc = s_grad.init(grad, (size_t)Lk, true))) return rc;
+    if ((rc = s_g.init(g, (size_t)Lk * k, true))) return rc;
+    if ((rc = s_ic.init(ic, (size_t)Lk * k * k, true))) return rc;
+    if ((rc = s_v.init(v, (size_t)n_models, true))) return rc;
+    hipLaunchKernelGGL(k_gradK, dim3((unsigned)((Lk + 255) / 256)), dim3(256), 0, 0, s_grad.dev, k, Lk, s_g.dev, s_ic.dev, s_v.dev, n_models);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return s_grad.finish(true);
+}
+
+extern "C" int bluest_cleanupK(double *X, int k, int64_t Lk, const int64_t *g, const double *ic, const double *v, int n_models)
+{
+    int rc = require_gpu(); if (rc) return rc;
+    rc = check_cmisc_args(n_models, k, Lk); if (rc) return rc;
+    if (Lk == 0) return BLUEST_OK;
+    if (!X || !g || !ic || !v) return fail(BLUEST_ERR_ARG, "null pointer");
+    Staged<double> s_X, s_ic, s_v; Staged<int64_t> s_g;
+    if ((rc = s_X.init(X, (size_t)n_models * Lk, true))) return rc;
+    if ((rc = s_g.init(g, (size_t)Lk * k, true))) return rc;
+    if ((rc = s_ic.init(ic, (size_t)Lk * k * k, true))) return rc;
+    if ((rc = s_v.init(v, (size_t)n_models, true))) return rc;
+    hipLaunchKernelGGL(k_cleanupK, dim3((unsigned)((Lk + 255) / 256)), dim3(256), 0, 0, s_X.dev, k, Lk, s_g.dev, s_ic.dev, s_v.dev);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return s_X.finish(true);
+}
+
+extern "C" int bluest_hessKQ(double *hess, int N, int k, int q, int64_t Lk, int64_t Lq, const int64_t *gk, const int64_t *gq,
+                             const double *ick, const double *icq, const double *invPHI)
+{
+    int rc = require_gpu(); if (rc) return rc;
+    rc = check_cmisc_args(N, k, Lk); if (rc) return rc;
+    rc = check_cmisc_args(N, q, Lq); if (rc) return rc;
+    if (Lk == 0 || Lq == 0) return BLUEST_OK;
+    if (Lk > 65535) return fail(BLUEST_ERR_ARG, "Lk=%lld > 65535: the (Lk,Lq) Hessian block is not meant for this size", (long long)Lk);
+    if (!hess || !gk || !gq || !ick || !icq || !invPHI) return fail(BLUEST_ERR_ARG, "null pointer");
+    Staged<double> s_h, s_ick, s_icq, s_P; Staged<int64_t> s_gk, s_gq;
+    if ((rc = s_h.init(hess, (size_t)Lk * Lq, true))) return rc;
+    if ((rc = s_gk.init(gk, (size_t)Lk * k, true))) return rc;
+    if ((rc = s_gq.init(gq, (size_t)Lq * q, true))) return rc;
+    if ((rc = s_ick.init(ick, (size_t)Lk * k * k, true))) return rc;
+    if ((rc = s_icq.init(icq, (size_t)Lq * q * q, true))) return rc;
+    if ((rc = s_P.init(invPHI, (size_t)N * N, true))) return rc;
+    double *ak = nullptr, *aq = nullptr;
+    HIP_TRY(hipMalloc((void **)&ak, (size_t)Lk * k * sizeof(double)));
+    hipError_t e = hipMalloc((void **)&aq, (size_t)Lq * q * sizeof(double));
+    if (e != hipSuccess) { (void)hipFree(ak); HIP_TRY(e); }
+    hipLaunchKernelGGL(k_hess_avec, dim3((unsigned)((Lk + 255) / 256)), dim3(256), 0, 0, ak, k, Lk, s_gk.dev, s_ick.dev, s_P.dev);
+    hipLaunchKernelGGL(k_hess_avec, dim3((unsigned)((Lq + 255) / 256)), dim3(256), 0, 0, aq, q, Lq, s_gq.dev, s_icq.dev, s_P.dev);
+    hipLaunchKernelGGL(k_hessKQ, dim3((unsigned)((Lq + 127) / 128), (unsigned)Lk), dim3(128), 0, 0, s_h.dev, N, k, q, Lk, Lq,
+                       s_gk.dev, s_gq.dev, ak, aq, s_P.dev);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(ak); (void)hipFree(aq);
+    HIP_TRY(e);
+    return s_h.finish(true);
+}
+
+static int launch_group_pinv(const double *dC, int N, int k, int64_t Lk, const int64_t *dg, double *dout, hipStream_t st)
+{
+    const dim3 grid((unsigned)((Lk + 63) / 64)), block(64);
+#define GP(KK) case KK: hipLaunchKernelGGL((k_group_pinv<KK>), grid, block, 0, st, dC, N, Lk, dg, dout); break;
+    switch (k) {
+        GP(1) GP(2) GP(3) GP(4) GP(5) GP(6) GP(7) GP(8) GP(9) GP(10) GP(11) GP(12) GP(13) GP(14) GP(15) GP(16)
+        default: return fail(BLUEST_ERR_ARG, "group size k=%d > %d", k, BLUEST_MAX_GROUP);
+    }
+#undef GP
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_group_pinv(const double *C, int N, int k, int64_t Lk, const int64_t *g, double *out)
+{
+    int rc = require_gpu(); if (rc) return rc;
+    rc = check_cmisc_args(N, k, Lk); if (rc) return rc;
+    if (Lk == 0) return BLUEST_OK;
+    if (!C || !g || !out) return fail(BLUEST_ERR_ARG, "null pointer");
+    Staged<double> s_C, s_out; Staged<int64_t> s_g;
+    if ((rc = s_C.init(C, (size_t)N * N, true))) return rc;
+    if ((rc = s_g.init(g, (size_t)Lk * k, true))) return rc;
+    if ((rc = s_out.init(out, (size_t)Lk * k * k, false))) return rc;
+    if ((rc = launch_group_pinv(s_C.dev, N, k, Lk, s_g.dev, s_out.dev, 0))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return s_out.finish(true);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Part 2 host side: the plan
+// ------------------------------------------------------------------------------------------------------
+struct OutputDesc {
+    int K = 0;
+    std::vector<int64_t> sizes;    // K entries
+    std::vector<int64_t> groups;   // concat (L_k * k)
+    std::vector<double> invcovs;   // concat (L_k * k * k)
+    std::vector<int64_t> mapping;  // L_o global indices
+    int64_t L_o = 0;
+};
+
+struct bluest_plan_s {
+    int N = 0;
+    int64_t L = 0;
+    std::vector<OutputDesc> outs;
+    bool finalized = false;
+    int max_cand = 0;
+    int iters = 1;  // chunk = 256*iters entries
+    int64_t n_chunks = 0, n_rows = 0, n_tiles = 0, grad_len = 0;
+    std::vector<int64_t> grad_off;
+    int64_t phi_bytes = 0, grad_bytes = 0;
+    // device
+    double *d_vals = nullptr;
+    int32_t *d_cols = nullptr;
+    RowDesc *d_rows = nullptr;
+    int32_t *d_out_row_begin = nullptr;
+    TileDesc *d_tiles = nullptr;
+    double *d_tvals = nullptr;
+    uint8_t *d_tidx = nullptr;
+    int32_t *d_invmap = nullptr;
+    int64_t *d_goff = nullptr;
+    double2 *d_partial = nullptr;
+    double *d_v = nullptr;       // workspace for eval
+    int32_t *d_status = nullptr; // workspace for eval when caller passes NULL
+};
+
+static void plan_free_device(bluest_plan_s *p)
+{
+    void *ptrs[] = {p->d_vals, p->d_cols, p->d_rows, p->d_out_row_begin, p->d_tiles, p->d_tvals, p->d_tidx,
+                    p->d_invmap, p->d_goff, p->d_partial, p->d_v, p->d_status};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+}
+
+extern "C" int bluest_plan_create(bluest_plan_t *plan, int n_models, int64_t L_global)
+{
+    if (!plan) return fail(BLUEST_ERR_ARG, "plan is NULL");
+    if (n_models <= 0 || n_models > BLUEST_MAX_MODELS)
+        return fail(BLUEST_ERR_ARG, "n_models=%d out of range (1..%d)", n_models, BLUEST_MAX_MODELS);
+    if (L_global <= 0 || L_global > 0x7fffffffLL) return fail(BLUEST_ERR_ARG, "L_global=%lld out of range", (long long)L_global);
+    int rc = require_gpu(); if (rc) return rc;
+    bluest_plan_s *p = new bluest_plan_s();
+    p->N = n_models;
+    p->L = L_global;
+    *plan = p;
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_destroy(bluest_plan_t plan)
+{
+    if (!plan) return BLUEST_OK;
+    plan_free_device(plan);
+    delete plan;
+    return BLUEST_OK;
+}
+
+static int plan_add_common(bluest_plan_t plan, int K, const int64_t *sizes, const int64_t *groups, const int64_t *mapping,
+                           OutputDesc &od)
+{
+    if (!plan) return fail(BLUEST_ERR_ARG, "plan is NULL");
+    if (plan->finalized) return fail(BLUEST_ERR_STATE, "plan already finalized");
+    if (K <= 0 || K > BLUEST_MAX_GROUP) return fail(BLUEST_ERR_ARG, "K=%d out of range (1..%d)", K, BLUEST_MAX_GROUP);
+    if (!sizes || !groups) return fail(BLUEST_ERR_ARG, "null pointer");
+    if ((int)plan->outs.size() >= 32767) return fail(BLUEST_ERR_ARG, "too many outputs");
+    od.K = K;
+    od.sizes.assign(sizes, sizes + K);
+    int64_t L_o = 0, ng = 0;
+    for (int k = 1; k <= K; k++) {
+        if (sizes[k - 1] < 0) return fail(BLUEST_ERR_ARG, "negative size");
+        L_o += sizes[k - 1];
+        ng += sizes[k - 1] * k;
+    }
+    if (L_o <= 0) return fail(BLUEST_ERR_ARG, "output has no groups");
+    od.L_o = L_o;
+    od.groups.assign(groups, groups + ng);
+    for (int64_t t = 0; t < ng; t++)
+        if (groups[t] < 0 || groups[t] >= plan->N) return fail(BLUEST_ERR_ARG, "model index %lld out of range", (long long)groups[t]);
+    if (mapping) {
+        od.mapping.assign(mapping, mapping + L_o);
+        for (int64_t t = 0; t < L_o; t++)
+            if (mapping[t] < 0 || mapping[t] >= plan->L) return fail(BLUEST_ERR_ARG, "mapping index %lld out of range", (long long)mapping[t]);
+    } else {
+        if (L_o != plan->L) return fail(BLUEST_ERR_ARG, "identity mapping needs L_o == L_global (%lld vs %lld)", (long long)L_o, (long long)plan->L);
+        od.mapping.resize(L_o);
+        for (int64_t t = 0; t < L_o; t++) od.mapping[t] = t;
+    }
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_add_output(bluest_plan_t plan, int K, const int64_t *sizes, const int64_t *groups,
+                                      const double *invcovs, const int64_t *mapping)
+{
+    OutputDesc od;
+    int rc = plan_add_common(plan, K, sizes, groups, mapping, od);
+    if (rc) return rc;
+    if (!invcovs) return fail(BLUEST_ERR_ARG, "invcovs is NULL");
+    int64_t ni = 0;
+    for (int k = 1; k <= K; k++) ni += sizes[k - 1] * k * k;
+    od.invcovs.assign(invcovs, invcovs + ni);
+    plan->outs.push_back(std::move(od));
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_add_output_cov(bluest_plan_t plan, const double *C, int K, const int64_t *sizes,
+                                          const int64_t *groups, const int64_t *mapping, double *invcovs_out)
+{
+    OutputDesc od;
+    int rc = plan_add_common(plan, K, sizes, groups, mapping, od);
+    if (rc) return rc;
+    if (!C) return fail(BLUEST_ERR_ARG, "C is NULL");
+    const int N = plan->N;
+    int64_t ni = 0, ng = 0;
+    for (int k = 1; k <= K; k++) { ni += sizes[k - 1] * k * k; ng += sizes[k - 1] * k; }
+    od.invcovs.resize(ni);
+    double *dC = nullptr, *dic = nullptr;
+    int64_t *dg = nullptr;
+    HIP_TRY(hipMalloc((void **)&dC, (size_t)N * N * sizeof(double)));
+    hipError_t e = hipMalloc((void **)&dic, (size_t)ni * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&dg, (size_t)ng * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMemcpy(dC, C, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dg, groups, (size_t)ng * sizeof(int64_t), hipMemcpyHostToDevice);
+    rc = BLUEST_OK;
+    if (e == hipSuccess) {
+        int64_t go = 0, io = 0;
+        for (int k = 1; k <= K && rc == BLUEST_OK; k++) {
+            const int64_t Lk = sizes[k - 1];
+            if (Lk > 0) rc = launch_group_pinv(dC, N, k, Lk, dg + go, dic + io, 0);
+            go += Lk * k; io += Lk * k * k;
+        }
+        if (rc == BLUEST_OK) e = hipMemcpy(od.invcovs.data(), dic, (size_t)ni * sizeof(double), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(dC); (void)hipFree(dic); (void)hipFree(dg);
+    if (rc) return rc;
+    HIP_TRY(e);
+    if (invcovs_out) memcpy(invcovs_out, od.invcovs.data(), (size_t)ni * sizeof(double));
+    plan->outs.push_back(std::move(od));
+    return BLUEST_OK;
+}
+
+template <typename T>
+static int upload(T **dst, const std::vector<T> &src)
+{
+    *dst = nullptr;
+    const size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc((void **)dst, bytes));
+    if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
+{
+    if (!plan) return fail(BLUEST_ERR_ARG, "plan is NULL");
+    if (plan->finalized) return fail(BLUEST_ERR_STATE, "plan already finalized");
+    if (plan->outs.empty()) return fail(BLUEST_ERR_STATE, "plan has no outputs");
+    if (max_candidates <= 0 || max_candidates > 65535) return fail(BLUEST_ERR_ARG, "max_candidates=%d out of range", max_candidates);
+    const int N = plan->N, n_out = (int)plan->outs.size();
+    const int nsym = N * (N + 1) / 2;
+    auto tri = [N](int a, int b) { return a * N - a * (a - 1) / 2 + (b - a); };
+
+    // ---- Phi pass: destination-major symmetric CSR ------------------------------------------------
+    // count entries per (output,row); pick the chunk size so that no row needs more than 64 chunks
+    std::vector<std::vector<int64_t>> counts(n_out, std::vector<int64_t>(nsym, 0));
+    int64_t max_row = 0;
+    for (int o = 0; o < n_out; o++) {
+        const OutputDesc &od = plan->outs[o];
+        int64_t go = 0;
+        for (int k = 1; k <= od.K; k++) {
+            for (int64_t i = 0; i < od.sizes[k - 1]; i++) {
+                const int64_t *g = od.groups.data() + go + i * k;
+                for (int j = 0; j < k; j++)
+                    for (int l = j; l < k; l++) counts[o][tri((int)std::min(g[j], g[l]), (int)std::max(g[j], g[l]))]++;
+            }
+            go += od.sizes[k - 1] * k;
+        }
+        for (int r = 0; r < nsym; r++) max_row = std::max(max_row, counts[o][r]);
+    }
+    int iters = 1;
+    while ((max_row + 256LL * iters - 1) / (256LL * iters) > 64 && iters < 1024) iters *= 2;
+    const int64_t CH = 256LL * iters;
+    plan->iters = iters;
+
+    std::vector<RowDesc> rows((size_t)n_out * nsym);
+    std::vector<int32_t> out_row_begin(n_out + 1);
+    int64_t n_chunks = 0;
+    for (int o = 0; o < n_out; o++) {
+        out_row_begin[o] = o * nsym;
+        for (int a = 0; a < N; a++)
+            for (int b = a; b < N; b++) {
+                RowDesc &rd = rows[(size_t)o * nsym + tri(a, b)];
+                const int64_t nc = (counts[o][tri(a, b)] + CH - 1) / CH;
+                rd.first_chunk = (int32_t)n_chunks;
+                rd.n_chunks = (int32_t)nc;
+                rd.out = (int16_t)o; rd.a = (int16_t)a; rd.b = (int16_t)b; rd.pad = 0;
+                n_chunks += nc;
+            }
+    }
+    out_row_begin[n_out] = n_out * nsym;
+    if (n_chunks <= 0 || n_chunks * CH > 0x7fffffff0LL) return fail(BLUEST_ERR_ARG, "problem too large for one plan (%lld chunks)", (long long)n_chunks);
+    std::vector<double> vals((size_t)(n_chunks * CH), 0.0);
+    std::vector<int32_t> cols((size_t)(n_chunks * CH), 0);
+    {
+        std::vector<int64_t> fill((size_t)n_out * nsym, 0);
+        for (int o = 0; o < n_out; o++) {
+            const OutputDesc &od = plan->outs[o];
+            int64_t go = 0, io = 0, li = 0;
+            for (int k = 1; k <= od.K; k++) {
+                for (int64_t i = 0; i < od.sizes[k - 1]; i++, li++) {
+                    const int64_t *g = od.groups.data() + go + i * k;
+                    const double *ic = od.invcovs.data() + io + i * k * k;
+                    for (int j = 0; j < k; j++)
+                        for (int l = j; l < k; l++) {
+                            const size_t r = (size_t)o * nsym + tri((int)std::min(g[j], g[l]), (int)std::max(g[j], g[l]));
+                            const int64_t pos = (int64_t)rows[r].first_chunk * CH + fill[r]++;
+                            vals[pos] = (j == l) ? ic[j * k + j] : 0.5 * (ic[j * k + l] + ic[l * k + j]);
+                            cols[pos] = (int32_t)od.mapping[li];
+                        }
+                }
+                go += od.sizes[k - 1] * k; io += od.sizes[k - 1] * k * k;
+            }
+        }
+        // padding: value 0, column = the row's first column (keeps max|m| per row exact, adds nothing)
+        for (size_t r = 0; r < rows.size(); r++) {
+            const int64_t beg = (int64_t)rows[r].first_chunk * CH, end = beg + (int64_t)rows[r].n_chunks * CH;
+            for (int64_t pos = beg + fill[r]; pos < end; pos++) cols[pos] = cols[beg];
+        }
+    }
+
+    // ---- gradient pass: group-major tiles ------------------------------------------------------------
+    std::vector<TileDesc> tiles;
+    std::vector<double> tvals;
+    std::vector<uint8_t> tidx;
+    plan->grad_off.assign(n_out, 0);
+    int64_t grad_len = 0;
+    for (int o = 0; o < n_out; o++) {
+        const OutputDesc &od = plan->outs[o];
+        plan->grad_off[o] = grad_len;
+        int64_t go = 0, io = 0, li = 0;
+        for (int k = 1; k <= od.K; k++) {
+            const int64_t Lk = od.sizes[k - 1];
+            const int ne = k * (k + 1) / 2;
+            for (int64_t t0 = 0; t0 < Lk; t0 += 64) {
+                TileDesc td;
+                td.val_off = (int64_t)tvals.size();
+                while (tidx.size() % 16) tidx.push_back(0);
+                td.idx_off = (int64_t)tidx.size();
+                td.grad_off = grad_len + li + t0;
+                td.n_valid = (int32_t)std::min<int64_t>(64, Lk - t0);
+                td.k = (int16_t)k; td.out = (int16_t)o;
+                tvals.resize(tvals.size() + (size_t)ne * 64, 0.0);
+                tidx.resize(tidx.size() + (size_t)k * 64, 0);
+                for (int lane = 0; lane < td.n_valid; lane++) {
+                    const int64_t i = t0 + lane;
+                    const int64_t *g = od.groups.data() + go + i * k;
+                    const double *ic = od.invcovs.data() + io + i * k * k;
+                    int e = 0;
+                    for (int j = 0; j < k; j++) {
+                        tidx[td.idx_off + j * 64 + lane] = (uint8_t)g[j];
+                        for (int l = j; l < k; l++, e++)
+                            tvals[td.val_off + e * 64 + lane] = (j == l) ? ic[j * k + j] : 0.5 * (ic[j * k + l] + ic[l * k + j]);
+                    }
+                }
+                tiles.push_back(td);
+            }
+            go += Lk * k; io += Lk * k * k; li += Lk;
+        }
+        grad_len += od.L_o;
+    }
+    plan->grad_len = grad_len;
+
+    // ---- inverse maps for combine_grad ------------------------------------------------------------
+    std::vector<int32_t> invmap((size_t)n_out * plan->L, -1);
+    for (int o = 0; o < n_out; o++)
+        for (int64_t li = 0; li < plan->outs[o].L_o; li++) invmap[(size_t)o * plan->L + plan->outs[o].mapping[li]] = (int32_t)li;
+
+    plan->n_chunks = n_chunks;
+    plan->n_rows = (int64_t)rows.size();
+    plan->n_tiles = (int64_t)tiles.size();
+    plan->max_cand = max_candidates;
+    plan->phi_bytes = n_chunks * CH * 12 + n_chunks * 16;
+    plan->grad_bytes = (int64_t)tvals.size() * 8 + (int64_t)tidx.size() + grad_len * 8;
+
+    int rc;
+    if ((rc = upload(&plan->d_vals, vals))) return rc;
+    if ((rc = upload(&plan->d_cols, cols))) return rc;
+    if ((rc = upload(&plan->d_rows, rows))) return rc;
+    if ((rc = upload(&plan->d_out_row_begin, out_row_begin))) return rc;
+    if ((rc = upload(&plan->d_tiles, tiles))) return rc;
+    if ((rc = upload(&plan->d_tvals, tvals))) return rc;
+    if ((rc = upload(&plan->d_tidx, tidx))) return rc;
+    if ((rc = upload(&plan->d_invmap, invmap))) return rc;
+    if ((rc = upload(&plan->d_goff, plan->grad_off))) return rc;
+    HIP_TRY(hipMalloc((void **)&plan->d_partial, (size_t)max_candidates * n_chunks * sizeof(double2)));
+    HIP_TRY(hipMalloc((void **)&plan->d_v, (size_t)max_candidates * n_out * N * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&plan->d_status, (size_t)max_candidates * n_out * sizeof(int32_t)));
+    plan->finalized = true;
+    // host copies of the reference-layout inputs are no longer needed
+    for (auto &od : plan->outs) { std::vector<double>().swap(od.invcovs); std::vector<int64_t>().swap(od.groups); }
+    return BLUEST_OK;
+}
+
+static int plan_ready(bluest_plan_t plan, int n_cand)
+{
+    if (!plan) return fail(BLUEST_ERR_ARG, "plan is NULL");
+    if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
+    if (n_cand <= 0 || n_cand > plan->max_cand) return fail(BLUEST_ERR_ARG, "n_cand=%d outside 1..%d", n_cand, plan->max_cand);
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_n_outputs(bluest_plan_t plan, int *n)
+{
+    if (!plan || !n) return fail(BLUEST_ERR_ARG, "null pointer");
+    *n = (int)plan->outs.size();
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_grad_layout(bluest_plan_t plan, int64_t *grad_len, int64_t *offsets)
+{
+    if (!plan) return fail(BLUEST_ERR_ARG, "plan is NULL");
+    if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
+    if (grad_len) *grad_len = plan->grad_len;
+    if (offsets) for (size_t o = 0; o < plan->outs.size(); o++) offsets[o] = plan->grad_off[o];
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_traffic(bluest_plan_t plan, int64_t *phi_bytes, int64_t *grad_bytes)
+{
+    if (!plan) return fail(BLUEST_ERR_ARG, "plan is NULL");
+    if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
+    if (phi_bytes) *phi_bytes = plan->phi_bytes;
+    if (grad_bytes) *grad_bytes = plan->grad_bytes;
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_phi_len(bluest_plan_t plan, int64_t *len)
+{
+    if (!plan || !len) return fail(BLUEST_ERR_ARG, "null pointer");
+    *len = (int64_t)plan->outs.size() * (plan->N * plan->N + 2 * plan->N + 1);
+    return BLUEST_OK;
+}
+
+static void launch_chunks(bluest_plan_t p, const double *m, int n_cand, int64_t m_stride, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_phi_chunks, dim3((unsigned)((p->n_chunks + 3) / 4)), dim3(256), 0, st, p->d_vals, p->d_cols,
+                       p->iters, p->n_chunks, m, m_stride, n_cand, p->d_partial);
+}
+
+extern "C" int bluest_plan_phi(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, double *phi_dev, void *stream)
+{
+    int rc = plan_ready(plan, n_cand); if (rc) return rc;
+    if (!m_dev || !phi_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (n_cand > 1 && m_stride < plan->L) return fail(BLUEST_ERR_ARG, "m_stride < L_global");
+    hipStream_t st = (hipStream_t)stream;
+    const int n_out = (int)plan->outs.size();
+    launch_chunks(plan, m_dev, n_cand, m_stride, st);
+    hipLaunchKernelGGL(k_fold_to_record, dim3(n_out, n_cand), dim3(64), 0, st, plan->N, n_out, plan->d_rows,
+                       plan->d_out_row_begin, plan->d_partial, plan->n_chunks, phi_dev);
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_solve(bluest_plan_t plan, const double *phi_dev, int n_cand, double delta, double *var_dev,
+                                 double *v_dev, int32_t *status_dev, void *stream)
+{
+    int rc = plan_ready(plan, n_cand); if (rc) return rc;
+    if (!phi_dev || !var_dev || !v_dev || !status_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    const int n_out = (int)plan->outs.size();
+    hipLaunchKernelGGL(k_solve_from_record, dim3(n_out, n_cand), dim3(64), 0, (hipStream_t)stream, plan->N, n_out, phi_dev,
+                       delta, var_dev, v_dev, status_dev);
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_grad(bluest_plan_t plan, const double *v_dev, const int32_t *status_dev, int n_cand,
+                                double *grad_dev, int64_t grad_stride, void *stream)
+{
+    int rc = plan_ready(plan, n_cand); if (rc) return rc;
+    if (!v_dev || !status_dev || !grad_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (n_cand > 1 && grad_stride < plan->grad_len) return fail(BLUEST_ERR_ARG, "grad_stride < grad_len");
+    const int n_out = (int)plan->outs.size();
+    hipLaunchKernelGGL(k_grad_tiles, dim3((unsigned)((plan->n_tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, plan->d_tiles,
+                       plan->n_tiles, plan->d_tvals, plan->d_tidx, v_dev, status_dev, plan->N, n_out, n_cand, grad_dev, grad_stride);
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, double delta,
+                                double *var_dev, double *grad_dev, int64_t grad_stride, int32_t *status_dev, void *stream)
+{
+    int rc = plan_ready(plan, n_cand); if (rc) return rc;
+    if (!m_dev || !var_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (n_cand > 1 && m_stride < plan->L) return fail(BLUEST_ERR_ARG, "m_stride < L_global");
+    if (grad_dev && n_cand > 1 && grad_stride < plan->grad_len) return fail(BLUEST_ERR_ARG, "grad_stride < grad_len");
+    hipStream_t st = (hipStream_t)stream;
+    const int n_out = (int)plan->outs.size();
+    int32_t *status = status_dev ? status_dev : plan->d_status;
+    launch_chunks(plan, m_dev, n_cand, m_stride, st);
+    hipLaunchKernelGGL(k_solve_from_chunks, dim3(n_out, n_cand), dim3(64), 0, st, plan->N, n_out, plan->d_rows,
+                       plan->d_out_row_begin, plan->d_partial, plan->n_chunks, delta, var_dev, plan->d_v, status);
+    if (grad_dev)
+        hipLaunchKernelGGL(k_grad_tiles, dim3((unsigned)((plan->n_tiles + 3) / 4)), dim3(256), 0, st, plan->d_tiles, plan->n_tiles,
+                           plan->d_tvals, plan->d_tidx, plan->d_v, status, plan->N, n_out, n_cand, grad_dev, grad_stride);
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_combine_grad(bluest_plan_t plan, const double *grad_dev, int64_t grad_stride, const double *coef_dev,
+                                        const double *scale_dev, int n_cand, double *out_dev, int64_t out_stride, void *stream)
+{
+    int rc = plan_ready(plan, n_cand); if (rc) return rc;
+    if (!grad_dev || !coef_dev || !out_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    const int n_out = (int)plan->outs.size();
+    hipLaunchKernelGGL(k_combine_grad, dim3((unsigned)((plan->L + 255) / 256), n_cand), dim3(256), 0, (hipStream_t)stream, grad_dev,
+                       grad_stride, plan->d_goff, plan->d_invmap, plan->L, n_out, coef_dev, scale_dev, n_cand, out_dev, out_stride);
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Part 3 host side
+// ------------------------------------------------------------------------------------------------------
+extern "C" int bluest_simplex_project(const double *x_dev, const double *g_dev, double lambda, double z, int64_t L, double *p_dev,
+                                      double *d_dev, double *stats_dev, void *stream)
+{
+    int rc = require_gpu(); if (rc) return rc;
+    if (!x_dev || L <= 0) return fail(BLUEST_ERR_ARG, "bad x / L");
+    if (!(z > 0.0)) return fail(BLUEST_ERR_ARG, "z must be positive");
+    hipStream_t st = (hipStream_t)stream;
+#define SP(IT) hipLaunchKernelGGL((k_simplex<IT>), dim3(1), dim3(1024), 0, st, x_dev, g_dev, lambda, z, L, p_dev, d_dev, stats_dev)
+    if (L <= 1024 * 4) SP(4);
+    else if (L <= 1024 * 8) SP(8);
+    else if (L <= 1024 * 16) SP(16);
+    else if (L <= 1024 * 32) SP(32);
+    else SP(0);
+#undef SP
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}

@@ -1,0 +1,243 @@
+"""
+MOSAP -- multi-output sample-allocation problem on the GPU.  Mirrors bluest/mosap.py:18-123,291-344: same
+constructor and attributes (SAPS, mappings, groups, sizes, cumsizes, L, e, ES), variances() / variance_GH()
+with the reference's list-over-outputs return shape, solve() with solver="spg".
+
+All outputs share ONE device plan: a call to variances()/variance_GH() is one Phi launch + one solve launch
+(+ one gradient launch) for every output together, instead of the reference's serial loop over SAPS
+(bluest/mosap.py:86-100).
+"""
+import numpy as np
+import torch
+
+from .plan import EVAL_INF, EVAL_NO_MODEL0, EVAL_OK, EVAL_SINGULAR, Plan
+from .sap import BLUESTError, SAP, SpgAllocator, indicator_vectors, normalise_groups, status_to_python
+
+
+def build_mappings(groups, multi_groups, cumsizes):
+    """mappings[n][j] = position in the global group list of the j-th group of output n (mosap.py:54-67),
+    by hashing instead of the reference's O(L_k^2) search"""
+    pos = {}
+    for k, gk in enumerate(groups):
+        base = int(cumsizes[k])
+        for j, g in enumerate(gk.tolist()):
+            pos[tuple(g)] = base + j
+    mappings = []
+    for mg in multi_groups:
+        idx = []
+        for gk in mg:
+            for g in np.asarray(gk).tolist():
+                key = tuple(g)
+                if key not in pos:
+                    raise AssertionError("group %s of an output is missing from the global group list (mosap.py:60)" % (key,))
+                idx.append(pos[key])
+        mappings.append(np.array(idx, dtype=np.int64))
+    return mappings
+
+
+class _SapView(SAP):
+    """SAPS[n] of a MOSAP: the reference builds one full SAP per output (mosap.py:39).  Here the per-output
+    data already lives in the shared plan; this view gives the same attributes and closures, creating its own
+    single-output plan only if somebody calls it directly."""
+
+    def __init__(self, parent, n):
+        self._parent, self._n = parent, n
+        self.verbose = parent.verbose
+        self.C = parent.C[n]
+        self.N = parent.N
+        self.K = parent.Ks[n]
+        self.costs = parent.multi_costs[n]
+        self.samples = self.budget = self.eps = self.tot_cost = None
+        groups = parent.multi_groups[n]
+        self.sizes = [0] + [len(g) for g in groups]
+        self.groups = groups
+        self.flattened_groups = [g for gk in groups for g in gk.tolist()]
+        self.cumsizes = np.cumsum(self.sizes)
+        self.L = int(self.cumsizes[-1])
+        flat = parent.plan.invcovs[n]
+        invcovs, off = [], 0
+        for k in range(1, self.K + 1):
+            cnt = self.sizes[k] * k * k
+            invcovs.append(flat[off:off + cnt] if cnt > 0 else np.array([]))
+            off += cnt
+        self.invcovs = invcovs
+        self.ES = indicator_vectors(groups, self.N)
+        self.e = self.ES[0]
+        self._psi = None
+        self._plan = None
+
+    @property
+    def plan(self):
+        if self._plan is None:
+            self._plan = Plan(self.N, self.L, [{"K": self.K, "sizes": self.sizes[1:], "groups": self.groups,
+                                                "invcovs": self.invcovs, "mapping": None}],
+                              max_candidates=1, device=self._parent.plan.device)
+            self.get_variance_functions()
+        return self._plan
+
+    def __getattr__(self, name):
+        if name in ("get_phi", "variance", "variance_GH"):
+            self.plan  # builds the closures
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+
+class MOSAP(object):
+    ''' MOSAP, MultiObjectiveSampleAllocationProblem '''
+
+    def __init__(self, C, K, Ks, groups, multi_groups, costs, multi_costs, verbose=True, device=None, max_candidates=1):
+        self.verbose = verbose
+        self.n_outputs = len(C)
+        self.C = C
+        self.N = C[0].shape[0]
+        self.K = K
+        self.Ks = Ks
+        self.costs = costs
+        self.multi_groups = multi_groups
+        self.multi_costs = multi_costs
+
+        self.flattened_groups = normalise_groups(groups, K)          # mosap.py:31-37 (in place)
+        self.groups = groups
+        for n in range(self.n_outputs):
+            normalise_groups(multi_groups[n], Ks[n])                 # sap.py:77 (in place, via SAP.__init__)
+
+        self.sizes = [0] + [len(groupsk) for groupsk in groups]
+        self.cumsizes = np.cumsum(self.sizes)
+        self.L = int(self.cumsizes[-1])
+        self.ES = [es.astype(np.int64) for es in indicator_vectors(groups, self.N)]
+        self.e = self.ES[0]
+        self.mappings = build_mappings(groups, multi_groups, self.cumsizes)  # m[mappings[n]] = m_n
+
+        outs = []
+        for n in range(self.n_outputs):
+            mg = multi_groups[n]
+            ident = len(self.mappings[n]) == self.L and (self.mappings[n] == np.arange(self.L)).all()
+            outs.append({"K": Ks[n], "sizes": [len(g) for g in mg], "groups": mg, "C": np.asarray(C[n], dtype=np.float64),
+                         "mapping": None if ident else self.mappings[n]})
+        self.plan = Plan(self.N, self.L, outs, max_candidates=max_candidates, device=device)
+        self.SAPS = [_SapView(self, n) for n in range(self.n_outputs)]
+
+        self.samples = None
+        self.budget = None
+        self.eps = None
+        self.tot_cost = None
+
+    def check_input(self, budget, eps):
+        """bluest/mosap.py:74-84"""
+        if budget is None and eps is None:
+            raise ValueError("Need to specify either budget or RMSE tolerance")
+        if eps is not None:
+            try:
+                if len(eps) != self.n_outputs:
+                    raise ValueError("eps must be a scalar or an array of tolerances")
+                eps = np.array(eps)
+            except TypeError:
+                eps = np.array([eps for n in range(self.n_outputs)])
+        return budget, eps
+
+    def variances(self, m, delta=0):
+        """bluest/mosap.py:86-89: list over outputs of V_n(m[mappings[n]])"""
+        var, _, status = self.plan.eval(m, delta=delta, want_grad=False)
+        var = var[0].cpu().numpy()
+        status = status[0].cpu().numpy()
+        out = []
+        for n in range(self.n_outputs):
+            if status[n] == EVAL_INF:
+                out.append(np.inf)
+                continue
+            status_to_python(int(status[n]), "variances[output %d]" % n)
+            out.append(float(var[n]))
+        return out
+
+    def variance_GH(self, m, nohess=False, delta=0):
+        """bluest/mosap.py:91-100: (variances, gradients, hessians) as lists over outputs; gradient n is with
+        respect to m[mappings[n]]"""
+        host = not isinstance(m, torch.Tensor)
+        var, grad, status = self.plan.eval(m, delta=delta, want_grad=True)
+        var = var[0].cpu().numpy()
+        status = status[0].cpu().numpy()
+        g_all = grad[0].cpu().numpy() if host else grad[0]
+        variances, gradients, hessians = [], [], []
+        for n in range(self.n_outputs):
+            off, Ln = self.plan.grad_off[n], len(self.mappings[n])
+            gradients.append(g_all[off:off + Ln])
+            if status[n] == EVAL_INF:
+                variances.append(np.inf)
+                hessians.append(None)
+                continue
+            if status[n] == EVAL_SINGULAR:
+                status_to_python(int(status[n]), "variance_GH[output %d]" % n)
+            variances.append(float(var[n]))
+            if nohess:
+                hessians.append(None)
+            else:
+                m_h = m.cpu().numpy() if isinstance(m, torch.Tensor) else np.asarray(m, dtype=np.float64)
+                hessians.append(self.SAPS[n]._hessian(m_h[self.mappings[n]], delta))
+        return variances, gradients, hessians
+
+    def get_max_sample_constraints(self, max_model_samples):
+        """bluest/mosap.py:326-344"""
+        if max_model_samples is None:
+            return [], []
+        if not isinstance(max_model_samples, np.ndarray) or len(max_model_samples) != self.N:
+            raise ValueError("The maximum number of model samples must be prescribed as a numpy array of the same length as the number of models.")
+        if max_model_samples[0] < 1:
+            raise ValueError("The high-fidelity model must be sampled at least once.")
+        es, rhs = [], []
+        for i in range(self.N):
+            if np.isfinite(max_model_samples[i]):
+                es.append(self.ES[i])
+                rhs.append(int(np.round(max_model_samples[i])))
+        return es, rhs
+
+    def solve(self, budget=None, eps=None, solver="spg", x0=None, continuous_relaxation=False, max_model_samples=None,
+              solver_params=None):
+        """bluest/mosap.py:291-324 with solver="spg" """
+        if budget is None and eps is None:
+            raise ValueError("Need to specify either budget or RMSE tolerance")
+        if solver not in ["spg", "scipy", "cvxpy", "ipopt", "cvxopt"]:
+            raise ValueError("Optimization solvers available: 'spg' (this build); the reference also lists 'scipy', 'ipopt', 'cvxopt', 'cvxpy'")
+        if solver != "spg":
+            raise BLUESTError("solver=%r is a third-party back-end of the reference that this GPU build does not ship; use solver='spg'" % solver)
+        if max_model_samples is not None:
+            raise BLUESTError("max_model_samples is not supported by solver='spg' (simplex projection only)")
+        budget, eps = self.check_input(budget, eps)
+
+        if self.verbose:
+            if eps is None: print("Minimizing statistical error for fixed cost...\n")
+            else:           print("Minimizing cost given statistical error tolerance...\n")
+
+        es = []
+        for n in range(self.n_outputs):
+            ee = np.zeros((self.L,))
+            ee[self.mappings[n]] = self.e[self.mappings[n]]
+            es.append(ee)
+        alloc = SpgAllocator(self.plan, self.costs, es, verbose=False)
+        try:
+            samples = alloc.solve(budget=budget, eps=eps, x0=x0, params=solver_params)
+        except BLUESTError as err:
+            if self.verbose: print(str(err))
+            self.samples = None
+            return None
+        self.solver_info = alloc.info
+        if any(samples @ ee < 1.0 - 1.0e-9 for ee in es):
+            if self.verbose: print("SPG solution samples model 0 less than once for some output; infeasible.")
+            self.samples = None
+            return None
+
+        if not continuous_relaxation:
+            from .integer import integer_projection_mosap
+            try:
+                samples = integer_projection_mosap(self, samples, budget=budget, eps=eps)
+            except AssertionError as err:
+                print(str(err))
+                self.samples = None
+                return None
+
+        self.samples = samples
+        self.budget = budget
+        self.eps = eps
+        self.tot_cost = samples @ self.costs
+        for n in range(self.n_outputs):
+            self.SAPS[n].samples = samples[self.mappings[n]]
+        return samples

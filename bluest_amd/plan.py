@@ -1,0 +1,194 @@
+"""
+Device-resident evaluation plan: Python face of Part 2 of include/bluest_hip.h.
+
+torch is used only as plumbing: it owns device buffers and the current HIP stream; every number is produced by
+the hand-written kernels in csrc/bluest_hip.hip.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+EVAL_OK, EVAL_INF, EVAL_NO_MODEL0, EVAL_SINGULAR = 0, 1, 2, 3
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def require_cuda():
+    if not torch.cuda.is_available():
+        raise _lib.BluestHipError("no GPU visible to torch: bluest_amd computes on MI355X only (no CPU fallback)")
+
+
+class Plan(object):
+    """One plan = all outputs of one (multi-output) sample-allocation problem, resident in HBM.
+
+    outputs: list of dicts with keys
+        K        max group size of this output
+        sizes    L_k for k = 1..K
+        groups   list over k of (L_k, k) int arrays (or one flat array)
+        invcovs  list over k of flat (L_k*k*k) float arrays, OR
+        C        (N, N) covariance -> per-group pseudo-inverses are computed on the GPU (sap.py:69-79)
+        mapping  (L_o,) indices into the global allocation vector, or None for identity
+    """
+
+    def __init__(self, n_models, L_global, outputs, max_candidates=1, device=None):
+        require_cuda()
+        self.lib = _lib.lib()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.N = int(n_models)
+        self.L = int(L_global)
+        self.n_out = len(outputs)
+        self.max_candidates = int(max_candidates)
+        self._h = ctypes.c_void_p()
+        self.invcovs = []  # reference-layout host copies when computed on device
+        with torch.cuda.device(self.device):
+            check(self.lib.bluest_plan_create(ctypes.byref(self._h), self.N, self.L))
+            try:
+                for out in outputs:
+                    K = int(out["K"])
+                    sizes = _i64(out["sizes"])
+                    assert len(sizes) == K
+                    g = out["groups"]
+                    groups = _i64(np.concatenate([np.asarray(x, dtype=np.int64).ravel() for x in g])
+                                  if isinstance(g, (list, tuple)) else g)
+                    mapping = None if out.get("mapping") is None else _i64(out["mapping"])
+                    if out.get("invcovs") is not None:
+                        ic = out["invcovs"]
+                        ic = _f64(np.concatenate([np.asarray(x, dtype=np.float64).ravel() for x in ic])
+                                  if isinstance(ic, (list, tuple)) else ic)
+                        check(self.lib.bluest_plan_add_output(self._h, K, ptr(sizes), ptr(groups), ptr(ic), ptr(mapping)))
+                        self.invcovs.append(None)
+                    else:
+                        C = _f64(out["C"])
+                        n_ic = int(sum(int(sizes[k - 1]) * k * k for k in range(1, K + 1)))
+                        ic = np.empty(n_ic, dtype=np.float64)
+                        check(self.lib.bluest_plan_add_output_cov(self._h, ptr(C), K, ptr(sizes), ptr(groups), ptr(mapping), ptr(ic)))
+                        self.invcovs.append(ic)
+                check(self.lib.bluest_plan_finalize(self._h, self.max_candidates))
+            except Exception:
+                self.lib.bluest_plan_destroy(self._h)
+                self._h = None
+                raise
+        glen = ctypes.c_int64(0)
+        offs = (ctypes.c_int64 * self.n_out)()
+        check(self.lib.bluest_plan_grad_layout(self._h, ctypes.byref(glen), offs))
+        self.grad_len = glen.value
+        self.grad_off = [int(x) for x in offs]
+        pb, gb = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(self.lib.bluest_plan_traffic(self._h, ctypes.byref(pb), ctypes.byref(gb)))
+        self.phi_bytes, self.grad_bytes = pb.value, gb.value
+        self.reclen = self.N * self.N + 2 * self.N + 1
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.lib.bluest_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- helpers ------------------------------------------------------------------------------------
+    def to_device(self, m):
+        """host/device array -> contiguous float64 device tensor of shape (n_cand, L)"""
+        if isinstance(m, torch.Tensor):
+            t = m.to(device=self.device, dtype=torch.float64)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(m), dtype=np.float64)).to(self.device)
+        if t.dim() == 1:
+            t = t.unsqueeze(0)
+        t = t.contiguous()
+        if t.shape[1] != self.L:
+            raise ValueError("allocation vector has length %d, plan expects %d" % (t.shape[1], self.L))
+        if t.shape[0] > self.max_candidates:
+            raise ValueError("%d candidates > max_candidates=%d" % (t.shape[0], self.max_candidates))
+        return t
+
+    # ---- fused single-GPU evaluation (MOSAP.variances / variance_GH) ----------------------------------
+    def eval(self, m, delta=0.0, want_grad=True, out=None):
+        """returns (var (n_cand,n_out), grad (n_cand,grad_len) | None, status (n_cand,n_out) int32) device tensors"""
+        m = self.to_device(m)
+        nc = m.shape[0]
+        if out is None:
+            var = torch.empty((nc, self.n_out), dtype=torch.float64, device=self.device)
+            grad = torch.empty((nc, self.grad_len), dtype=torch.float64, device=self.device) if want_grad else None
+            status = torch.empty((nc, self.n_out), dtype=torch.int32, device=self.device)
+        else:
+            var, grad, status = out
+        with torch.cuda.device(self.device):
+            check(self.lib.bluest_plan_eval(self._h, m.data_ptr(), nc, m.stride(0), float(delta), var.data_ptr(),
+                                            None if grad is None else grad.data_ptr(),
+                                            0 if grad is None else grad.stride(0), status.data_ptr(), _stream()))
+        return var, grad, status
+
+    # ---- three-phase path (multi-GPU: all-reduce the record between phi() and solve()) ----------------
+    def phi(self, m, out=None):
+        m = self.to_device(m)
+        nc = m.shape[0]
+        rec = out if out is not None else torch.empty((nc, self.n_out, self.reclen), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.bluest_plan_phi(self._h, m.data_ptr(), nc, m.stride(0), rec.data_ptr(), _stream()))
+        return rec
+
+    def solve(self, rec, delta=0.0):
+        nc = rec.shape[0]
+        var = torch.empty((nc, self.n_out), dtype=torch.float64, device=self.device)
+        v = torch.empty((nc, self.n_out, self.N), dtype=torch.float64, device=self.device)
+        status = torch.empty((nc, self.n_out), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.bluest_plan_solve(self._h, rec.data_ptr(), nc, float(delta), var.data_ptr(), v.data_ptr(),
+                                             status.data_ptr(), _stream()))
+        return var, v, status
+
+    def grad(self, v, status, out=None):
+        nc = v.shape[0]
+        grad = out if out is not None else torch.empty((nc, self.grad_len), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.bluest_plan_grad(self._h, v.data_ptr(), status.data_ptr(), nc, grad.data_ptr(), grad.stride(0), _stream()))
+        return grad
+
+    def combine_grad(self, grad, coef, scale=None, out=None):
+        """out[c][j] = scale[j] * sum_o coef[c][o] * grad_o[c][local_o(j)]"""
+        nc = grad.shape[0]
+        res = out if out is not None else torch.empty((nc, self.L), dtype=torch.float64, device=self.device)
+        coef = coef.to(device=self.device, dtype=torch.float64).contiguous()
+        with torch.cuda.device(self.device):
+            check(self.lib.bluest_plan_combine_grad(self._h, grad.data_ptr(), grad.stride(0), coef.data_ptr(),
+                                                    None if scale is None else scale.data_ptr(), nc, res.data_ptr(),
+                                                    res.stride(0), _stream()))
+        return res
+
+    def phi_matrix(self, m, delta=0.0):
+        """Phi(m) + delta*I for every output as an (n_cand, n_out, N, N) device tensor (misc.py:459-461)"""
+        rec = self.phi(m)
+        N = self.N
+        PHI = rec[:, :, :N * N].reshape(rec.shape[0], self.n_out, N, N).clone()
+        if delta:
+            PHI += float(delta) * torch.eye(N, dtype=torch.float64, device=self.device)
+        return PHI
+
+
+def simplex_project(x, g=None, lmbda=0.0, z=1.0, want_p=True, want_d=True):
+    """p = P_simplex(x - lmbda*g), d = p - x on the GPU; returns (p, d, stats[4] device tensor)"""
+    require_cuda()
+    L = x.numel()
+    p = torch.empty_like(x) if want_p else None
+    d = torch.empty_like(x) if want_d else None
+    stats = torch.empty(4, dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().bluest_simplex_project(x.data_ptr(), None if g is None else g.data_ptr(), float(lmbda), float(z), L,
+                                                None if p is None else p.data_ptr(), None if d is None else d.data_ptr(),
+                                                stats.data_ptr(), _stream()))
+    return p, d, stats

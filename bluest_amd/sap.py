@@ -1,0 +1,326 @@
+"""
+SAP -- single-output sample-allocation problem on the GPU.  Mirrors bluest/sap.py:52-220 for the hot path:
+same constructor, same attributes (psi, groups, sizes, cumsizes, invcovs, L, N, e, ES, costs), same closures
+variance / variance_GH / get_phi, same solve() signature -- with solver="spg" added (the four third-party
+back-ends of the reference are outside this build).
+"""
+import numpy as np
+import torch
+
+from . import misc
+from .plan import EVAL_INF, EVAL_NO_MODEL0, EVAL_OK, EVAL_SINGULAR, Plan, simplex_project
+from .spg import spg
+
+spg_sap_default_params = {
+    "eps": 1.0e-7,            # stop when ||P(x-g)-x||_inf <= eps (objective normalised by its initial value)
+    "maxit": 20000,
+    "max_fevals": 10 ** 6,
+    "lmbda_min": 10. ** -30,
+    "lmbda_max": 10. ** 30,
+    "linesearch_history_length": 10,
+    "smoothing_p": 32.0,      # multi-output: max_o V_o is replaced by the p-norm (smooth); inf = plain max
+    "rel_tol": 1.0e-9,        # additionally stop when the objective stalls (relative decrease over a window)
+    "stall_window": 200,
+}
+
+
+class BLUESTError(RuntimeError):
+    pass
+
+
+def normalise_groups(groups, K):
+    """list over k of int64 arrays (L_k, k); mutates the list in place like sap.py:77 does"""
+    flattened = []
+    for k in range(1, K + 1):
+        gk = groups[k - 1]
+        if not isinstance(gk, np.ndarray):
+            flattened += [list(g) for g in gk]
+        else:
+            flattened += gk.tolist()
+        groups[k - 1] = np.array(gk, dtype=np.int64).reshape((-1, k))
+    return flattened
+
+
+def indicator_vectors(groups, N):
+    """ES[i][j] = 1 if model i is in group j (sap.py:89-95), vectorised"""
+    L = sum(len(g) for g in groups)
+    ES = np.zeros((N, L), dtype=np.int64)
+    off = 0
+    for gk in groups:
+        if len(gk):
+            cols = np.repeat(np.arange(off, off + len(gk)), gk.shape[1])
+            ES[gk.ravel(), cols] = 1
+        off += len(gk)
+    return [ES[i] for i in range(N)]
+
+
+def status_to_python(status, where):
+    """reference behaviour for the per-evaluation status codes"""
+    if status == EVAL_NO_MODEL0:
+        raise AssertionError("%s: model 0 is not sampled (bluest/misc.py:470)" % where)
+    if status == EVAL_SINGULAR:
+        raise AssertionError("%s: information matrix is singular on the sampled models (bluest/misc.py:473-474)" % where)
+
+
+class SpgAllocator(object):
+    """SPG in the scaled variable x = cost*m/B over the unit simplex; all vectors live in HBM.
+
+    objective F(m) = || (V_o(m)/s_o)_o ||_p  (p = inf: max, single output: V itself), minimised over
+    {m >= 0, cost.m = B}.  V is homogeneous of degree -1 in m, so the eps-constrained problem
+    (min cost s.t. V_o <= eps_o^2) is the B = 1 problem with s_o = eps_o^2 followed by a rescale.
+    """
+
+    def __init__(self, plan, costs, e_list, verbose=False):
+        self.plan = plan
+        self.dev = plan.device
+        self.costs = np.asarray(costs, dtype=np.float64)
+        self.w = torch.from_numpy(self.costs).to(self.dev)
+        self.e_list = e_list  # per output: indicator (global numbering) of groups containing model 0
+        self.verbose = verbose
+
+    def solve(self, budget=None, eps=None, x0=None, params=None):
+        prm = dict(spg_sap_default_params)
+        if params:
+            prm.update(params)
+        plan = self.plan
+        n_out = plan.n_out
+        B = float(budget) if budget is not None else 1.0
+        s = np.ones(n_out) if budget is not None else np.asarray(eps, dtype=np.float64) ** 2
+        p = float(prm["smoothing_p"]) if n_out > 1 else np.inf
+        scale = B / self.w                                         # m = scale * x
+        st = {"x": None, "var": None, "status": None, "fevals": 0, "gevals": 0, "norm": 1.0}
+
+        def objective(var):
+            r = var / s
+            if not np.isfinite(r).all():
+                return np.inf, None
+            rmax = r.max()
+            if np.isinf(p):
+                coef = np.zeros(n_out)
+                coef[int(np.argmax(r))] = 1.0
+                return rmax, coef / s
+            t = (r / rmax) ** p
+            F = rmax * t.sum() ** (1.0 / p)
+            coef = (r / rmax) ** (p - 1) * t.sum() ** (1.0 / p - 1.0)   # dF/dr_o
+            return F, coef / s
+
+        def evaluate(x, want_grad):
+            m = scale * x
+            var, grad, status = plan.eval(m, want_grad=want_grad)
+            var_h = var[0].cpu().numpy()
+            status_h = status[0].cpu().numpy()
+            ok = (status_h == EVAL_OK).all()
+            F, coef = objective(var_h) if ok else (np.inf, None)
+            return F, coef, grad, m
+
+        def feval(x):
+            st["fevals"] += 1
+            F, coef, _, _ = evaluate(x, False)
+            return F / st["norm"]
+
+        def geval(x):
+            st["gevals"] += 1
+            F, coef, grad, _ = evaluate(x, True)
+            if coef is None:
+                raise BLUESTError("SPG: gradient requested at an infeasible point")
+            c = torch.from_numpy(coef / st["norm"]).to(self.dev).reshape(1, -1)
+            return plan.combine_grad(grad, c, scale=scale)[0]
+
+        def proj(x):
+            return simplex_project(x, want_d=False)[0]
+
+        def proj_step(x, g, lmbda):
+            _, d, stats = simplex_project(x, g, lmbda, want_p=False)
+            sh = stats.cpu().numpy()
+            return d, float(sh[0]), float(sh[1])
+
+        L = plan.L
+        if x0 is None:
+            x = torch.full((L,), 1.0 / L, dtype=torch.float64, device=self.dev)
+        else:
+            x = torch.from_numpy(np.asarray(x0, dtype=np.float64)).to(self.dev) * self.w / B
+        x = proj(x)
+        F0 = feval(x)
+        if not np.isfinite(F0):
+            raise BLUESTError("SPG: the initial allocation does not sample model 0 / is infeasible")
+        st["norm"] = F0
+
+        hist = []
+
+        def stall(it, f, gpmax, lmbda):
+            hist.append(f)
+
+        res = spg(feval, geval, proj, x, eps=prm["eps"], maxit=prm["maxit"], max_fevals=prm["max_fevals"], verbose=self.verbose,
+                  lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"], Hlength=prm["linesearch_history_length"],
+                  proj_step=proj_step, callback=stall)
+        xs = res["x"]
+        m = (scale * xs)
+        if budget is None:
+            # rescale so that max_o V_o/eps_o^2 = 1 (V homogeneous of degree -1)
+            var, _, status = plan.eval(m, want_grad=False)
+            r = (var[0].cpu().numpy() / s).max()
+            m = m * r
+        self.info = {"it": res["it"], "count": res["count"], "gpmax": res["gpmax"], "f": res["f"] * st["norm"],
+                     "solver_info": res["solver_info"], "fevals": st["fevals"], "gevals": st["gevals"]}
+        return m.cpu().numpy()
+
+
+class SAP(object):
+    def __init__(self, C, K, groups, costs, verbose=True, device=None, max_candidates=1):
+        """bluest/sap.py:53-97.  `groups` (list over k of lists of model tuples) is converted in place to int64
+        arrays, as the reference does at :77.  The per-group pseudo-inverses (:69-79) are computed on the GPU."""
+        self.verbose = verbose
+        self.C = C
+        self.N = C.shape[0]
+        self.K = K
+        self.costs = costs
+        self.samples = None
+        self.budget = None
+        self.eps = None
+        self.tot_cost = None
+
+        sizes = [0] + [len(groupsk) for groupsk in groups]
+        self.flattened_groups = normalise_groups(groups, K)
+        self.sizes = sizes
+        self.groups = groups
+        self.cumsizes = np.cumsum(sizes)
+        self.L = int(self.cumsizes[-1])
+
+        self.plan = Plan(self.N, self.L, [{"K": K, "sizes": sizes[1:], "groups": groups, "C": np.asarray(C, dtype=np.float64),
+                                           "mapping": None}], max_candidates=max_candidates, device=device)
+        flat = self.plan.invcovs[0]
+        invcovs, off = [], 0
+        for k in range(1, K + 1):
+            n = sizes[k] * k * k
+            invcovs.append(flat[off:off + n] if n > 0 else np.array([]))
+            off += n
+        self.invcovs = invcovs
+
+        self.ES = indicator_vectors(groups, self.N)
+        self.e = self.ES[0]
+        self._psi = None
+        self.get_variance_functions()
+
+    # ---- psi is only needed by SDP solvers / integer projection: assembled on demand (sap.py:129) --------
+    @property
+    def psi(self):
+        if self._psi is None:
+            self._psi = np.hstack([misc.assemble_psi(self.N, k, self.sizes[k], self.groups[k - 1], self.invcovs[k - 1])
+                                   for k in range(1, self.K + 1) if len(self.groups[k - 1]) > 0])
+        return self._psi
+
+    def get_variance_functions(self):
+        """bluest/sap.py:121-143: the operator boundary solvers call"""
+        plan = self.plan
+
+        def host(m):
+            return not isinstance(m, torch.Tensor)
+
+        def get_phi(m, delta=0):
+            PHI = plan.phi_matrix(m, delta=delta)[0, 0]
+            return PHI.cpu().numpy() if host(m) else PHI
+
+        def variance(m, delta=0):
+            """bluest/misc.py:463-477"""
+            var, _, status = plan.eval(m, delta=delta, want_grad=False)
+            st = int(status[0, 0])
+            if st == EVAL_INF:
+                return np.inf
+            status_to_python(st, "variance")
+            return float(var[0, 0])
+
+        def variance_GH(m, delta=0, nohess=False):
+            """bluest/misc.py:479-505"""
+            var, grad, status = plan.eval(m, delta=delta, want_grad=True)
+            st = int(status[0, 0])
+            g = grad[0].cpu().numpy() if host(m) else grad[0]
+            if st == EVAL_INF:
+                return np.inf, g      # the reference returns a 2-tuple here (misc.py:484)
+            if st == EVAL_SINGULAR:
+                status_to_python(st, "variance_GH")
+            V = float(var[0, 0])
+            if nohess:
+                return V, g, None
+            return V, g, self._hessian(m, delta)
+
+        self.get_phi = get_phi
+        self.variance = variance
+        self.variance_GH = variance_GH
+
+    def _hessian(self, m, delta):
+        """bluest/misc.py:497-503: K x K blocks of hessKQ, then hess += hess.T.  O(L^2) memory by construction."""
+        m_h = m.cpu().numpy() if isinstance(m, torch.Tensor) else np.asarray(m, dtype=np.float64)
+        rec = self.plan.phi(m_h)
+        N = self.N
+        PHI = rec[0, 0, :N * N].reshape(N, N) + float(delta) * torch.eye(N, dtype=torch.float64, device=rec.device)
+        invPHI = torch.linalg.pinv(PHI).cpu().numpy()
+        L, K, cs = self.L, self.K, self.cumsizes
+        hess = np.zeros((L, L))
+        for k in range(1, K + 1):
+            for q in range(1, K + 1):
+                if self.sizes[k] and self.sizes[q]:
+                    hess[cs[k - 1]:cs[k], cs[q - 1]:cs[q]] = misc.hessKQ(k, q, self.sizes[k], self.sizes[q], self.groups[k - 1],
+                                                                          self.groups[q - 1], self.invcovs[k - 1],
+                                                                          self.invcovs[q - 1], invPHI)
+        hess += hess.T
+        return hess
+
+    def get_max_sample_constraints(self, max_model_samples):
+        """bluest/sap.py:222-240"""
+        if max_model_samples is None:
+            return [], []
+        if not isinstance(max_model_samples, np.ndarray) or len(max_model_samples) != self.N:
+            raise ValueError("The maximum number of model samples must be prescribed as a numpy array of the same length as the number of models.")
+        if max_model_samples[0] < 1:
+            raise ValueError("The high-fidelity model must be sampled at least once.")
+        es, rhs = [], []
+        for i in range(self.N):
+            if np.isfinite(max_model_samples[i]):
+                es.append(self.ES[i])
+                rhs.append(int(np.round(max_model_samples[i])))
+        return es, rhs
+
+    def solve(self, budget=None, eps=None, solver="spg", x0=None, continuous_relaxation=False, max_model_samples=None,
+              solver_params=None):
+        """bluest/sap.py:189-220 with solver="spg" (the reference's cvxpy/cvxopt/ipopt/scipy back-ends are
+        third-party and not part of this build)."""
+        if budget is None and eps is None:
+            raise ValueError("Need to specify either budget or RMSE tolerance")
+        if solver not in ["spg", "scipy", "cvxpy", "ipopt", "cvxopt"]:
+            raise ValueError("Optimization solvers available: 'spg' (this build); the reference also lists 'scipy', 'ipopt', 'cvxopt', 'cvxpy'")
+        if solver != "spg":
+            raise BLUESTError("solver=%r is a third-party back-end of the reference that this GPU build does not ship; use solver='spg'" % solver)
+        if max_model_samples is not None:
+            raise BLUESTError("max_model_samples is not supported by solver='spg' (simplex projection only)")
+
+        if self.verbose:
+            if eps is None: print("Minimizing statistical error for fixed cost...\n")
+            else:           print("Minimizing cost given statistical error tolerance...\n")
+
+        alloc = SpgAllocator(self.plan, self.costs, [self.e], verbose=False)
+        try:
+            samples = alloc.solve(budget=budget, eps=None if eps is None else [eps], x0=x0, params=solver_params)
+        except BLUESTError as err:
+            if self.verbose: print(str(err))
+            self.samples = None
+            return None
+        self.solver_info = alloc.info
+        if samples @ self.e < 1.0 - 1.0e-9:
+            if self.verbose: print("SPG solution samples model 0 less than once; infeasible for this budget.")
+            self.samples = None
+            return None
+
+        if not continuous_relaxation:
+            from .integer import integer_projection_sap
+            try:
+                samples = integer_projection_sap(self, samples, budget=budget, eps=eps)
+            except AssertionError as err:
+                print(str(err))
+                self.samples = None
+                return None
+
+        self.samples = samples
+        self.budget = budget
+        self.eps = eps
+        self.tot_cost = samples @ self.costs
+        return samples

@@ -1,0 +1,171 @@
+/*
+ * bluest_hip.h -- C-ABI of libbluest_hip.so: the MI355X (gfx950) implementation of BLUEST's sample-allocation
+ * hot path (Phi(m) assembly, V = e0^T Phi^-1 e0, grad V, simplex projection for the SPG solver).
+ *
+ * This is the drop-in boundary.  Part 1 mirrors, one entry point per function, the reference's only native
+ * module `_cmisc_bluest` (/root/reference/bluest/cmisc.cpp:99-110): the same arguments in the same order and
+ * the same in-place accumulation contract, as plain pointers and sizes.  Part 2 is the device-resident "plan"
+ * that the Python operators SAP / MOSAP (bluest/sap.py:131-143, bluest/mosap.py:86-100) sit on: group tables
+ * and per-group inverse covariances stay in HBM, one call evaluates V and grad V for every output.
+ *
+ * Conventions
+ *   - every function returns BLUEST_OK (0) or a BLUEST_ERR_* code; bluest_last_error() gives the message
+ *     of the last failure on the calling thread.  Nothing throws, nothing takes ownership of caller memory.
+ *   - "hd" pointers (Part 1) may be HOST or DEVICE pointers (detected with hipPointerGetAttributes); host
+ *     buffers are staged through HBM and the call is synchronous.  "dev" pointers (Part 2) must be device
+ *     pointers; those calls are asynchronous on `stream` (a hipStream_t passed as void*, NULL = default).
+ *   - arithmetic is IEEE float64, indices int64, exactly as the reference (cmisc.cpp uses `long int`).
+ *   - there is NO CPU fallback: without a usable GPU every compute entry point fails with BLUEST_ERR_NOGPU.
+ */
+#ifndef BLUEST_HIP_H
+#define BLUEST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLUEST_ABI_VERSION 1
+
+#define BLUEST_OK          0
+#define BLUEST_ERR_ARG     1   /* bad argument (null pointer, size out of range) */
+#define BLUEST_ERR_HIP     2   /* a HIP runtime call failed */
+#define BLUEST_ERR_NOGPU   3   /* no gfx950 device visible */
+#define BLUEST_ERR_STATE   4   /* plan not finalized / already finalized */
+
+#define BLUEST_MAX_MODELS  64  /* n  (Phi is n x n) */
+#define BLUEST_MAX_GROUP   16  /* k_max */
+
+/* per-(candidate,output) evaluation status written by bluest_plan_solve / bluest_plan_eval */
+#define BLUEST_EVAL_OK         0
+#define BLUEST_EVAL_INF        1  /* max|m| < 0.05  -> V = +inf, grad = +inf   (bluest/misc.py:464,484)      */
+#define BLUEST_EVAL_NO_MODEL0  2  /* model 0 not sampled -> reference asserts   (bluest/misc.py:470)          */
+#define BLUEST_EVAL_SINGULAR   3  /* restricted Phi not positive definite       (bluest/misc.py:473-474)      */
+
+int         bluest_abi_version(void);
+const char *bluest_last_error(void);
+int         bluest_device_count(int *count);
+int         bluest_device_name(char *buf, int buflen);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Part 1 -- stateless mirrors of _cmisc_bluest (reference: bluest/cmisc.cpp)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* replaces assemble_psi_c (cmisc.cpp:10-23): psi[(N*g_j+g_l), i] += invcov_i[j,l];
+ * psi is C-order (N*N, Lk), zero-filled by the caller (bluest/misc.py:601). */
+int bluest_assemble_psi(double *psi_hd, int N, int k, int64_t Lk, const int64_t *groupsk_hd,
+                        const double *invcovsk_hd);
+
+/* replaces objectiveK_c<double> (cmisc.cpp:25-40, overload :104): PHI[N*g_j+g_l] += m_i*invcov_i[j,l] */
+int bluest_objectiveK_f64(double *PHI_hd, int N, int k, int64_t Lk, const double *mk_hd,
+                          const int64_t *groupsk_hd, const double *invcovsk_hd);
+
+/* replaces objectiveK_c<long int> (cmisc.cpp:25-40, overload :105): integer sample counts */
+int bluest_objectiveK_i64(double *PHI_hd, int N, int k, int64_t Lk, const int64_t *mk_hd,
+                          const int64_t *groupsk_hd, const double *invcovsk_hd);
+
+/* replaces gradK_c (cmisc.cpp:58-72): grad_i += v[g]^T invcov_i v[g], v = invPHI[0] (length >= max(g)+1) */
+int bluest_gradK(double *grad_hd, int k, int64_t Lk, const int64_t *groupsk_hd, const double *invcovsk_hd,
+                 const double *invPHI_0_hd, int n_models);
+
+/* replaces cleanupK_c (cmisc.cpp:42-56), INCLUDING its `=` (not `+=`) at line 51: only the l=k-1 term
+ * survives, X[g_j, i] = invcov_i[j,k-1]*v[g_{k-1}].  X is C-order (N, Lk). */
+int bluest_cleanupK(double *X_hd, int k, int64_t Lk, const int64_t *groupsk_hd, const double *invcovsk_hd,
+                    const double *invPHI_0_hd, int n_models);
+
+/* replaces hessKQ_c (cmisc.cpp:74-97): hess[ik,iq] += a_k(ik)^T invPHI[g^k,g^q] a_q(iq),
+ * a_k(ik)_j = sum_l v[g^k_l] invcov^k[l,j]; hess is C-order (Lk, Lq); invPHI is C-order (N, N). */
+int bluest_hessKQ(double *hess_hd, int N, int k, int q, int64_t Lk, int64_t Lq, const int64_t *groupsk_hd,
+                  const int64_t *groupsq_hd, const double *invcovsk_hd, const double *invcovsq_hd,
+                  const double *invPHI_hd);
+
+/* replaces the per-group numpy.linalg.pinv(C[g,g]) loop of SAP.__init__ (bluest/sap.py:69-79):
+ * invcov_i = pinv(C[g_i,g_i]) (symmetric eigen-decomposition, cut-off 1e-15*max|lambda| as numpy's default
+ * rcond), flattened C-order (Lk*k*k). */
+int bluest_group_pinv(const double *C_hd, int N, int k, int64_t Lk, const int64_t *groupsk_hd,
+                      double *invcovsk_hd);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Part 2 -- device-resident plan (operator level: bluest/sap.py:131-143, bluest/mosap.py:86-100)
+ *
+ * A plan holds, for each output o, the groups and inverse covariances of SAP_o re-laid out in HBM for the two
+ * streaming passes (destination-major symmetric CSR for the Phi pass, group-major 64-wide tiles for the
+ * gradient pass), plus the map from SAP_o's local group numbering to the global allocation vector m
+ * (`mappings[o]` of bluest/mosap.py:54-67).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct bluest_plan_s *bluest_plan_t;
+
+/* n_models = N (<= BLUEST_MAX_MODELS); L_global = length of the global allocation vector m */
+int bluest_plan_create(bluest_plan_t *plan, int n_models, int64_t L_global);
+int bluest_plan_destroy(bluest_plan_t plan);
+
+/* Add output o (call once per output, in order).  K = max group size of this output; sizes[k-1] = L_k for
+ * k = 1..K; groups = concat_k (L_k*k) model indices; invcovs = concat_k (L_k*k*k) (HOST pointers, copied);
+ * mapping = L_o global indices (m_o = m[mapping]) or NULL for the identity (requires L_o == L_global). */
+int bluest_plan_add_output(bluest_plan_t plan, int K, const int64_t *sizes, const int64_t *groups,
+                           const double *invcovs, const int64_t *mapping);
+
+/* Same, but the per-group pseudo-inverses are computed on the GPU from the n x n covariance C (host pointer);
+ * if invcovs_out (host) is non-NULL the inverses are also returned in the reference layout. */
+int bluest_plan_add_output_cov(bluest_plan_t plan, const double *C, int K, const int64_t *sizes,
+                               const int64_t *groups, const int64_t *mapping, double *invcovs_out);
+
+/* Build the HBM layouts.  max_candidates = largest number of allocation vectors evaluated per call. */
+int bluest_plan_finalize(bluest_plan_t plan, int max_candidates);
+
+int bluest_plan_n_outputs(bluest_plan_t plan, int *n_outputs);
+/* total length of the concatenated per-output gradient (sum_o L_o) and the offset of output o inside it */
+int bluest_plan_grad_layout(bluest_plan_t plan, int64_t *grad_len, int64_t *offsets /* n_outputs */);
+/* HBM bytes the Phi pass / gradient pass stream per candidate (actual layout, for roofline accounting) */
+int bluest_plan_traffic(bluest_plan_t plan, int64_t *phi_bytes, int64_t *grad_bytes);
+/* size in doubles of one candidate's Phi-pass result: n_outputs * (N*N + 2*N + 1), see bluest_plan_phi */
+int bluest_plan_phi_len(bluest_plan_t plan, int64_t *len);
+
+/* Phase A (a4/a5/a6 of SURVEY.md 8a): for every candidate c and output o write into phi_dev[c][o] a record of
+ * N*N + 2*N + 1 doubles: Phi_o(m_c) WITHOUT the delta*I term (N*N); then for each model a, 1.0 if some group
+ * containing a has |m_i| > 1e-6 else 0.0 (N doubles: the `idx` of bluest/misc.py:453-457); then for each model
+ * a, 1.0 if some group containing a has m_i != 0 (N doubles: the support of Phi); then 1.0 if max|m| >= 0.05
+ * (1 double, bluest/misc.py:464).  All fields are sums/indicators, so partial records from several GPUs (each
+ * holding a shard of the groups) combine with one all-reduce(SUM) and are then tested with `> 0`.
+ * m_dev: n_cand vectors of length L_global, m_stride doubles apart. */
+int bluest_plan_phi(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, double *phi_dev,
+                    void *stream);
+
+/* Phase B (a7/a8): from the (all-reduced) records, V = (Phi[idx,idx]^-1)_00 on the sampled models
+ * (bluest/misc.py:467-472,490), v = row 0 of pinv(Phi + delta I) (bluest/misc.py:487), status codes above.
+ * var_dev: n_cand*n_outputs, v_dev: n_cand*n_outputs*N, status_dev: n_cand*n_outputs int32. */
+int bluest_plan_solve(bluest_plan_t plan, const double *phi_dev, int n_cand, double delta, double *var_dev,
+                      double *v_dev, int32_t *status_dev, void *stream);
+
+/* Phase C (a9): grad_o,i = -v[g_i]^T invcov_i v[g_i] for every group of every output (this GPU's shard);
+ * grad_dev: n_cand rows of grad_len doubles (row stride grad_stride); +inf where status == BLUEST_EVAL_INF. */
+int bluest_plan_grad(bluest_plan_t plan, const double *v_dev, const int32_t *status_dev, int n_cand,
+                     double *grad_dev, int64_t grad_stride, void *stream);
+
+/* A + B (+ C if grad_dev != NULL) back to back on one stream, single GPU (MOSAP.variances / variance_GH). */
+int bluest_plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, double delta,
+                     double *var_dev, double *grad_dev, int64_t grad_stride, int32_t *status_dev, void *stream);
+
+/* Fold the per-output gradients back onto the global allocation vector:
+ * out[c][j] = scale[j] * sum_o coef[c][o] * grad_o[c][local_o(j)]   (0 where output o has no group j).
+ * coef_dev: n_cand*n_outputs; scale_dev: L_global or NULL (=1). */
+int bluest_plan_combine_grad(bluest_plan_t plan, const double *grad_dev, int64_t grad_stride,
+                             const double *coef_dev, const double *scale_dev, int n_cand, double *out_dev,
+                             int64_t out_stride, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Part 3 -- SPG building block (NEW solver="spg"; algorithm of bluest/spg.py:39-132 with proj = simplex)
+ *
+ * p = P_simplex(x - lambda*g), d = p - x, where P projects onto {p >= 0, sum p = z}.
+ * stats_dev[0] = g.d, stats_dev[1] = max|d|, stats_dev[2] = tau (threshold, after shifting by max),
+ * stats_dev[3] = number of positive entries of p.  g_dev may be NULL (then lambda is ignored: p = P(x)).
+ * d_dev or p_dev may be NULL.
+ * ---------------------------------------------------------------------------------------------------- */
+int bluest_simplex_project(const double *x_dev, const double *g_dev, double lambda, double z, int64_t L,
+                           double *p_dev, double *d_dev, double *stats_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLUEST_HIP_H */

@@ -1,0 +1,397 @@
+"""
+GPU parity tests (-m gpu): the HIP path, called through the C-ABI (ctypes -> libbluest_hip.so), against
+  (1) the golden vectors produced by the real reference (tests/golden/, oracle/gen_golden.py),
+  (2) the CPU oracle on the same seeded inputs,
+  (3) size-independent properties at BASELINE.json's full sizes.
+Tolerance: float64 work, north-star bar is 1e-10 relative; most checks hold 1e-12.  Where the inputs are
+ill-conditioned (Hodgkin-Huxley paper data, cond 1e9..5e10) the bound is cond*eps and is written in the test.
+"""
+import numpy as np
+import pytest
+
+from bluest_amd import synth
+from conftest import golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    from bluest_amd import _lib
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    assert _lib.device_count() >= 1
+    return torch
+
+
+def _split(prefix, G):
+    return {k[len(prefix):]: v for k, v in G.items() if k.startswith(prefix)}
+
+
+def test_cmisc_mirror_known_answers(gpu):
+    """Part 1 of the C-ABI against every native function of the compiled reference (cmisc.cpp:99-110)"""
+    from bluest_amd import misc
+    G = golden("cmisc_known_answers.npz")
+    N = int(G["N"])
+    for k, q in ((1, 2), (2, 3), (3, 3), (4, 2)):
+        g = _split("k%dq%d_" % (k, q), G)
+        Lk, Lq = len(g["gk"]), len(g["gq"])
+        assert rel_err(misc.assemble_psi(N, k, Lk, g["gk"], g["ick"]), g["psi"]) == 0.0
+        assert rel_err(misc.objectiveK(N, k, Lk, g["mk"], g["gk"], g["ick"]), g["PHI"]) < 1e-14
+        assert rel_err(misc.objectiveK(N, k, Lk, g["mki"], g["gk"], g["ick"]), g["PHIi"]) < 1e-14
+        assert rel_err(misc.gradK(k, Lk, g["gk"], g["ick"], g["P"]), g["grad"]) < 1e-14
+        assert rel_err(misc.cleanupK(k, Lk, g["gk"], g["ick"], g["P"]), g["X"]) < 1e-15
+        assert rel_err(misc.hessKQ(k, q, Lk, Lq, g["gk"], g["gq"], g["ick"], g["icq"], g["P"]), g["hess"]) < 1e-13
+    # in-place accumulation contract (+=) of the native module
+    g = _split("k3q3_", G)
+    PHI = np.ones(N * N)
+    misc.objectiveK_c(PHI, N, 3, len(g["gk"]), g["mk"], g["gk"].ravel(), g["ick"])
+    assert rel_err(PHI - 1.0, g["PHI"]) < 1e-13
+    with pytest.raises(TypeError):
+        misc.objectiveK_c(np.ones(N * N, dtype=np.float32), N, 3, len(g["gk"]), g["mk"], g["gk"].ravel(), g["ick"])
+
+
+def test_cmisc_mirror_device_pointers(gpu):
+    """the stateless entry points also take device pointers (no PCIe staging)"""
+    import ctypes
+    from bluest_amd import _lib
+    torch = gpu
+    G = golden("cmisc_known_answers.npz")
+    N = int(G["N"])
+    g = _split("k3q3_", G)
+    Lk = len(g["gk"])
+    dev = torch.device("cuda")
+    PHI = torch.zeros(N * N, dtype=torch.float64, device=dev)
+    mk = torch.from_numpy(g["mk"]).to(dev)
+    gk = torch.from_numpy(g["gk"].ravel()).to(dev)
+    ic = torch.from_numpy(g["ick"]).to(dev)
+    _lib.check(_lib.lib().bluest_objectiveK_f64(PHI.data_ptr(), N, 3, Lk, mk.data_ptr(), gk.data_ptr(), ic.data_ptr()))
+    assert rel_err(PHI.cpu().numpy(), g["PHI"]) < 1e-14
+    grad = torch.zeros(Lk, dtype=torch.float64, device=dev)
+    v = torch.from_numpy(np.ascontiguousarray(g["P"][0])).to(dev)
+    _lib.check(_lib.lib().bluest_gradK(grad.data_ptr(), 3, Lk, gk.data_ptr(), ic.data_ptr(), v.data_ptr(), N))
+    assert rel_err(grad.cpu().numpy(), g["grad"]) < 1e-14
+
+
+CASES = ("base", "sparse", "drop_last_model", "only_first3", "int64")
+
+
+def _check_sap_file(fname, tol=TOL, via_mosap=False):
+    from bluest_amd.mosap import MOSAP
+    from bluest_amd.sap import SAP
+    G = golden(fname)
+    n, kmax, n_out = int(G["n"]), int(G["kmax"]), int(G["n_out"])
+    prob = synth.problem(n, kmax, n_out)
+    if via_mosap:
+        mos = MOSAP([c.copy() for c in prob["C"]], kmax, [kmax] * n_out, [g.copy() for g in prob["groups"]],
+                    [[g.copy() for g in prob["groups"]] for _ in range(n_out)], prob["costs"], [prob["costs"]] * n_out,
+                    verbose=False)
+    for o in range(n_out):
+        sap = mos.SAPS[o] if via_mosap else SAP(prob["C"][o].copy(), kmax, [g.tolist() for g in prob["groups"]], prob["costs"],
+                                                 verbose=False)
+        if o == 0:
+            ic = np.concatenate(sap.invcovs)
+            if "invcovs_o0" in G:
+                assert rel_err(ic, G["invcovs_o0"]) < 1e-12     # GPU Jacobi pinv vs numpy SVD pinv (sap.py:74)
+            else:
+                assert rel_err(ic[::101], G["invcovs_o0_sub"]) < 1e-12
+                assert abs(np.linalg.norm(ic) / G["invcovs_o0_norm"] - 1) < 1e-13
+            if "psi_o0" in G:
+                assert rel_err(sap.psi, G["psi_o0"]) < 1e-12
+        for name in CASES:
+            m = prob["m"][o] if name == "base" else G["o%d_%s_m" % (o, name)]
+            mf = m.astype(np.float64)
+            for delta in ((0.0, 1e-6) if name in ("base", "drop_last_model") else (0.0,)):
+                tag = "o%d_%s_" % (o, name) + ("d%g_" % delta if delta else "")
+                if via_mosap:
+                    V = mos.variances(mf, delta=delta)[o]
+                    Vs, gs, _ = mos.variance_GH(mf, nohess=True, delta=delta)
+                    Vgh, grad = Vs[o], gs[o]
+                    PHI = mos.plan.phi_matrix(mf, delta=delta)[0, o].cpu().numpy()
+                else:
+                    V = sap.variance(mf, delta=delta)
+                    Vgh, grad, _ = sap.variance_GH(mf, delta=delta, nohess=True)
+                    PHI = sap.get_phi(mf, delta=delta)
+                assert abs(V / G[tag + "V"] - 1) < tol, (tag, V, G[tag + "V"])
+                assert abs(Vgh / G[tag + "Vgh"] - 1) < tol
+                assert rel_err(PHI, G[tag + "PHI"]) < tol
+                if tag + "grad" in G:
+                    assert rel_err(grad, G[tag + "grad"]) < tol
+                else:
+                    assert rel_err(grad[::97], G[tag + "grad_sub"]) < tol
+                    assert abs(np.linalg.norm(grad) / G[tag + "grad_norm"] - 1) < tol
+                if tag + "hess" in G and not via_mosap:
+                    assert rel_err(sap.variance_GH(mf, delta=delta)[2], G[tag + "hess"]) < 1e-10
+        if not via_mosap:
+            # all-tiny allocation -> inf (misc.py:464,484), 2-tuple from variance_GH as in the reference
+            tiny = 0.01 * np.ones(sap.L)
+            assert np.isinf(sap.variance(tiny))
+            out = sap.variance_GH(tiny, nohess=True)
+            assert len(out) == 2 and np.isinf(out[0]) and np.isinf(out[1]).all()
+
+
+@pytest.mark.parametrize("fname", ["sap_n5_all.npz", "sap_n6_all.npz", "sap_n12_all.npz"])
+def test_sap_golden_small(gpu, fname):
+    _check_sap_file(fname)
+
+
+def test_mosap_golden_n20_k5_o8(gpu):
+    """the headline configuration (n=20, k_max=5, K_tot=21699, n_out=8): all outputs in one plan"""
+    _check_sap_file("sap_n20_k5_o8.npz", via_mosap=True)
+
+
+def test_model0_unsampled(gpu):
+    """misc.py:470: variance() raises AssertionError; variance_GH() does not (it has no such assert)"""
+    from bluest_amd.sap import SAP
+    prob = synth.problem(5, 3, 1)
+    sap = SAP(prob["C"][0], 3, [g.tolist() for g in prob["groups"]], prob["costs"], verbose=False)
+    m = prob["m"][0].copy()
+    m[sap.e == 1] = 0.0
+    with pytest.raises(AssertionError):
+        sap.variance(m)
+    V, g, _ = sap.variance_GH(m, nohess=True)
+    assert np.isfinite(V) and np.isfinite(g).all()
+
+
+def test_mosap_ragged(gpu, oracle):
+    """different group sets per output: mappings (mosap.py:54-67) and fan-out (mosap.py:86-100)"""
+    from bluest_amd.mosap import MOSAP
+    G = golden("mosap_n6_o3_ragged.npz")
+    n, n_out, kmax = int(G["n"]), int(G["n_out"]), int(G["kmax"])
+    prob = synth.problem(n, kmax, n_out)
+    groups = [G["g_k%d" % k].tolist() for k in range(1, kmax + 1)]
+    multi_groups = [[G["mg%d_k%d" % (o, k)].tolist() for k in range(1, kmax + 1)] for o in range(n_out)]
+    w = prob["w"]
+    costs = synth.group_costs([np.array(g) for g in groups], w)
+    multi_costs = [synth.group_costs([np.array(g) for g in mg], w) for mg in multi_groups]
+    mos = MOSAP(prob["C"], kmax, [kmax] * n_out, groups, multi_groups, costs, multi_costs, verbose=False)
+    assert isinstance(groups[0], np.ndarray) and groups[0].dtype == np.int64   # converted in place (mosap.py:34)
+    for o in range(n_out):
+        assert (mos.mappings[o] == G["map%d" % o]).all()
+    assert (mos.e == G["e"]).all()
+    assert rel_err(mos.variances(G["m"]), G["Vs"]) < TOL
+    Vgh, grads, _ = mos.variance_GH(G["m"], nohess=True)
+    assert rel_err(Vgh, G["Vgh"]) < TOL
+    for o in range(n_out):
+        assert rel_err(grads[o], G["grad%d" % o]) < TOL
+        # the per-output view evaluates its own local allocation (SAPS[n].variance(m[mappings[n]]))
+        assert abs(mos.SAPS[o].variance(G["m"][mos.mappings[o]]) / G["Vs"][o] - 1) < TOL
+
+
+def test_hh_paper_known_answer(gpu):
+    """Hodgkin-Huxley paper data (n=12, n_out=5, k_max=7, K_tot=3301), stored integer allocation.
+    cond(C) = 1e9..5e10: V agrees with the reference to cond*eps ~ 1e-6; errors/eps to 4 digits."""
+    from bluest_amd.mosap import MOSAP
+    G = golden("hh_paper_known_answer.npz")
+    n, n_out, kmax = int(G["n"]), int(G["n_out"]), int(G["kmax"])
+    groups = synth.all_groups(n, kmax)
+    costs = synth.group_costs(groups, G["costs"])
+    Cs = [G["C%d" % o] for o in range(n_out)]
+    mos = MOSAP(Cs, kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in groups] for _ in range(n_out)],
+                costs, [costs] * n_out, verbose=False)
+    samples = G["samples"]
+    Vs = np.array(mos.variances(samples))        # int64 allocation goes straight in
+    assert rel_err(Vs, G["Vs"]) < 1e-5
+    eps = np.sqrt(np.array([C[0, 0] for C in Cs])) / 1000
+    assert np.allclose(np.sqrt(Vs) / eps, [0.8906, 1.00004, 0.9479, 0.5477, 0.5583], rtol=2e-4)
+    assert abs(float(samples @ costs) / 60626.8057 - 1) < 1e-8
+
+
+@pytest.mark.parametrize("fname", ["spg_traj_n6.npz", "spg_traj_n12_k4.npz"])
+def test_spg_trajectory(gpu, fname):
+    """m* parity is trajectory parity: the same SPG driver with GPU callbacks and the GPU simplex
+    projection reproduces, evaluation by evaluation, the run of the reference spg() with the reference's CPU
+    callbacks: same iteration and evaluation counts, every f within 1e-9, final x within 1e-6."""
+    torch = gpu
+    from bluest_amd.plan import simplex_project
+    from bluest_amd.sap import SAP
+    from bluest_amd.spg import spg
+    G = golden(fname)
+    n, kmax = int(G["n"]), int(G["kmax"])
+    prob = synth.problem(n, kmax, 1)
+    sap = SAP(prob["C"][0], kmax, [g.tolist() for g in prob["groups"]], prob["costs"], verbose=False)
+    dev = sap.plan.device
+    scale = torch.from_numpy(prob["budget"] / prob["costs"]).to(dev)
+    fvals, gnorms = [], []
+
+    def feval(x):
+        try:
+            f = sap.variance(scale * x)
+        except AssertionError:
+            f = np.inf
+        fvals.append(f)
+        return f
+
+    def geval(x):
+        g = scale * sap.variance_GH(scale * x, nohess=True)[1]
+        gnorms.append(float(torch.linalg.norm(g)))
+        return g
+
+    def proj(x):
+        return simplex_project(x, want_d=False)[0]
+
+    x0 = torch.full((sap.L,), 1.0 / sap.L, dtype=torch.float64, device=dev)
+    res = spg(feval, geval, proj, x0, eps=float(G["eps"]), maxit=int(G["maxit"]), max_fevals=10 ** 5, verbose=False)
+    assert res["it"] == int(G["it"]) and res["count"] == int(G["count"]) and res["solver_info"] == int(G["solver_info"])
+    assert len(fvals) == len(G["fvals"])
+    fin = np.isfinite(G["fvals"])
+    assert (np.isfinite(fvals) == fin).all()
+    assert rel_err(np.array(fvals)[fin], G["fvals"][fin]) < 1e-9
+    assert rel_err(gnorms, G["gnorms"]) < 1e-7
+    assert abs(res["f"] / float(G["f"]) - 1) < 1e-9
+    assert rel_err(res["x"].cpu().numpy(), G["x"]) < 1e-6
+
+
+def test_simplex_projection_vs_oracle(gpu, oracle):
+    torch = gpu
+    from bluest_amd.plan import simplex_project
+    rng = np.random.RandomState(0)
+    dev = torch.device("cuda")
+    for L in (1, 2, 63, 64, 65, 1000, 4096, 4097, 21699, 32768, 32769, 100000):
+        for scale in (1.0, 1e-6, 1e30):
+            v = scale * rng.randn(L)
+            if L > 2:
+                v[rng.randint(L)] = v.max()          # ties at the maximum
+            want = oracle.simplex_projection(v)
+            x = torch.from_numpy(v).to(dev)
+            p, d, stats = simplex_project(x)
+            p = p.cpu().numpy()
+            assert p.min() >= 0 and abs(p.sum() - 1) < 1e-12
+            assert np.abs(p - want).max() < 1e-14 * max(1.0, L ** 0.5), (L, scale)
+            assert np.abs(d.cpu().numpy() - (p - v)).max() <= 1e-16 * max(1.0, np.abs(v).max())
+            st = stats.cpu().numpy()
+            assert st[3] == (p > 0).sum() and abs(st[1] - np.abs(p - v).max()) <= 1e-15 * max(1.0, np.abs(v).max())
+    # fused step: p = P(x - lambda g), g.d
+    L = 21699
+    xv, gv = rng.rand(L) / L, rng.randn(L)
+    for lam in (0.0, 1e-3, 1.0, 1e30):
+        want = oracle.simplex_projection(xv - lam * gv)
+        p, d, stats = simplex_project(torch.from_numpy(xv).to(dev), torch.from_numpy(gv).to(dev), lam)
+        assert np.abs(p.cpu().numpy() - want).max() < 1e-13
+        assert abs(float(stats[0]) - gv @ (want - xv)) <= 1e-12 * max(1.0, np.abs(gv).sum())
+
+
+def test_group_pinv_vs_oracle(gpu, oracle):
+    """per-group pseudo-inverse (sap.py:69-79) incl. group sizes 1..12, a singular block and an unsorted group"""
+    from bluest_amd import misc
+    rng = np.random.RandomState(2)
+    C, _ = synth.wishart_covariance(14)
+    for k in range(1, 13):
+        g = np.array([rng.choice(14, k, replace=False) for _ in range(70)], dtype=np.int64)
+        got = misc.group_pinv(C, k, g)
+        want = np.concatenate([np.linalg.pinv(C[np.ix_(gi, gi)]).ravel() for gi in g])
+        assert rel_err(got, want) < 1e-11, k
+    Cs = C.copy(); Cs[3] = Cs[2]; Cs[:, 3] = Cs[:, 2]            # models 2,3 perfectly correlated -> singular block
+    g = np.array([[1, 2, 3], [0, 2, 3]], dtype=np.int64)
+    got = misc.group_pinv(Cs, 3, g)
+    want = np.concatenate([np.linalg.pinv(Cs[np.ix_(gi, gi)]).ravel() for gi in g])
+    assert rel_err(got, want) < 1e-9
+
+
+# ---- size-independent properties at full size --------------------------------------------------------
+
+def _mosap(n, kmax, n_out, max_candidates=1):
+    from bluest_amd.mosap import MOSAP
+    prob = synth.problem(n, kmax, n_out)
+    groups = prob["groups"]
+    mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in groups] for _ in range(n_out)],
+                prob["costs"], [prob["costs"]] * n_out, verbose=False, max_candidates=max_candidates)
+    return prob, mos
+
+
+def _properties(torch, prob, mos, fd_checks=3):
+    plan = mos.plan
+    dev = plan.device
+    n_out, L = plan.n_out, plan.L
+    rng = np.random.RandomState(42)
+    m1 = torch.from_numpy(prob["m"][0]).to(dev)
+    m2 = torch.from_numpy(10 * rng.rand(L)).to(dev)
+    # bitwise reproducibility (no float atomics on the plan path)
+    a = plan.eval(m1)
+    b = plan.eval(m1)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    var1, grad1, st = a
+    assert (st == 0).all()
+    # linearity of Phi in m (misc.py:459-461)
+    P1, P2, P12 = plan.phi_matrix(m1), plan.phi_matrix(m2), plan.phi_matrix(0.3 * m1 + 1.7 * m2)
+    assert float((P12 - (0.3 * P1 + 1.7 * P2)).abs().max() / P12.abs().max()) < 1e-13
+    # Phi symmetric, V > 0, gradient <= 0
+    assert float((P1 - P1.transpose(-1, -2)).abs().max()) == 0.0
+    assert (var1 > 0).all() and (grad1 <= 0).all()
+    # homogeneity: V(t m) = V(m)/t, grad(t m) = grad(m)/t^2, and Euler: m_o . grad_o = -V_o
+    var_t, grad_t, _ = plan.eval(4.0 * m1)
+    assert float((var_t * 4.0 / var1 - 1).abs().max()) < 1e-12
+    assert float((grad_t * 16.0 - grad1).abs().max() / grad1.abs().max()) < 1e-12
+    for o in range(n_out):
+        go = grad1[0, plan.grad_off[o]:plan.grad_off[o] + len(mos.mappings[o])]
+        mo = m1[torch.from_numpy(mos.mappings[o]).to(dev)]
+        assert abs(float(go @ mo) / float(var1[0, o]) + 1) < 1e-11
+    # directional finite differences of V along random directions
+    for _ in range(fd_checks):
+        dvec = torch.from_numpy(rng.rand(L)).to(dev)
+        h = 1e-6
+        vp, _, _ = plan.eval(m1 + h * dvec, want_grad=False)
+        vm, _, _ = plan.eval(m1 - h * dvec, want_grad=False)
+        fd = (vp - vm)[0] / (2 * h)
+        for o in range(n_out):
+            go = grad1[0, plan.grad_off[o]:plan.grad_off[o] + len(mos.mappings[o])]
+            an = float(go @ dvec[torch.from_numpy(mos.mappings[o]).to(dev)])
+            assert abs(float(fd[o]) / an - 1) < 1e-6
+    # three-phase path (phi record -> solve -> grad) == fused path, bit for bit
+    rec = plan.phi(m1)
+    var3, v3, st3 = plan.solve(rec)
+    grad3 = plan.grad(v3, st3)
+    assert torch.equal(var3, var1) and torch.equal(grad3, grad1)
+    # combine_grad: gradient of sum_o c_o V_o w.r.t. the global allocation
+    coef = torch.from_numpy(rng.rand(1, n_out)).to(dev)
+    gg = plan.combine_grad(grad1, coef)[0]
+    want = torch.zeros(L, dtype=torch.float64, device=dev)
+    for o in range(n_out):
+        want[torch.from_numpy(mos.mappings[o]).to(dev)] += coef[0, o] * grad1[0, plan.grad_off[o]:plan.grad_off[o] + len(mos.mappings[o])]
+    assert float((gg - want).abs().max() / want.abs().max()) < 1e-14
+
+
+def test_properties_n20_k5_o8(gpu):
+    prob, mos = _mosap(20, 5, 8)
+    assert mos.L == 21699
+    _properties(gpu, prob, mos)
+
+
+def test_properties_n12_all_groups(gpu):
+    prob, mos = _mosap(12, 12, 1)
+    assert mos.L == 4095
+    _properties(gpu, prob, mos)
+
+
+def test_properties_n25_k6(gpu, oracle):
+    """largest configuration of BASELINE.json (K_tot = 245505); also checked against the CPU oracle's sparse loop"""
+    prob, mos = _mosap(25, 6, 1)
+    assert mos.L == 245505
+    _properties(gpu, prob, mos, fd_checks=1)
+    sap = mos.SAPS[0]
+    m = prob["m"][0]
+    PHI = np.zeros(25 * 25)
+    for k in range(1, 7):
+        PHI += oracle.objectiveK(25, k, sap.sizes[k], m[sap.cumsizes[k - 1]:sap.cumsizes[k]], sap.groups[k - 1], sap.invcovs[k - 1])
+    got = mos.plan.phi_matrix(m)[0, 0].cpu().numpy()
+    assert rel_err(got, PHI.reshape(25, 25)) < 1e-12
+    V = mos.variances(m)[0]
+    idx = np.arange(25)
+    assert abs(V / np.linalg.solve(PHI.reshape(25, 25), np.eye(25, 1).ravel())[0] - 1) < 1e-10
+
+
+def test_candidate_batch(gpu):
+    """a batch of allocation vectors in one launch == one by one (line-search trial points, integer candidates)"""
+    torch = gpu
+    prob, mos = _mosap(12, 4, 3, max_candidates=5)
+    plan = mos.plan
+    rng = np.random.RandomState(1)
+    M = torch.from_numpy(10 * rng.rand(5, plan.L)).to(plan.device)
+    M[3, :] = 0.01                                  # -> inf
+    var, grad, st = plan.eval(M)
+    for c in range(5):
+        v1, g1, s1 = plan.eval(M[c])
+        assert torch.equal(var[c], v1[0]) and torch.equal(grad[c], g1[0]) and torch.equal(st[c], s1[0])
+    assert (st[3] == 1).all() and torch.isinf(var[3]).all() and torch.isinf(grad[3]).all()

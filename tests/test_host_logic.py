@@ -1,0 +1,50 @@
+"""CPU tests of the host-side logic that needs no GPU: group normalisation, indicator vectors, mappings,
+the SPG driver (on numpy), synthetic-input bookkeeping."""
+import numpy as np
+import pytest
+
+from bluest_amd import synth
+
+
+def test_algorithmic_bytes_match_survey():
+    assert synth.algorithmic_bytes(12, 12)["eval"] == 3014736
+    assert synth.algorithmic_bytes(20, 5)["eval"] == 9577424
+    assert synth.algorithmic_bytes(25, 6)["eval"] == 152961080
+    assert synth.n_groups(20, 5) == 21699 and synth.n_groups(25, 6) == 245505 and synth.n_groups(12, 12) == 4095
+
+
+def test_indicator_vectors_and_mappings():
+    from bluest_amd.mosap import build_mappings
+    from bluest_amd.sap import indicator_vectors, normalise_groups
+    groups = [[(0,), (1,), (2,)], [(0, 1), (0, 2), (1, 2)], [(0, 1, 2)]]
+    flat = normalise_groups(groups, 3)
+    assert flat == [[0], [1], [2], [0, 1], [0, 2], [1, 2], [0, 1, 2]]
+    assert all(isinstance(g, np.ndarray) and g.dtype == np.int64 for g in groups)
+    ES = indicator_vectors(groups, 3)
+    assert (ES[0] == [1, 0, 0, 1, 1, 0, 1]).all() and (ES[2] == [0, 0, 1, 0, 1, 1, 1]).all()
+    cum = np.cumsum([0, 3, 3, 1])
+    mg = [[np.array([[0], [2]]), np.array([[1, 2]]), np.zeros((0, 3), dtype=np.int64)],
+          [np.array([[1]]), np.array([[0, 1], [0, 2]]), np.array([[0, 1, 2]])]]
+    maps = build_mappings(groups, mg, cum)
+    assert maps[0].tolist() == [0, 2, 5] and maps[1].tolist() == [1, 3, 4, 6]
+    with pytest.raises(AssertionError):
+        build_mappings(groups, [[np.array([[7]])]], cum)
+
+
+def test_spg_driver_on_numpy(oracle):
+    """same driver as on the GPU, numpy vectors: box-simplex QP with known solution; identical to the oracle's spg"""
+    from bluest_amd.spg import spg
+    rng = np.random.RandomState(0)
+    A = rng.randn(30, 30); A = A @ A.T + np.eye(30)
+    b = rng.randn(30)
+    feval = lambda x: 0.5 * x @ A @ x - b @ x
+    geval = lambda x: A @ x - b
+    proj = oracle.simplex_projection
+    x0 = np.ones(30) / 30
+    r1 = spg(feval, geval, proj, x0, eps=1e-10, maxit=500, verbose=False)
+    r2 = oracle.spg(feval, geval, proj, x0, eps=1e-10, maxit=500)
+    assert r1["solver_info"] == 0 and r1["it"] == r2["it"] and r1["count"] == r2["count"]
+    assert np.array_equal(r1["x"], r2["x"]) and r1["f"] == r2["f"]
+    # KKT: gradient constant on the support, larger off it
+    g = geval(r1["x"]); sup = r1["x"] > 0
+    assert np.ptp(g[sup]) < 1e-8 and (g[~sup] >= g[sup].max() - 1e-8).all()

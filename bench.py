@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of the BLUEST sample-allocation hot path on MI355X.
+
+metric   : Phi-assemblies/s.  One assembly = for ONE output, build Phi(m) over all K_tot groups, solve for
+           V = e0^T Phi^-1 e0 and evaluate grad V for every group.
+workload : BASELINE.json configs[3]: n=20 models, groups up to size 5 (K_tot=21699), n_out=8 outputs,
+           synthetic Wishart covariances (bluest_amd/synth.py).  A "step" evaluates one allocation vector m for
+           all 8 outputs (what one SPG iteration / one MOSAP.variance_GH call does): 3 kernel launches
+           (Phi chunks -> fold+solve -> gradient tiles), inputs resident in HBM, results left in HBM.
+N > 1    : the group set is sharded across the ranks (one process per GPU); each step all-reduces the partial
+           Phi records (n_out*(n^2+2n+1) f64) over RCCL, then every rank solves redundantly and evaluates the
+           gradient of its shard.  Total work is fixed => "scaling": "strong".
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_MODELS, KMAX, N_OUT = 20, 5, 8
+HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_outputs(prob, lo=None, hi=None):
+    """plan description for all outputs; optionally only the groups with global index in [lo, hi) (a shard)"""
+    outs = []
+    groups = prob["groups"]
+    sizes = [len(g) for g in groups]
+    cum = np.concatenate([[0], np.cumsum(sizes)])
+    for o in range(prob["n_out"]):
+        if lo is None:
+            outs.append({"K": prob["kmax"], "sizes": sizes, "groups": groups, "C": prob["C"][o], "mapping": None})
+        else:
+            sg, ss, mp = [], [], []
+            for k in range(prob["kmax"]):
+                a, b = max(lo, cum[k]) - cum[k], min(hi, cum[k + 1]) - cum[k]
+                a, b = int(max(a, 0)), int(max(b, 0))
+                if b < a:
+                    b = a
+                sg.append(groups[k][a:b])
+                ss.append(b - a)
+                mp.append(np.arange(cum[k] + a, cum[k] + b, dtype=np.int64))
+            outs.append({"K": prob["kmax"], "sizes": ss, "groups": sg, "C": prob["C"][o], "mapping": np.concatenate(mp)})
+    return outs
+
+
+def shard_bounds(prob, rank, world):
+    """contiguous shards balanced by sum k^2 (the streamed bytes), SURVEY.md 8e"""
+    w = np.concatenate([np.full(len(g), (k + 1) ** 2, dtype=np.float64) for k, g in enumerate(prob["groups"])])
+    c = np.concatenate([[0.0], np.cumsum(w)])
+    cuts = [int(np.searchsorted(c, c[-1] * r / world)) for r in range(world + 1)]
+    cuts[0], cuts[-1] = 0, len(w)
+    return cuts[rank], cuts[rank + 1]
+
+
+def cpu_baseline(prob, seconds=12.0):
+    """reference CPU path restated in plain C (oracle/), one host core, output 0 only (bounded sample):
+    B1 = as executed by the reference (dense psi GEMV + pinv + gradK loops, misc.py:479-495),
+    B2 = sparse objectiveK_c-style loop (cmisc.cpp:25-40) + the same solve and gradK."""
+    from oracle import oracle as orc
+    orc.build()
+    sap = orc.OracleSAP(prob["C"][0], prob["kmax"], prob["groups"], prob["costs"])
+    m = prob["m"][0]
+    res = {}
+    for name, dense in (("B1_dense_psi", True), ("B2_sparse", False)):
+        sap.c_variance_GH(m, dense=dense)
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < seconds / 2:
+            sap.c_variance_GH(m, dense=dense)
+            reps += 1
+        res[name] = reps / (time.perf_counter() - t0)
+    return {"value": res["B1_dense_psi"], "unit": "Phi-assemblies/s", "cores": 1, "kind": "port",
+            "sample": "output 0 of the n=20,k_max=5 workload, variance+gradient evaluations repeated for ~%.0f s on one core; "
+                      "B1 = dense psi@m + pinv + gradK as the reference executes (bluest/misc.py:479-495)" % (seconds / 2),
+            "B2_sparse_value": res["B2_sparse"], "host_cores_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--graph-steps", type=int, default=40, help="steps captured per hipGraph")
+    ap.add_argument("--n", type=int, default=N_MODELS)
+    ap.add_argument("--kmax", type=int, default=KMAX)
+    ap.add_argument("--n-out", type=int, default=N_OUT)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from bluest_amd import synth
+    from bluest_amd.plan import Plan
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs the torch.distributed.run launcher with --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    prob = synth.problem(args.n, args.kmax, args.n_out)
+    L = prob["K_tot"]
+    if world == 1:
+        plan = Plan(args.n, L, build_outputs(prob), max_candidates=1, device=dev)
+    else:
+        lo, hi = shard_bounds(prob, rank, world)
+        plan = Plan(args.n, L, build_outputs(prob, lo, hi), max_candidates=1, device=dev)
+    n_out = plan.n_out
+
+    # a small ring of different allocation vectors so that consecutive steps do not repeat the same input
+    rng = np.random.RandomState(2024)
+    ring = [torch.from_numpy(prob["m"][0]).to(dev)] + [torch.from_numpy(10.0 * rng.rand(L)).to(dev) for _ in range(3)]
+    var = torch.empty((1, n_out), dtype=torch.float64, device=dev)
+    grad = torch.empty((1, plan.grad_len), dtype=torch.float64, device=dev)
+    status = torch.empty((1, n_out), dtype=torch.int32, device=dev)
+    rec = torch.empty((1, n_out, plan.reclen), dtype=torch.float64, device=dev)
+
+    def step(i):
+        m = ring[i % len(ring)]
+        if world == 1:
+            plan.eval(m, out=(var, grad, status))
+        else:
+            plan.phi(m, out=rec)
+            dist.all_reduce(rec)
+            v2, vv, st = plan.solve(rec)
+            plan.grad(vv, st, out=grad)
+            var.copy_(v2)
+
+    # ---- optional hipGraph of one ring cycle (single GPU; RCCL is left eager) -----------------------
+    use_graph = (world == 1) and not args.no_graph
+    cycle = max(len(ring), args.graph_steps - args.graph_steps % len(ring))
+    graph = None
+    if use_graph:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for i in range(cycle):
+                step(i)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for i in range(cycle):
+                step(i)
+
+    def run(nsteps):
+        if graph is not None:
+            for _ in range(nsteps // cycle):
+                graph.replay()
+            for i in range(nsteps % cycle):
+                step(i)
+        else:
+            for i in range(nsteps):
+                step(i)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    assert bool((status == 0).all()) or world > 1
+    assert bool(torch.isfinite(var).all())
+
+    # ---- per-kernel durations with HIP events on the launch stream (single GPU) -----------------------
+    roofline = None
+    kern = {}
+    if rank == 0:
+        ab = synth.algorithmic_bytes(args.n, args.kmax)
+        if world == 1:
+            st = torch.cuda.current_stream()
+            m = ring[0]
+            reps = 300
+            v_ws = torch.empty((1, n_out, args.n), dtype=torch.float64, device=dev)
+
+            def timed(fn):
+                fn()
+                torch.cuda.synchronize()
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+                for a, b in evs:
+                    a.record(st); fn(); b.record(st)
+                torch.cuda.synchronize()
+                return float(np.median([a.elapsed_time(b) for a, b in evs])) * 1e-3
+
+            empty = timed(lambda: None)
+            from bluest_amd.plan import _stream
+            lib, h = plan.lib, plan._h
+            var2, vv, st2 = plan.solve(plan.phi(m, out=rec))
+            t_chunks = timed(lambda: lib.bluest_plan_phi_chunks(h, m.data_ptr(), 1, L, _stream())) - empty
+            t_nograd = timed(lambda: plan.eval(m, want_grad=False, out=(var, None, status))) - empty
+            t_grad = timed(lambda: plan.grad(vv, st2, out=grad)) - empty
+            t_step = timed(lambda: plan.eval(m, out=(var, grad, status))) - empty
+            kern = {"event_pair_overhead_us": empty * 1e6, "k_phi_chunks_us": t_chunks * 1e6,
+                    "k_phi_chunks+k_solve_from_chunks_us": t_nograd * 1e6, "k_grad_tiles_us": t_grad * 1e6,
+                    "eager_step_3_kernels_us": t_step * 1e6}
+            # dominant kernel = the longer of the two streaming passes
+            if t_grad >= t_chunks:
+                kname, tk, abytes, lbytes = "k_grad_tiles", max(t_grad, 1e-9), ab["grad"] * n_out, plan.grad_bytes
+            else:
+                kname, tk, abytes, lbytes = "k_phi_chunks", max(t_chunks, 1e-9), ab["phi"] * n_out, plan.phi_bytes
+            achieved = abytes / tk
+            roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK, "traffic": None,
+                        "algorithmic_bytes_per_launch": abytes, "layout_bytes_per_launch": lbytes, "avg_launch_us": tk * 1e6,
+                        "step": {"algorithmic_bytes": ab["eval"] * n_out, "achieved_GBps": ab["eval"] * n_out * args.steps / elapsed / 1e9,
+                                 "frac": ab["eval"] * n_out * args.steps / elapsed / HBM_PEAK}}
+
+    if rank == 0:
+        out = {
+            "metric": "Phi-assemblies/s", "value": args.steps * n_out / elapsed, "unit": "assemblies/s (one output: Phi(m) over all groups -> V, grad V)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "n=%d models, groups up to size %d (K_tot=%d), n_out=%d, Wishart covariances; one step = V and grad V of one allocation for all outputs"
+                                   % (args.n, args.kmax, L, n_out),
+                       "n_models": args.n, "k_max": args.kmax, "K_tot": L, "n_out": n_out, "batch": 1,
+                       "parallelism": "single GPU" if world == 1 else "group set sharded over %d GPUs, RCCL all-reduce of Phi per step" % world,
+                       "launch": "hipGraph replay" if graph is not None else "eager"},
+            "kernels_us": kern,
+        }
+        if roofline is not None:
+            out["roofline"] = roofline
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(prob)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

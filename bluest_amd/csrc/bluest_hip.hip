@@ -1322,6 +1322,16 @@ static void launch_chunks(bluest_plan_t p, const double *m, int n_cand, int64_t 
                        p->iters, p->n_chunks, m, m_stride, n_cand, p->d_partial);
 }
 
+extern "C" int bluest_plan_phi_chunks(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, void *stream)
+{
+    int rc = plan_ready(plan, n_cand); if (rc) return rc;
+    if (!m_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (n_cand > 1 && m_stride < plan->L) return fail(BLUEST_ERR_ARG, "m_stride < L_global");
+    launch_chunks(plan, m_dev, n_cand, m_stride, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
 extern "C" int bluest_plan_phi(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, double *phi_dev, void *stream)
 {
     int rc = plan_ready(plan, n_cand); if (rc) return rc;

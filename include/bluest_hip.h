@@ -132,6 +132,10 @@ int bluest_plan_phi_len(bluest_plan_t plan, int64_t *len);
 int bluest_plan_phi(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, double *phi_dev,
                     void *stream);
 
+/* Diagnostics: launch ONLY the Phi chunk kernel (partials stay in the plan's workspace); lets bench.py time
+ * the streaming kernel alone with HIP events. */
+int bluest_plan_phi_chunks(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, void *stream);
+
 /* Phase B (a7/a8): from the (all-reduced) records, V = (Phi[idx,idx]^-1)_00 on the sampled models
  * (bluest/misc.py:467-472,490), v = row 0 of pinv(Phi + delta I) (bluest/misc.py:487), status codes above.
  * var_dev: n_cand*n_outputs, v_dev: n_cand*n_outputs*N, status_dev: n_cand*n_outputs int32. */

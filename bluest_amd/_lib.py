@@ -62,6 +62,9 @@ def lib():
             raise BluestHipError(
                 "%s not found: build the HIP extension first (python -m bluest_amd.build). "
                 "bluest_amd has no CPU fallback." % LIB_PATH)
+        # torch bundles its own libamdhip64.so.7; load it FIRST so that this library binds to the same HIP runtime
+        # (two runtimes in one process cannot both own the device)
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)

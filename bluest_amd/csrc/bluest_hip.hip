@@ -401,83 +401,101 @@ __global__ __launch_bounds__(256) void k_phi_chunks(const double *__restrict__ v
     }
 }
 
+// ---- solve: one workgroup of 256 threads folds the chunk partials, then wavefront 0 factorises in REGISTERS ----
+//
+// Ordering trick: the restricted system is permuted so that the TARGET model (model 0 if it is sampled, else the
+// smallest sampled model, as pinv(PHI[idx])[0,0] of misc.py:490 would pick) comes LAST.  With A = L L^T and
+// e = e_last:  L y = e  =>  y = e_last / L_nn, so V = e^T A^-1 e = 1/L_nn^2 needs NO triangular solve, and
+// x = A^-1 e needs only the backward one.  Lane i holds row i of A / L in registers (static indices after full
+// unrolling); column broadcasts are v_readlane (SGPR operands), no LDS and no barriers inside the factorisation.
 #define LDA (BLUEST_MAX_MODELS + 1)
 struct SolveLds {
     double phi[BLUEST_MAX_MODELS * BLUEST_MAX_MODELS];  // full symmetric Phi (no delta)
-    double ar[BLUEST_MAX_MODELS * LDA];                 // compacted matrix / Cholesky factor
+    double lt[BLUEST_MAX_MODELS * LDA];                 // L, for the transposed read of the backward solve
     double amax[BLUEST_MAX_MODELS];                     // per model: max |m_i| over groups containing it
-    double rhs[BLUEST_MAX_MODELS];
-    double sol[BLUEST_MAX_MODELS];
+    int model_of_pos[BLUEST_MAX_MODELS];
 };
 
-// fold chunk partials of output `o`, candidate `c` into lds.phi / lds.amax (one wavefront)
+__device__ __forceinline__ double readlane_f64(double x, int l)
+{   // l must be wave-uniform (here: a compile-time constant after unrolling)
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double rsqrt_f64(double x)
+{   // v_rsq_f64 seed + two Newton steps (y <- y + y*(1 - x y^2)/2): full double accuracy for normal x > 0
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-x * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    return y;
+}
+
+// fold chunk partials of rows [row_begin, row_begin+n_rows) into lds.phi / lds.amax; all threads of the block
 __device__ __forceinline__ void fold_rows(SolveLds &lds, int N, const RowDesc *__restrict__ rows, int row_begin,
-                                          int n_rows, const double2 *__restrict__ partial, int lane)
+                                          int n_rows, const double2 *__restrict__ partial, int tid, int nthreads)
 {
-    for (int r = lane; r < n_rows; r += WAVE) {
+    for (int r = tid; r < n_rows; r += nthreads) {
         const RowDesc rd = rows[row_begin + r];
         const double2 *p = partial + rd.first_chunk;
         double s = 0.0, am = 0.0;
         int c = 0;
-        for (; c + 4 <= rd.n_chunks; c += 4) {   // 4 loads in flight, summed in chunk order
+        for (; c + 8 <= rd.n_chunks; c += 8) {   // 8 loads in flight, summed in chunk order
             const double2 p0 = p[c], p1 = p[c + 1], p2 = p[c + 2], p3 = p[c + 3];
-            s += p0.x; s += p1.x; s += p2.x; s += p3.x;
-            am = fmax(fmax(am, fmax(p0.y, p1.y)), fmax(p2.y, p3.y));
+            const double2 p4 = p[c + 4], p5 = p[c + 5], p6 = p[c + 6], p7 = p[c + 7];
+            s += p0.x; s += p1.x; s += p2.x; s += p3.x; s += p4.x; s += p5.x; s += p6.x; s += p7.x;
+            am = fmax(fmax(fmax(am, fmax(p0.y, p1.y)), fmax(p2.y, p3.y)), fmax(fmax(p4.y, p5.y), fmax(p6.y, p7.y)));
         }
-        for (; c < rd.n_chunks; c++) { const double2 p0 = p[c]; s += p0.x; am = fmax(am, p0.y); }
+        for (; c + 2 <= rd.n_chunks; c += 2) {
+            const double2 p0 = p[c], p1 = p[c + 1];
+            s += p0.x; s += p1.x;
+            am = fmax(am, fmax(p0.y, p1.y));
+        }
+        if (c < rd.n_chunks) { const double2 p0 = p[c]; s += p0.x; am = fmax(am, p0.y); }
         lds.phi[rd.a * N + rd.b] = s;
         lds.phi[rd.b * N + rd.a] = s;
         if (rd.a == rd.b) lds.amax[rd.a] = am;
     }
 }
 
-// Cholesky of the leading nr x nr block of lds.ar (row stride LDA), left-looking by columns, lane = row.
-// Returns false if a pivot is not positive.
-__device__ __forceinline__ bool chol_inplace(SolveLds &lds, int nr, int lane)
+// single-wavefront LDS ordering: LDS operations of one wave execute in order; this only stops the compiler from
+// moving LDS accesses across it and drains lgkmcnt
+__device__ __forceinline__ void wave_lds_sync()
 {
-    bool ok = true;
-    for (int j = 0; j < nr; j++) {
-        double s = 0.0;
-        if (lane >= j && lane < nr) {
-            s = lds.ar[lane * LDA + j];
-            for (int c = 0; c < j; c++) s = fma(-lds.ar[lane * LDA + c], lds.ar[j * LDA + c], s);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Right-looking Cholesky of the nr x nr matrix whose row `lane` sits in a[0..nr) (lower triangle used).
+// On return a[c] (c <= lane) = L[lane][c]; dv[j] = 1/L[j][j] (wave-uniform).  false if a pivot is not positive.
+template <int NT>
+__device__ __forceinline__ bool chol_regs(double (&a)[NT], double (&dv)[NT], int nr, double &last_pivot, double &last_dinv)
+{
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        if (j < nr) {
+            const double piv = readlane_f64(a[j], j);
+            if (!(piv > 0.0) || !isfinite(piv)) return false;
+            const double dinv = rsqrt_f64(piv);
+            last_pivot = piv;
+            last_dinv = dinv;
+            dv[j] = dinv;
+            a[j] *= dinv;
+#pragma unroll
+            for (int c = j + 1; c < NT; c++)
+                if (c < nr) a[c] = fma(-a[j], readlane_f64(a[j], c), a[c]);
         }
-        const double piv = __shfl(s, j, WAVE);
-        if (!(piv > 0.0) || !isfinite(piv)) { ok = false; break; }
-        const double d = sqrt(piv);
-        if (lane == j) lds.ar[j * LDA + j] = d;
-        else if (lane > j && lane < nr) lds.ar[lane * LDA + j] = s / d;
-        __syncthreads();
     }
-    return ok;
+    return true;
 }
 
-// solve (L L^T) x = e_pos using the factor in lds.ar; result in lds.sol[0..nr)
-__device__ __forceinline__ void chol_solve_unit(SolveLds &lds, int nr, int pos, int lane)
-{
-    double r = (lane == pos) ? 1.0 : 0.0;
-    // forward: L y = e_pos
-    for (int c = 0; c < nr; c++) {
-        double yc = 0.0;
-        if (lane == c) { yc = r / lds.ar[c * LDA + c]; lds.sol[c] = yc; }
-        yc = __shfl(yc, c, WAVE);
-        if (lane > c && lane < nr) r = fma(-lds.ar[lane * LDA + c], yc, r);
-    }
-    __syncthreads();
-    r = (lane < nr) ? lds.sol[lane] : 0.0;
-    // backward: L^T x = y
-    for (int c = nr - 1; c >= 0; c--) {
-        double xc = 0.0;
-        if (lane == c) { xc = r / lds.ar[c * LDA + c]; }
-        xc = __shfl(xc, c, WAVE);
-        if (lane == c) lds.sol[c] = xc;
-        if (lane < c) r = fma(-lds.ar[c * LDA + lane], xc, r);
-    }
-    __syncthreads();
-}
-
-// Given lds.phi / lds.amax (and `big` = max|m| >= 0.05), produce V, v, status for one (candidate, output).
-__device__ __forceinline__ void solve_core(SolveLds &lds, int N, double delta, bool s1, bool s2, bool big,
+// One (candidate, output): masks -> permuted restricted matrix in registers -> Cholesky -> V (-> v).
+// Called by ONE wavefront (lane = 0..63); lds.phi is ready.
+template <int NT>
+__device__ __forceinline__ void solve_wave(SolveLds &lds, int N, double delta, bool s1, bool s2, bool big, bool want_v,
                                            double *__restrict__ var_out, double *__restrict__ v_out,
                                            int32_t *__restrict__ status_out, int lane)
 {
@@ -485,108 +503,140 @@ __device__ __forceinline__ void solve_core(SolveLds &lds, int N, double delta, b
     const unsigned long long mask1 = __ballot(lane < N && s1);
     const unsigned long long mask2 = (delta != 0.0) ? __ballot(lane < N) : __ballot(lane < N && s2);
     int status = BLUEST_EVAL_OK;
-    double V = 0.0;
-    double vmine = 0.0;  // v[lane]
+    double V = 0.0, vmine = 0.0;
     if (!big) {
         status = BLUEST_EVAL_INF;
         V = INFINITY;
+    } else if (mask1 == 0ull) {
+        status = BLUEST_EVAL_NO_MODEL0;
+        V = NAN;
     } else {
         if (!(mask1 & 1ull)) status = BLUEST_EVAL_NO_MODEL0;
-        const int npass = (mask1 == mask2) ? 1 : 2;
+        const int npass = (mask1 == mask2 || !want_v) ? 1 : 2;
         for (int pass = 0; pass < npass; pass++) {
             const unsigned long long mask = (pass == 0) ? mask1 : mask2;
+            if (pass == 1 && !(mask & 1ull)) { vmine = 0.0; break; }   // row 0 of pinv(Phi) is zero
             const int nr = __popcll(mask);
+            const int target = __ffsll((long long)mask) - 1;           // smallest sampled model, ordered LAST
             const bool mine = lane < N && ((mask >> lane) & 1ull);
-            const int pos = __popcll(mask & ((1ull << lane) - 1ull));
-            __syncthreads();
-            if (mine) {
-                int cb = 0;
-                for (int b = 0; b < N; b++)
-                    if ((mask >> b) & 1ull) {
-                        double x = lds.phi[lane * N + b];
-                        if (b == lane) x += delta;
-                        lds.ar[pos * LDA + cb] = x;
-                        cb++;
-                    }
+            const int pos = (lane == target) ? nr - 1 : __popcll(mask & ((1ull << lane) - 1ull)) - 1;
+            wave_lds_sync();
+            if (mine) lds.model_of_pos[pos] = lane;
+            wave_lds_sync();
+            const bool rowlane = lane < nr;
+            const int rowm = rowlane ? lds.model_of_pos[lane] : 0;
+            double a[NT], dv[NT];
+#pragma unroll
+            for (int c = 0; c < NT; c++) {
+                a[c] = 0.0;
+                dv[c] = 0.0;
+                if (c < nr) {
+                    const double x = lds.phi[rowm * N + lds.model_of_pos[c]];
+                    a[c] = rowlane ? ((c == lane) ? x + delta : x) : 0.0;
+                }
             }
-            __syncthreads();
-            if (nr == 0) { if (pass == 0) V = NAN; continue; }
-            const bool ok = chol_inplace(lds, nr, lane);
-            __syncthreads();
+            double last_pivot = 0.0, last_dinv = 0.0;
+            const bool ok = chol_regs<NT>(a, dv, nr, last_pivot, last_dinv);
             if (!ok) {
                 if (status == BLUEST_EVAL_OK) status = BLUEST_EVAL_SINGULAR;
                 if (pass == 0) V = NAN;
-                if (pass == npass - 1) vmine = NAN;
+                vmine = NAN;
                 continue;
             }
-            if (pass == 0) {
-                chol_solve_unit(lds, nr, 0, lane);  // e_0 of the restricted system (misc.py:472,490)
-                V = lds.sol[0];
-                if (npass == 1) {  // same block serves v: row 0 of pinv(Phi) is this solution iff model 0 is in it
-                    vmine = (mine && (mask & 1ull)) ? lds.sol[pos] : 0.0;
+            if (pass == 0) V = 1.0 / last_pivot;     // = 1/L_nn^2 = (A^-1)_{target,target}
+            if (want_v && pass == npass - 1) {
+                if (!(mask & 1ull)) { vmine = 0.0; continue; }
+                // x = A^-1 e_last: y = L^-1 e_last = e_last/L_nn, then L^T x = y backwards.
+                // Lane i needs column i of L below the diagonal: transpose once through LDS.
+                wave_lds_sync();
+#pragma unroll
+                for (int c = 0; c < NT; c++)
+                    if (c < nr && rowlane && c <= lane) lds.lt[lane * LDA + c] = a[c];
+                wave_lds_sync();
+                double col[NT];
+#pragma unroll
+                for (int c = 0; c < NT; c++) col[c] = (c < nr && c > lane) ? lds.lt[c * LDA + lane] : 0.0;
+                double r = (lane == nr - 1) ? last_dinv : 0.0;
+                double xmine = 0.0;
+#pragma unroll
+                for (int c = NT - 1; c >= 0; c--) {
+                    if (c < nr) {
+                        const double xc = readlane_f64(r, c) * dv[c];
+                        if (lane == c) xmine = xc;
+                        r = fma(-col[c], xc, r);
+                    }
                 }
-            } else {
-                if (mask & 1ull) {
-                    chol_solve_unit(lds, nr, 0, lane);
-                    vmine = mine ? lds.sol[pos] : 0.0;
-                } else {
-                    vmine = 0.0;
-                }
+                wave_lds_sync();
+                lds.lt[lane] = xmine;                // x in permuted order, indexed by position
+                wave_lds_sync();
+                vmine = mine ? lds.lt[pos] : 0.0;
             }
-            __syncthreads();
         }
     }
-    if (lane < N) v_out[lane] = vmine;
+    if (lane < N && want_v) v_out[lane] = vmine;
     if (lane == 0) { *var_out = V; *status_out = status; }
 }
 
-// fused: fold chunk partials + solve.  grid = (n_out, n_cand), block = 64.
-__global__ __launch_bounds__(64) void k_solve_from_chunks(int N, int n_out, const RowDesc *__restrict__ rows,
-                                                          const int32_t *__restrict__ out_row_begin,
-                                                          const double2 *__restrict__ partial, int64_t n_chunks,
-                                                          double delta, double *__restrict__ var,
-                                                          double *__restrict__ v, int32_t *__restrict__ status)
+#define SOLVE_DISPATCH(N, ...)                                                                               \
+    do {                                                                                                     \
+        if (N <= 8) solve_wave<8>(__VA_ARGS__);                                                               \
+        else if (N <= 12) solve_wave<12>(__VA_ARGS__);                                                        \
+        else if (N <= 16) solve_wave<16>(__VA_ARGS__);                                                        \
+        else if (N <= 20) solve_wave<20>(__VA_ARGS__);                                                        \
+        else if (N <= 24) solve_wave<24>(__VA_ARGS__);                                                        \
+        else if (N <= 32) solve_wave<32>(__VA_ARGS__);                                                        \
+        else if (N <= 48) solve_wave<48>(__VA_ARGS__);                                                        \
+        else solve_wave<64>(__VA_ARGS__);                                                                     \
+    } while (0)
+
+// fused: fold chunk partials + solve.  grid = (n_out, n_cand), block = 256 (fold) -> wavefront 0 (solve).
+__global__ __launch_bounds__(256) void k_solve_from_chunks(int N, int n_out, const RowDesc *__restrict__ rows,
+                                                           const int32_t *__restrict__ out_row_begin,
+                                                           const double2 *__restrict__ partial, int64_t n_chunks,
+                                                           double delta, int want_v, double *__restrict__ var,
+                                                           double *__restrict__ v, int32_t *__restrict__ status)
 {
     __shared__ SolveLds lds;
-    const int o = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
-    if (lane < N) lds.amax[lane] = 0.0;
-    for (int t = lane; t < N * N; t += WAVE) lds.phi[t] = 0.0;
+    const int o = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+    if (tid < N) lds.amax[tid] = 0.0;
+    for (int t = tid; t < N * N; t += 256) lds.phi[t] = 0.0;
     __syncthreads();
-    fold_rows(lds, N, rows, out_row_begin[o], out_row_begin[o + 1] - out_row_begin[o],
-              partial + (int64_t)c * n_chunks, lane);
+    fold_rows(lds, N, rows, out_row_begin[o], out_row_begin[o + 1] - out_row_begin[o], partial + (int64_t)c * n_chunks, tid, 256);
     __syncthreads();
+    if (tid >= WAVE) return;   // single wavefront from here on
+    const int lane = tid;
     const double am = (lane < N) ? lds.amax[lane] : 0.0;
     const bool big = wave_max(am) >= 0.05;
     const int64_t e = (int64_t)c * n_out + o;
-    solve_core(lds, N, delta, am > 1.0e-6, am > 0.0, big, var + e, v + e * N, status + e, lane);
+    SOLVE_DISPATCH(N, lds, N, delta, am > 1.0e-6, am > 0.0, big, want_v != 0, var + e, v + e * N, status + e, lane);
 }
 
 // multi-GPU path, phase A tail: fold chunk partials into an all-reduce-able record.
-__global__ __launch_bounds__(64) void k_fold_to_record(int N, int n_out, const RowDesc *__restrict__ rows,
-                                                       const int32_t *__restrict__ out_row_begin,
-                                                       const double2 *__restrict__ partial, int64_t n_chunks,
-                                                       double *__restrict__ rec)
+__global__ __launch_bounds__(256) void k_fold_to_record(int N, int n_out, const RowDesc *__restrict__ rows,
+                                                        const int32_t *__restrict__ out_row_begin,
+                                                        const double2 *__restrict__ partial, int64_t n_chunks,
+                                                        double *__restrict__ rec)
 {
     __shared__ SolveLds lds;
-    const int o = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
-    if (lane < N) lds.amax[lane] = 0.0;
-    for (int t = lane; t < N * N; t += WAVE) lds.phi[t] = 0.0;
+    const int o = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+    if (tid < N) lds.amax[tid] = 0.0;
+    for (int t = tid; t < N * N; t += 256) lds.phi[t] = 0.0;
     __syncthreads();
-    fold_rows(lds, N, rows, out_row_begin[o], out_row_begin[o + 1] - out_row_begin[o],
-              partial + (int64_t)c * n_chunks, lane);
+    fold_rows(lds, N, rows, out_row_begin[o], out_row_begin[o + 1] - out_row_begin[o], partial + (int64_t)c * n_chunks, tid, 256);
     __syncthreads();
     const int reclen = N * N + 2 * N + 1;
     double *r = rec + ((int64_t)c * n_out + o) * reclen;
-    for (int t = lane; t < N * N; t += WAVE) r[t] = lds.phi[t];
-    const double am = (lane < N) ? lds.amax[lane] : 0.0;
-    if (lane < N) { r[N * N + lane] = (am > 1.0e-6) ? 1.0 : 0.0; r[N * N + N + lane] = (am > 0.0) ? 1.0 : 0.0; }
+    for (int t = tid; t < N * N; t += 256) r[t] = lds.phi[t];
+    if (tid >= WAVE) return;
+    const double am = (tid < N) ? lds.amax[tid] : 0.0;
+    if (tid < N) { r[N * N + tid] = (am > 1.0e-6) ? 1.0 : 0.0; r[N * N + N + tid] = (am > 0.0) ? 1.0 : 0.0; }
     const double big = wave_max(am);
-    if (lane == 0) r[N * N + 2 * N] = (big >= 0.05) ? 1.0 : 0.0;
+    if (tid == 0) r[N * N + 2 * N] = (big >= 0.05) ? 1.0 : 0.0;
 }
 
-// multi-GPU path, phase B: solve from an (all-reduced) record.
+// multi-GPU path, phase B: solve from an (all-reduced) record.  block = 64.
 __global__ __launch_bounds__(64) void k_solve_from_record(int N, int n_out, const double *__restrict__ rec,
-                                                          double delta, double *__restrict__ var,
+                                                          double delta, int want_v, double *__restrict__ var,
                                                           double *__restrict__ v, int32_t *__restrict__ status)
 {
     __shared__ SolveLds lds;
@@ -599,7 +649,7 @@ __global__ __launch_bounds__(64) void k_solve_from_record(int N, int n_out, cons
     const bool s2 = lane < N && r[N * N + N + lane] > 0.0;
     const bool big = r[N * N + 2 * N] > 0.0;
     const int64_t e = (int64_t)c * n_out + o;
-    solve_core(lds, N, delta, s1, s2, big, var + e, v + e * N, status + e, lane);
+    SOLVE_DISPATCH(N, lds, N, delta, s1, s2, big, want_v != 0, var + e, v + e * N, status + e, lane);
 }
 
 // gradient pass: one wavefront per tile, lane = group.  q = sum_j v_j (s_jj v_j + 2 sum_{l>j} s_jl v_l).
@@ -1340,7 +1390,7 @@ extern "C" int bluest_plan_phi(bluest_plan_t plan, const double *m_dev, int n_ca
     hipStream_t st = (hipStream_t)stream;
     const int n_out = (int)plan->outs.size();
     launch_chunks(plan, m_dev, n_cand, m_stride, st);
-    hipLaunchKernelGGL(k_fold_to_record, dim3(n_out, n_cand), dim3(64), 0, st, plan->N, n_out, plan->d_rows,
+    hipLaunchKernelGGL(k_fold_to_record, dim3(n_out, n_cand), dim3(256), 0, st, plan->N, n_out, plan->d_rows,
                        plan->d_out_row_begin, plan->d_partial, plan->n_chunks, phi_dev);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
@@ -1353,7 +1403,7 @@ extern "C" int bluest_plan_solve(bluest_plan_t plan, const double *phi_dev, int 
     if (!phi_dev || !var_dev || !v_dev || !status_dev) return fail(BLUEST_ERR_ARG, "null pointer");
     const int n_out = (int)plan->outs.size();
     hipLaunchKernelGGL(k_solve_from_record, dim3(n_out, n_cand), dim3(64), 0, (hipStream_t)stream, plan->N, n_out, phi_dev,
-                       delta, var_dev, v_dev, status_dev);
+                       delta, 1, var_dev, v_dev, status_dev);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }
@@ -1382,8 +1432,8 @@ extern "C" int bluest_plan_eval(bluest_plan_t plan, const double *m_dev, int n_c
     const int n_out = (int)plan->outs.size();
     int32_t *status = status_dev ? status_dev : plan->d_status;
     launch_chunks(plan, m_dev, n_cand, m_stride, st);
-    hipLaunchKernelGGL(k_solve_from_chunks, dim3(n_out, n_cand), dim3(64), 0, st, plan->N, n_out, plan->d_rows,
-                       plan->d_out_row_begin, plan->d_partial, plan->n_chunks, delta, var_dev, plan->d_v, status);
+    hipLaunchKernelGGL(k_solve_from_chunks, dim3(n_out, n_cand), dim3(256), 0, st, plan->N, n_out, plan->d_rows,
+                       plan->d_out_row_begin, plan->d_partial, plan->n_chunks, delta, grad_dev ? 1 : 0, var_dev, plan->d_v, status);
     if (grad_dev)
         hipLaunchKernelGGL(k_grad_tiles, dim3((unsigned)((plan->n_tiles + 3) / 4)), dim3(256), 0, st, plan->d_tiles, plan->n_tiles,
                            plan->d_tvals, plan->d_tidx, plan->d_v, status, plan->N, n_out, n_cand, grad_dev, grad_stride);

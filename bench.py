@@ -30,36 +30,25 @@ N_MODELS, KMAX, N_OUT = 20, 5, 8
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def build_outputs(prob, lo=None, hi=None):
-    """plan description for all outputs; optionally only the groups with global index in [lo, hi) (a shard)"""
-    outs = []
+def build_outputs(prob):
+    """plan description (bluest_amd.plan.Plan) of every output of the synthetic problem"""
     groups = prob["groups"]
     sizes = [len(g) for g in groups]
-    cum = np.concatenate([[0], np.cumsum(sizes)])
-    for o in range(prob["n_out"]):
-        if lo is None:
-            outs.append({"K": prob["kmax"], "sizes": sizes, "groups": groups, "C": prob["C"][o], "mapping": None})
-        else:
-            sg, ss, mp = [], [], []
-            for k in range(prob["kmax"]):
-                a, b = max(lo, cum[k]) - cum[k], min(hi, cum[k + 1]) - cum[k]
-                a, b = int(max(a, 0)), int(max(b, 0))
-                if b < a:
-                    b = a
-                sg.append(groups[k][a:b])
-                ss.append(b - a)
-                mp.append(np.arange(cum[k] + a, cum[k] + b, dtype=np.int64))
-            outs.append({"K": prob["kmax"], "sizes": ss, "groups": sg, "C": prob["C"][o], "mapping": np.concatenate(mp)})
-    return outs
+    return [{"K": prob["kmax"], "sizes": sizes, "groups": groups, "C": prob["C"][o], "mapping": None} for o in range(prob["n_out"])]
 
 
-def shard_bounds(prob, rank, world):
-    """contiguous shards balanced by sum k^2 (the streamed bytes), SURVEY.md 8e"""
-    w = np.concatenate([np.full(len(g), (k + 1) ** 2, dtype=np.float64) for k, g in enumerate(prob["groups"])])
-    c = np.concatenate([[0.0], np.cumsum(w)])
-    cuts = [int(np.searchsorted(c, c[-1] * r / world)) for r in range(world + 1)]
-    cuts[0], cuts[-1] = 0, len(w)
-    return cuts[rank], cuts[rank + 1]
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json, written
+    by tools/pmc_traffic.py with the guide's gfx950 FETCH_SIZE correction); None if that profile is absent"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return d["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(prob, seconds=12.0):
@@ -117,9 +106,11 @@ def main():
     L = prob["K_tot"]
     if world == 1:
         plan = Plan(args.n, L, build_outputs(prob), max_candidates=1, device=dev)
+        sharded = None
     else:
-        lo, hi = shard_bounds(prob, rank, world)
-        plan = Plan(args.n, L, build_outputs(prob, lo, hi), max_candidates=1, device=dev)
+        from bluest_amd.dist import ShardedPlan
+        sharded = ShardedPlan(args.n, [len(g) for g in prob["groups"]], build_outputs(prob), max_candidates=1, device=dev)
+        plan = sharded.plan
     n_out = plan.n_out
 
     # a small ring of different allocation vectors so that consecutive steps do not repeat the same input
@@ -135,10 +126,7 @@ def main():
         if world == 1:
             plan.eval(m, out=(var, grad, status))
         else:
-            plan.phi(m, out=rec)
-            dist.all_reduce(rec)
-            v2, vv, st = plan.solve(rec)
-            plan.grad(vv, st, out=grad)
+            v2, g2, st = sharded.eval(m, rec=rec)      # phi -> all-reduce(SUM) over RCCL -> solve -> grad of the shard
             var.copy_(v2)
 
     # ---- optional hipGraph of one ring cycle (single GPU; RCCL is left eager) -----------------------
@@ -192,31 +180,43 @@ def main():
     if rank == 0:
         ab = synth.algorithmic_bytes(args.n, args.kmax)
         if world == 1:
-            st = torch.cuda.current_stream()
-            m = ring[0]
-            reps = 300
-            v_ws = torch.empty((1, n_out, args.n), dtype=torch.float64, device=dev)
-
-            def timed(fn):
-                fn()
-                torch.cuda.synchronize()
-                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-                for a, b in evs:
-                    a.record(st); fn(); b.record(st)
-                torch.cuda.synchronize()
-                return float(np.median([a.elapsed_time(b) for a, b in evs])) * 1e-3
-
-            empty = timed(lambda: None)
             from bluest_amd.plan import _stream
             lib, h = plan.lib, plan._h
+            m = ring[0]
             var2, vv, st2 = plan.solve(plan.phi(m, out=rec))
-            t_chunks = timed(lambda: lib.bluest_plan_phi_chunks(h, m.data_ptr(), 1, L, _stream())) - empty
-            t_nograd = timed(lambda: plan.eval(m, want_grad=False, out=(var, None, status))) - empty
-            t_grad = timed(lambda: plan.grad(vv, st2, out=grad)) - empty
-            t_step = timed(lambda: plan.eval(m, out=(var, grad, status))) - empty
-            kern = {"event_pair_overhead_us": empty * 1e6, "k_phi_chunks_us": t_chunks * 1e6,
-                    "k_phi_chunks+k_solve_from_chunks_us": t_nograd * 1e6, "k_grad_tiles_us": t_grad * 1e6,
-                    "eager_step_3_kernels_us": t_step * 1e6}
+            R = 50
+
+            def timed(fn):
+                """average duration of one launch: hipGraph of R back-to-back launches on the launch stream, HIP events
+                around the replay (this is what rocprofv3 --kernel-trace reports per dispatch: end-to-end on a busy queue)"""
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    fn()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(R):
+                        fn()
+                g.replay()
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(20):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); g.replay(); e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1) * 1e-3 / R)
+                return float(np.median(ts))
+
+            t_chunks = timed(lambda: lib.bluest_plan_phi_chunks(h, m.data_ptr(), 1, L, _stream()))
+            t_nograd = timed(lambda: plan.eval(m, want_grad=False, out=(var, None, status)))
+            t_grad = timed(lambda: plan.grad(vv, st2, out=grad))
+            t_step = timed(lambda: plan.eval(m, out=(var, grad, status)))
+            kern = {"method": "hipGraph of %d back-to-back launches, HIP events around the replay, median of 20" % R,
+                    "k_phi_chunks_us": t_chunks * 1e6, "k_phi_chunks+k_solve_from_chunks_us": t_nograd * 1e6,
+                    "k_solve_from_chunks_us(by difference)": (t_nograd - t_chunks) * 1e6, "k_grad_tiles_us": t_grad * 1e6,
+                    "step_3_kernels_us": t_step * 1e6}
             # dominant kernel = the longer of the two streaming passes
             if t_grad >= t_chunks:
                 kname, tk, abytes, lbytes = "k_grad_tiles", max(t_grad, 1e-9), ab["grad"] * n_out, plan.grad_bytes
@@ -224,7 +224,7 @@ def main():
                 kname, tk, abytes, lbytes = "k_phi_chunks", max(t_chunks, 1e-9), ab["phi"] * n_out, plan.phi_bytes
             achieved = abytes / tk
             roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK, "traffic": None,
+                        "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(kname),
                         "algorithmic_bytes_per_launch": abytes, "layout_bytes_per_launch": lbytes, "avg_launch_us": tk * 1e6,
                         "step": {"algorithmic_bytes": ab["eval"] * n_out, "achieved_GBps": ab["eval"] * n_out * args.steps / elapsed / 1e9,
                                  "frac": ab["eval"] * n_out * args.steps / elapsed / HBM_PEAK}}

@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -35,6 +36,7 @@
 // error plumbing
 // ------------------------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
+static int g_debug_solve = getenv("BLUEST_DEBUG_SOLVE") ? atoi(getenv("BLUEST_DEBUG_SOLVE")) : 0;  // timing experiments only
 
 static int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 static int fail(int code, const char *fmt, ...)
@@ -401,6 +403,56 @@ __global__ __launch_bounds__(256) void k_phi_chunks(const double *__restrict__ v
     }
 }
 
+// Phi pass, shared structure: when every output has the same groups and mapping (the usual multi-output case) the
+// column indices and the gathered m are common; one wavefront streams the chunk of OB outputs and reads them once.
+// vals / partial keep the output-major chunk numbering of the general layout (chunk id = o*ncpo + c).
+template <int OB>
+__global__ __launch_bounds__(256) void k_phi_chunks_shared(const double *__restrict__ vals, const int32_t *__restrict__ cols,
+                                                           int iters, int64_t ncpo, int n_out, const double *__restrict__ m,
+                                                           int64_t m_stride, int n_cand, int64_t n_chunks,
+                                                           double2 *__restrict__ partial)
+{
+    const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int o0 = blockIdx.y * OB;
+    if (chunk >= ncpo) return;
+    const int64_t CH = (int64_t)iters * 256;
+    const int64_t base = chunk * CH + lane * 4;
+    for (int c = 0; c < n_cand; c++) {
+        const double *mc = m + (int64_t)c * m_stride;
+        double s[OB];
+#pragma unroll
+        for (int oo = 0; oo < OB; oo++) s[oo] = 0.0;
+        double amax = 0.0;
+        for (int it = 0; it < iters; it++) {
+            const int4 cc = *reinterpret_cast<const int4 *>(cols + base + it * 256);
+            double2 v01[OB], v23[OB];
+#pragma unroll
+            for (int oo = 0; oo < OB; oo++) {
+                const int o = (o0 + oo < n_out) ? o0 + oo : n_out - 1;
+                const double *vp = vals + (int64_t)o * ncpo * CH + base + it * 256;
+                v01[oo] = *reinterpret_cast<const double2 *>(vp);
+                v23[oo] = *reinterpret_cast<const double2 *>(vp + 2);
+            }
+            const double m0 = mc[cc.x], m1 = mc[cc.y], m2 = mc[cc.z], m3 = mc[cc.w];
+            amax = fmax(fmax(amax, fmax(fabs(m0), fabs(m1))), fmax(fabs(m2), fabs(m3)));
+#pragma unroll
+            for (int oo = 0; oo < OB; oo++) {
+                s[oo] = fma(v01[oo].x, m0, s[oo]);
+                s[oo] = fma(v01[oo].y, m1, s[oo]);
+                s[oo] = fma(v23[oo].x, m2, s[oo]);
+                s[oo] = fma(v23[oo].y, m3, s[oo]);
+            }
+        }
+        amax = wave_max(amax);
+#pragma unroll
+        for (int oo = 0; oo < OB; oo++) {
+            const double t = wave_sum(s[oo]);
+            if (lane == 0 && o0 + oo < n_out) partial[(int64_t)c * n_chunks + (int64_t)(o0 + oo) * ncpo + chunk] = make_double2(t, amax);
+        }
+    }
+}
+
 // ---- solve: one workgroup of 256 threads folds the chunk partials, then wavefront 0 factorises in REGISTERS ----
 //
 // Ordering trick: the restricted system is permuted so that the TARGET model (model 0 if it is sampled, else the
@@ -469,39 +521,40 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// Right-looking Cholesky of the nr x nr matrix whose row `lane` sits in a[0..nr) (lower triangle used).
-// On return a[c] (c <= lane) = L[lane][c]; dv[j] = 1/L[j][j] (wave-uniform).  false if a pivot is not positive.
+__device__ __forceinline__ int uniform_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// Right-looking Cholesky of an NT x NT matrix whose row `lane` sits in a[0..NT) (lower triangle used), straight-line
+// code: no predicates, no LDS, no barriers.  On return a[c] (c <= lane) = L[lane][c]; dv[j] = 1/L[j][j]
+// (wave-uniform).  Non-positive pivots are reported through `bad` (NaNs simply propagate).
 template <int NT>
-__device__ __forceinline__ bool chol_regs(double (&a)[NT], double (&dv)[NT], int nr, double &last_pivot, double &last_dinv)
+__device__ __forceinline__ void chol_regs(double (&a)[NT], double (&dv)[NT], double &last_pivot, int &bad)
 {
 #pragma unroll
     for (int j = 0; j < NT; j++) {
-        if (j < nr) {
-            const double piv = readlane_f64(a[j], j);
-            if (!(piv > 0.0) || !isfinite(piv)) return false;
-            const double dinv = rsqrt_f64(piv);
-            last_pivot = piv;
-            last_dinv = dinv;
-            dv[j] = dinv;
-            a[j] *= dinv;
+        const double piv = readlane_f64(a[j], j);
+        bad |= (!(piv > 0.0) || !isfinite(piv)) ? 1 : 0;
+        const double dinv = rsqrt_f64(piv);
+        if (j == NT - 1) last_pivot = piv;
+        dv[j] = dinv;
+        a[j] *= dinv;
 #pragma unroll
-            for (int c = j + 1; c < NT; c++)
-                if (c < nr) a[c] = fma(-a[j], readlane_f64(a[j], c), a[c]);
-        }
+        for (int c = j + 1; c < NT; c++) a[c] = fma(-a[j], readlane_f64(a[j], c), a[c]);
     }
-    return true;
 }
 
-// One (candidate, output): masks -> permuted restricted matrix in registers -> Cholesky -> V (-> v).
-// Called by ONE wavefront (lane = 0..63); lds.phi is ready.
+// One (candidate, output): masks -> permuted, identity-padded restricted matrix in registers -> Cholesky -> V (-> v).
+// Called by ONE wavefront (lane = 0..63); lds.phi is ready.  Order of the NT positions:
+//   [ NT-nr identity pads | sampled models except the target, ascending | target ]
+// so the target always sits at the static position NT-1.
 template <int NT>
-__device__ __forceinline__ void solve_wave(SolveLds &lds, int N, double delta, bool s1, bool s2, bool big, bool want_v,
-                                           double *__restrict__ var_out, double *__restrict__ v_out,
-                                           int32_t *__restrict__ status_out, int lane)
+__device__ __forceinline__ void solve_wave(SolveLds &lds, int N, double delta, bool s1, bool s2, bool big_in, bool want_v,
+                                        double *__restrict__ var_out, double *__restrict__ v_out,
+                                        int32_t *__restrict__ status_out, int lane)
 {
     // mask1: models touched by a group with |m| > 1e-6 (misc.py:453-457) -> V; mask2: support of Phi+delta*I -> v
     const unsigned long long mask1 = __ballot(lane < N && s1);
     const unsigned long long mask2 = (delta != 0.0) ? __ballot(lane < N) : __ballot(lane < N && s2);
+    const bool big = uniform_i(big_in ? 1 : 0) != 0;
     int status = BLUEST_EVAL_OK;
     double V = 0.0, vmine = 0.0;
     if (!big) {
@@ -517,27 +570,29 @@ __device__ __forceinline__ void solve_wave(SolveLds &lds, int N, double delta, b
             const unsigned long long mask = (pass == 0) ? mask1 : mask2;
             if (pass == 1 && !(mask & 1ull)) { vmine = 0.0; break; }   // row 0 of pinv(Phi) is zero
             const int nr = __popcll(mask);
+            const int npad = NT - nr;
             const int target = __ffsll((long long)mask) - 1;           // smallest sampled model, ordered LAST
             const bool mine = lane < N && ((mask >> lane) & 1ull);
-            const int pos = (lane == target) ? nr - 1 : __popcll(mask & ((1ull << lane) - 1ull)) - 1;
+            const int pos = (lane == target) ? NT - 1 : npad + __popcll(mask & ((1ull << lane) - 1ull)) - 1;
+            wave_lds_sync();
+            if (lane < NT) lds.model_of_pos[lane] = -1;
             wave_lds_sync();
             if (mine) lds.model_of_pos[pos] = lane;
             wave_lds_sync();
-            const bool rowlane = lane < nr;
-            const int rowm = rowlane ? lds.model_of_pos[lane] : 0;
+            const int rowm = (lane < NT) ? lds.model_of_pos[lane] : -1;
             double a[NT], dv[NT];
 #pragma unroll
             for (int c = 0; c < NT; c++) {
-                a[c] = 0.0;
-                dv[c] = 0.0;
-                if (c < nr) {
-                    const double x = lds.phi[rowm * N + lds.model_of_pos[c]];
-                    a[c] = rowlane ? ((c == lane) ? x + delta : x) : 0.0;
-                }
+                const int colm = lds.model_of_pos[c];                  // broadcast read
+                const bool real = rowm >= 0 && colm >= 0;
+                const double x = lds.phi[real ? rowm * N + colm : 0];
+                const double diag = (c == lane) ? 1.0 : 0.0;
+                a[c] = real ? ((c == lane) ? x + delta : x) : diag;    // pads: identity
             }
-            double last_pivot = 0.0, last_dinv = 0.0;
-            const bool ok = chol_regs<NT>(a, dv, nr, last_pivot, last_dinv);
-            if (!ok) {
+            double last_pivot = 1.0;
+            int bad = 0;
+            chol_regs<NT>(a, dv, last_pivot, bad);
+            if (uniform_i(bad)) {
                 if (status == BLUEST_EVAL_OK) status = BLUEST_EVAL_SINGULAR;
                 if (pass == 0) V = NAN;
                 vmine = NAN;
@@ -549,22 +604,24 @@ __device__ __forceinline__ void solve_wave(SolveLds &lds, int N, double delta, b
                 // x = A^-1 e_last: y = L^-1 e_last = e_last/L_nn, then L^T x = y backwards.
                 // Lane i needs column i of L below the diagonal: transpose once through LDS.
                 wave_lds_sync();
+                if (lane < NT) {
 #pragma unroll
-                for (int c = 0; c < NT; c++)
-                    if (c < nr && rowlane && c <= lane) lds.lt[lane * LDA + c] = a[c];
+                    for (int c = 0; c < NT; c++) lds.lt[lane * LDA + c] = a[c];
+                }
                 wave_lds_sync();
                 double col[NT];
 #pragma unroll
-                for (int c = 0; c < NT; c++) col[c] = (c < nr && c > lane) ? lds.lt[c * LDA + lane] : 0.0;
-                double r = (lane == nr - 1) ? last_dinv : 0.0;
+                for (int c = 0; c < NT; c++) {
+                    const double t = lds.lt[c * LDA + (lane < NT ? lane : 0)];
+                    col[c] = (c > lane) ? t : 0.0;
+                }
+                double r = (lane == NT - 1) ? dv[NT - 1] : 0.0;
                 double xmine = 0.0;
 #pragma unroll
                 for (int c = NT - 1; c >= 0; c--) {
-                    if (c < nr) {
-                        const double xc = readlane_f64(r, c) * dv[c];
-                        if (lane == c) xmine = xc;
-                        r = fma(-col[c], xc, r);
-                    }
+                    const double xc = readlane_f64(r, c) * dv[c];
+                    xmine = (lane == c) ? xc : xmine;
+                    r = fma(-col[c], xc, r);
                 }
                 wave_lds_sync();
                 lds.lt[lane] = xmine;                // x in permuted order, indexed by position
@@ -577,21 +634,10 @@ __device__ __forceinline__ void solve_wave(SolveLds &lds, int N, double delta, b
     if (lane == 0) { *var_out = V; *status_out = status; }
 }
 
-#define SOLVE_DISPATCH(N, ...)                                                                               \
-    do {                                                                                                     \
-        if (N <= 8) solve_wave<8>(__VA_ARGS__);                                                               \
-        else if (N <= 12) solve_wave<12>(__VA_ARGS__);                                                        \
-        else if (N <= 16) solve_wave<16>(__VA_ARGS__);                                                        \
-        else if (N <= 20) solve_wave<20>(__VA_ARGS__);                                                        \
-        else if (N <= 24) solve_wave<24>(__VA_ARGS__);                                                        \
-        else if (N <= 32) solve_wave<32>(__VA_ARGS__);                                                        \
-        else if (N <= 48) solve_wave<48>(__VA_ARGS__);                                                        \
-        else solve_wave<64>(__VA_ARGS__);                                                                     \
-    } while (0)
-
 // fused: fold chunk partials + solve.  grid = (n_out, n_cand), block = 256 (fold) -> wavefront 0 (solve).
-__global__ __launch_bounds__(256) void k_solve_from_chunks(int N, int n_out, const RowDesc *__restrict__ rows,
-                                                           const int32_t *__restrict__ out_row_begin,
+// want_v: bit0 = also produce v (gradient wanted); bit1 / bit2 = timing diagnostics (fold only / solve twice).
+template <int NT>
+__global__ __launch_bounds__(256) void k_solve_from_chunks(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
                                                            const double2 *__restrict__ partial, int64_t n_chunks,
                                                            double delta, int want_v, double *__restrict__ var,
                                                            double *__restrict__ v, int32_t *__restrict__ status)
@@ -601,19 +647,24 @@ __global__ __launch_bounds__(256) void k_solve_from_chunks(int N, int n_out, con
     if (tid < N) lds.amax[tid] = 0.0;
     for (int t = tid; t < N * N; t += 256) lds.phi[t] = 0.0;
     __syncthreads();
-    fold_rows(lds, N, rows, out_row_begin[o], out_row_begin[o + 1] - out_row_begin[o], partial + (int64_t)c * n_chunks, tid, 256);
+    fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, 256);
     __syncthreads();
     if (tid >= WAVE) return;   // single wavefront from here on
     const int lane = tid;
+    const int64_t e = (int64_t)c * n_out + o;
+    if (want_v & 2) {   // diagnostics: fold only (timing experiments)
+        if (lane == 0) { var[e] = lds.phi[0]; status[e] = 0; }
+        return;
+    }
     const double am = (lane < N) ? lds.amax[lane] : 0.0;
     const bool big = wave_max(am) >= 0.05;
-    const int64_t e = (int64_t)c * n_out + o;
-    SOLVE_DISPATCH(N, lds, N, delta, am > 1.0e-6, am > 0.0, big, want_v != 0, var + e, v + e * N, status + e, lane);
+    const int reps = (want_v & 4) ? 2 : 1;   // diagnostics: run the solve twice
+    for (int rep = 0; rep < reps; rep++)
+        solve_wave<NT>(lds, N, delta, am > 1.0e-6, am > 0.0, big, (want_v & 1) != 0, var + e, v + e * N, status + e, lane);
 }
 
 // multi-GPU path, phase A tail: fold chunk partials into an all-reduce-able record.
-__global__ __launch_bounds__(256) void k_fold_to_record(int N, int n_out, const RowDesc *__restrict__ rows,
-                                                        const int32_t *__restrict__ out_row_begin,
+__global__ __launch_bounds__(256) void k_fold_to_record(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
                                                         const double2 *__restrict__ partial, int64_t n_chunks,
                                                         double *__restrict__ rec)
 {
@@ -622,7 +673,7 @@ __global__ __launch_bounds__(256) void k_fold_to_record(int N, int n_out, const 
     if (tid < N) lds.amax[tid] = 0.0;
     for (int t = tid; t < N * N; t += 256) lds.phi[t] = 0.0;
     __syncthreads();
-    fold_rows(lds, N, rows, out_row_begin[o], out_row_begin[o + 1] - out_row_begin[o], partial + (int64_t)c * n_chunks, tid, 256);
+    fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, 256);
     __syncthreads();
     const int reclen = N * N + 2 * N + 1;
     double *r = rec + ((int64_t)c * n_out + o) * reclen;
@@ -635,6 +686,7 @@ __global__ __launch_bounds__(256) void k_fold_to_record(int N, int n_out, const 
 }
 
 // multi-GPU path, phase B: solve from an (all-reduced) record.  block = 64.
+template <int NT>
 __global__ __launch_bounds__(64) void k_solve_from_record(int N, int n_out, const double *__restrict__ rec,
                                                           double delta, int want_v, double *__restrict__ var,
                                                           double *__restrict__ v, int32_t *__restrict__ status)
@@ -649,8 +701,21 @@ __global__ __launch_bounds__(64) void k_solve_from_record(int N, int n_out, cons
     const bool s2 = lane < N && r[N * N + N + lane] > 0.0;
     const bool big = r[N * N + 2 * N] > 0.0;
     const int64_t e = (int64_t)c * n_out + o;
-    SOLVE_DISPATCH(N, lds, N, delta, s1, s2, big, want_v != 0, var + e, v + e * N, status + e, lane);
+    solve_wave<NT>(lds, N, delta, s1, s2, big, (want_v & 1) != 0, var + e, v + e * N, status + e, lane);
 }
+
+// host-side choice of the register-array size NT >= N
+#define NT_DISPATCH(N, LAUNCH)                                                                                \
+    do {                                                                                                     \
+        if (N <= 8) { LAUNCH(8); }                                                                           \
+        else if (N <= 12) { LAUNCH(12); }                                                                    \
+        else if (N <= 16) { LAUNCH(16); }                                                                    \
+        else if (N <= 20) { LAUNCH(20); }                                                                    \
+        else if (N <= 26) { LAUNCH(26); }                                                                    \
+        else if (N <= 32) { LAUNCH(32); }                                                                    \
+        else if (N <= 48) { LAUNCH(48); }                                                                    \
+        else { LAUNCH(64); }                                                                                 \
+    } while (0)
 
 // gradient pass: one wavefront per tile, lane = group.  q = sum_j v_j (s_jj v_j + 2 sum_{l>j} s_jl v_l).
 template <int K>
@@ -1035,6 +1100,8 @@ struct bluest_plan_s {
     bool finalized = false;
     int max_cand = 0;
     int iters = 1;  // chunk = 256*iters entries
+    bool shared = false;  // all outputs have identical groups + mapping
+    int nsym = 0;
     int64_t n_chunks = 0, n_rows = 0, n_tiles = 0, grad_len = 0;
     std::vector<int64_t> grad_off;
     int64_t phi_bytes = 0, grad_bytes = 0;
@@ -1206,6 +1273,12 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     while ((max_row + 256LL * iters - 1) / (256LL * iters) > 64 && iters < 1024) iters *= 2;
     const int64_t CH = 256LL * iters;
     plan->iters = iters;
+    plan->nsym = nsym;
+    plan->shared = true;
+    for (int o = 1; o < n_out; o++) {
+        const OutputDesc &x = plan->outs[0], &y = plan->outs[o];
+        if (x.K != y.K || x.sizes != y.sizes || x.groups != y.groups || x.mapping != y.mapping) { plan->shared = false; break; }
+    }
 
     std::vector<RowDesc> rows((size_t)n_out * nsym);
     std::vector<int32_t> out_row_begin(n_out + 1);
@@ -1304,7 +1377,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     plan->n_rows = (int64_t)rows.size();
     plan->n_tiles = (int64_t)tiles.size();
     plan->max_cand = max_candidates;
-    plan->phi_bytes = n_chunks * CH * 12 + n_chunks * 16;
+    plan->phi_bytes = n_chunks * CH * 8 + (plan->shared ? n_chunks / n_out : n_chunks) * CH * 4 + n_chunks * 16;
     plan->grad_bytes = (int64_t)tvals.size() * 8 + (int64_t)tidx.size() + grad_len * 8;
 
     int rc;
@@ -1368,6 +1441,18 @@ extern "C" int bluest_plan_phi_len(bluest_plan_t plan, int64_t *len)
 
 static void launch_chunks(bluest_plan_t p, const double *m, int n_cand, int64_t m_stride, hipStream_t st)
 {
+    const int n_out = (int)p->outs.size();
+    if (p->shared && n_out >= 2) {
+        const int64_t ncpo = p->n_chunks / n_out;
+        const unsigned gx = (unsigned)((ncpo + 3) / 4);
+#define LCS(OB) hipLaunchKernelGGL((k_phi_chunks_shared<OB>), dim3(gx, (n_out + OB - 1) / OB), dim3(256), 0, st, p->d_vals, p->d_cols, \
+                                   p->iters, ncpo, n_out, m, m_stride, n_cand, p->n_chunks, p->d_partial)
+        if (n_out >= 8) LCS(8);
+        else if (n_out >= 4) LCS(4);
+        else LCS(2);
+#undef LCS
+        return;
+    }
     hipLaunchKernelGGL(k_phi_chunks, dim3((unsigned)((p->n_chunks + 3) / 4)), dim3(256), 0, st, p->d_vals, p->d_cols,
                        p->iters, p->n_chunks, m, m_stride, n_cand, p->d_partial);
 }
@@ -1391,7 +1476,7 @@ extern "C" int bluest_plan_phi(bluest_plan_t plan, const double *m_dev, int n_ca
     const int n_out = (int)plan->outs.size();
     launch_chunks(plan, m_dev, n_cand, m_stride, st);
     hipLaunchKernelGGL(k_fold_to_record, dim3(n_out, n_cand), dim3(256), 0, st, plan->N, n_out, plan->d_rows,
-                       plan->d_out_row_begin, plan->d_partial, plan->n_chunks, phi_dev);
+                       plan->nsym, plan->d_partial, plan->n_chunks, phi_dev);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }
@@ -1402,8 +1487,10 @@ extern "C" int bluest_plan_solve(bluest_plan_t plan, const double *phi_dev, int 
     int rc = plan_ready(plan, n_cand); if (rc) return rc;
     if (!phi_dev || !var_dev || !v_dev || !status_dev) return fail(BLUEST_ERR_ARG, "null pointer");
     const int n_out = (int)plan->outs.size();
-    hipLaunchKernelGGL(k_solve_from_record, dim3(n_out, n_cand), dim3(64), 0, (hipStream_t)stream, plan->N, n_out, phi_dev,
-                       delta, 1, var_dev, v_dev, status_dev);
+#define LSR(NT) hipLaunchKernelGGL((k_solve_from_record<NT>), dim3(n_out, n_cand), dim3(64), 0, (hipStream_t)stream, plan->N, n_out, \
+                                   phi_dev, delta, 1, var_dev, v_dev, status_dev)
+    NT_DISPATCH(plan->N, LSR);
+#undef LSR
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }
@@ -1432,8 +1519,11 @@ extern "C" int bluest_plan_eval(bluest_plan_t plan, const double *m_dev, int n_c
     const int n_out = (int)plan->outs.size();
     int32_t *status = status_dev ? status_dev : plan->d_status;
     launch_chunks(plan, m_dev, n_cand, m_stride, st);
-    hipLaunchKernelGGL(k_solve_from_chunks, dim3(n_out, n_cand), dim3(256), 0, st, plan->N, n_out, plan->d_rows,
-                       plan->d_out_row_begin, plan->d_partial, plan->n_chunks, delta, grad_dev ? 1 : 0, var_dev, plan->d_v, status);
+    const int want = (grad_dev ? 1 : 0) | g_debug_solve;
+#define LSC(NT) hipLaunchKernelGGL((k_solve_from_chunks<NT>), dim3(n_out, n_cand), dim3(256), 0, st, plan->N, n_out, plan->d_rows, \
+                                   plan->nsym, plan->d_partial, plan->n_chunks, delta, want, var_dev, plan->d_v, status)
+    NT_DISPATCH(plan->N, LSC);
+#undef LSC
     if (grad_dev)
         hipLaunchKernelGGL(k_grad_tiles, dim3((unsigned)((plan->n_tiles + 3) / 4)), dim3(256), 0, st, plan->d_tiles, plan->n_tiles,
                            plan->d_tvals, plan->d_tidx, plan->d_v, status, plan->N, n_out, n_cand, grad_dev, grad_stride);

@@ -221,10 +221,11 @@ def main():
             if t_grad >= t_chunks:
                 kname, tk, abytes, lbytes = "k_grad_tiles", max(t_grad, 1e-9), ab["grad"] * n_out, plan.grad_bytes
             else:
-                kname, tk, abytes, lbytes = "k_phi_chunks", max(t_chunks, 1e-9), ab["phi"] * n_out, plan.phi_bytes
+                kname, tk, abytes, lbytes = "k_phi_chunks_shared", max(t_chunks, 1e-9), ab["phi"] * n_out, plan.phi_bytes
             achieved = abytes / tk
             roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(kname),
+                        "traffic_source": "profiles/*_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)",
                         "algorithmic_bytes_per_launch": abytes, "layout_bytes_per_launch": lbytes, "avg_launch_us": tk * 1e6,
                         "step": {"algorithmic_bytes": ab["eval"] * n_out, "achieved_GBps": ab["eval"] * n_out * args.steps / elapsed / 1e9,
                                  "frac": ab["eval"] * n_out * args.steps / elapsed / HBM_PEAK}}

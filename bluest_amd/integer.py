@@ -1,13 +1,249 @@
 """
-Integer projection of a continuous allocation (bluest/sap.py:145-187, bluest/mosap.py:212-289,
-bluest/misc.py:141-382): SURVEY.md section 8(f) row 1 -- the first "next" row after the hot path.
+Integer projection of a continuous allocation: same search as the reference --
+bluest/misc.py:141-167 (bounds), :228-311 (multi-output brute force), :313-382 (single output), with the fallback
+ladders of bluest/sap.py:145-187 and bluest/mosap.py:212-289 -- but the heavy step, forming
+phis = basephi + psi[:, idx] @ ms for up to 2^LL candidates and taking pinv(phis)[:,0,0] (misc.py:293-294, 368-369),
+runs on the GPU (`bluest_intproj_eval`: one wavefront per candidate and output, register-resident Cholesky).
+
+The candidate enumeration and the linear filters (model-0 constraint, budget, ordering) are host numpy on <= 2^20
+small integers per chunk, written to keep the reference's selection rule (including its ordering of candidates).
+`MOSAP.cleanup_solution` (mosap.py:125-210) is not ported, so its two rungs of the ladder are
+skipped.
 """
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+from .plan import _stream
 from .sap import BLUESTError
 
-
-def integer_projection_sap(sap, samples, budget=None, eps=None):
-    raise BLUESTError("integer projection is not built yet in this round: call solve(..., continuous_relaxation=True)")
+CHUNK_BITS = 18   # candidates generated / evaluated per chunk: 2^18
 
 
-def integer_projection_mosap(mosap, samples, budget=None, eps=None):
-    raise BLUESTError("integer projection is not built yet in this round: call solve(..., continuous_relaxation=True)")
+def get_feasible_integer_bounds(sol, N, e=None):
+    """bluest/misc.py:141-167: the ~1.2N largest entries (plus the N largest among the groups containing model 0)
+    get floor/ceil bounds; everything else is rounded"""
+    idx = np.argsort(sol)[-int(1.2 * N):]
+    idx = np.array([item for item in idx if sol[item] > 1.0e-8], dtype=np.int64)
+    if e is not None:
+        if sum(e > 0.99) == 0:
+            val = 1 / sum(e) / 2
+            while sum(e > val) == 0:
+                val /= 2
+        else:
+            val = 0.99
+        idx2 = np.argwhere(e > val).flatten()
+        temp = np.argsort(sol[e > val])[::-1]
+        idx2 = idx2[temp[:N]]
+        idx = np.unique(np.concatenate([idx, idx2]))
+    L = len(sol)
+    lb = np.zeros((L,), dtype=int)
+    ub = np.zeros((L,), dtype=int)
+    lb[idx] = np.floor(sol).astype(int)[idx]
+    ub[idx] = np.ceil(sol).astype(int)[idx]
+    temp = np.argsort(lb[idx])[::-1]
+    idx = idx[temp]
+    return lb[idx], ub[idx], idx
+
+
+def psi_column(sap, li):
+    """column li of SAP_n's psi (cmisc.cpp:10-23) from the group's inverse covariance: (N*N,) vector"""
+    N = sap.N
+    k = int(np.searchsorted(sap.cumsizes, li, side="right"))          # group size
+    i = li - int(sap.cumsizes[k - 1])
+    g = sap.groups[k - 1][i]
+    ic = np.asarray(sap.invcovs[k - 1][i * k * k:(i + 1) * k * k]).reshape(k, k)
+    col = np.zeros(N * N)
+    col[(N * g[:, None] + g[None, :]).ravel()] = ic.ravel()
+    return col
+
+
+def candidate_variances(N, base_phi, cols, ms, device):
+    """GPU: V[c, o] = pinv(base_phi[o] + sum_j ms[j, c] cols[o, j])[0, 0]; ms is (LL, n_c) as in the reference"""
+    n_out, LL = cols.shape[0], cols.shape[1]
+    n_c = ms.shape[1]
+    base_d = base_phi.to(device=device, dtype=torch.float64).contiguous()
+    cols_d = torch.from_numpy(np.ascontiguousarray(cols)).to(device)
+    ms_d = torch.from_numpy(np.ascontiguousarray(ms.T, dtype=np.float64)).to(device)
+    V = torch.empty((n_c, n_out), dtype=torch.float64, device=device)
+    with torch.cuda.device(device):
+        check(_lib.lib().bluest_intproj_eval(N, n_out, LL, base_d.data_ptr(), cols_d.data_ptr(), ms_d.data_ptr(), n_c, V.data_ptr(), _stream()))
+    return V
+
+
+def _search(sol, N, w, e, saps, mappings, plan, budget, eps, max_samples_info, lb, ub, idx, multi):
+    """bluest/misc.py:228-311 (multi) / :313-382 (single), chunked over the 2^LL candidates"""
+    ES, rhs = max_samples_info
+    No = len(saps)
+    LL = len(idx)
+    val = np.round(sol).astype(int)
+    baseval = val.copy()
+    baseval[idx] = 0
+    basecost = w @ baseval
+    basees = [e[mappings[n]] @ baseval[mappings[n]] for n in range(No)]
+    base_max = [ees @ baseval for ees in ES]
+    if len(ES) > 0 and any(b > rr for b, rr in zip(base_max, rhs)):
+        return None, np.inf
+    if budget is not None and basecost > budget:
+        return None, np.inf
+    need_e = [n for n in range(No) if basees[n] < 1]
+    if multi and len(need_e) == 0:
+        return None, np.inf        # the reference returns here as well (misc.py:263, `es` stays empty)
+
+    # base information matrices and the psi columns of the free groups, per output
+    base_phi = plan.phi_matrix(baseval.astype(np.float64))[0].reshape(No, N * N)
+    cols = np.zeros((No, LL, N * N))
+    in_out = np.zeros((No, LL), dtype=bool)
+    for n in range(No):
+        pos = {int(g): li for li, g in enumerate(mappings[n])}
+        for j, gidx in enumerate(idx):
+            li = pos.get(int(gidx))
+            if li is not None:
+                cols[n, j] = psi_column(saps[n], li)
+                in_out[n, j] = True
+
+    bnds = np.vstack([lb, ub])
+    best = (None, np.inf, -np.inf)   # (ms column, objective V_max, cost) under the reference's selection rule
+    found_any = False
+    total = 1 << LL
+    step = 1 << min(LL, CHUNK_BITS)
+    weights = 2 ** np.arange(LL, dtype=np.int64)
+    for start in range(0, total, step):
+        codes = np.arange(start, min(start + step, total), dtype=np.int64)
+        combs = ((codes[:, None] & weights[None, :]) > 0).astype(np.int64)      # misc.py:169-175 unpackbits
+        ms = bnds[combs, np.arange(LL)[None, :]].T                               # (LL, n_c)
+        keep = np.ones(ms.shape[1], dtype=bool)
+        if not multi:
+            if basees[0] < 1:
+                keep &= basees[0] + e[idx] @ ms >= 1                             # misc.py:337-342
+        else:
+            anyok = np.zeros(ms.shape[1], dtype=bool)                            # misc.py:257-265 (union over outputs)
+            for n in need_e:
+                anyok |= basees[n] + (e[idx] * in_out[n]) @ ms >= 1
+            keep &= anyok
+        for ees, b, rr in zip(ES, base_max, rhs):                               # misc.py:267-276, 344-353
+            keep &= b + ees[idx] @ ms <= rr
+        costs = basecost + w[idx] @ ms
+        if budget is not None:
+            keep &= costs <= 1.0001 * budget                                    # misc.py:284, 361
+        if not keep.any():
+            continue
+        ms, costs = ms[:, keep], costs[keep]
+        V = candidate_variances(N, base_phi, cols, ms, plan.device)
+        Vmax = V.max(dim=1).values.cpu().numpy()
+        if budget is not None:
+            i = int(np.argmin(Vmax))
+            # the reference reverses the candidate order before argmin: on exact ties the LAST candidate wins
+            ties = np.nonzero(Vmax == Vmax[i])[0]
+            i = int(ties[-1])
+            if np.isfinite(Vmax[i]) and (Vmax[i] < best[1] or (Vmax[i] == best[1])):
+                best = (ms[:, i].copy(), float(Vmax[i]), float(costs[i]))
+                found_any = True
+        else:
+            Vh = V.cpu().numpy()
+            ok = np.all(Vh <= 1.0001 * np.asarray(eps)[None, :] ** 2, axis=1)    # misc.py:301, 375
+            if ok.any():
+                cand = np.nonzero(ok)[0]
+                i = int(cand[np.argmin(costs[cand])])                           # cheapest feasible (misc.py:289,302)
+                if not found_any or costs[i] < best[2]:
+                    best = (ms[:, i].copy(), float(Vmax[i]), float(costs[i]))
+                found_any = True
+    if not found_any:
+        return None, np.inf
+    val[idx] = best[0]
+    return val, best[1]
+
+
+def best_closest_integer_solution(sol, N, w, e, saps, mappings, plan, budget=None, eps=None, max_samples_info=([], []),
+                                  LL_max=15, rng=None, multi=True):
+    """bluest/misc.py:177-226 (multi) and :313-321 (single: LL <= 24 or ValueError)"""
+    lb_full, ub_full, idx_full = get_feasible_integer_bounds(sol, N, e=e)
+    LL = len(idx_full)
+    if not multi:
+        if LL > 24:
+            raise ValueError('Too many dimensions to brute-force it')
+        return _search(sol, N, w, e, saps, mappings, plan, budget, eps, max_samples_info, lb_full, ub_full, idx_full, False)
+    if LL <= LL_max:
+        return _search(sol, N, w, e, saps, mappings, plan, budget, eps, max_samples_info, lb_full, ub_full, idx_full, True)
+    # misc.py:192-226: brute-force a random subset of LL_max entries, randomise the rest, up to 250 trials
+    print('WARNING! Too many dimensions to brute-force it. Randomising search. Note: result might not be optimal.')
+    rng = np.random if rng is None else rng
+    best_val, best_fval, trial = None, np.inf, 0
+    while best_val is None and trial < 250:
+        trial += 1
+        sample = rng.permutation(LL)
+        brute, rest = sample[:LL_max], sample[LL_max:]
+        r_sol = sol.copy()
+        r_bnds = np.vstack([lb_full[rest], ub_full[rest]])
+        comb = rng.randint(2, size=len(rest))
+        r_sol[idx_full[rest]] = r_bnds[comb, np.arange(len(rest))]
+        best_val, best_fval = _search(r_sol, N, w, e, saps, mappings, plan, budget, eps, max_samples_info,
+                                      lb_full[brute], ub_full[brute], idx_full[brute], True)
+    if best_val is None:
+        print("Unable to find feasible integer solution.")
+        return None, np.inf
+    return best_val, best_fval
+
+
+def _increase_tolerance(budget, eps, fac):
+    b = None if budget is None else budget * (1 + fac)
+    e = None if eps is None else np.sqrt(np.asarray(eps, dtype=np.float64) ** 2 * (1 + fac))
+    return b, e
+
+
+def integer_projection_sap(sap, samples, budget=None, eps=None, max_model_samples=None):
+    """bluest/sap.py:145-187"""
+    if budget is None and eps is None:
+        raise ValueError("Need to specify either budget or RMSE tolerance")
+    if sap.verbose: print("Integer projection...")
+    ss = samples.copy()
+    es, rhs = sap.get_max_sample_constraints(max_model_samples)
+    maps = [np.arange(sap.L)]
+    epsv = None if eps is None else [eps]
+    args = (sap.N, sap.costs, sap.e, [sap], maps, sap.plan)
+    out, fval = best_closest_integer_solution(ss, *args, budget=budget, eps=epsv, max_samples_info=(es, rhs), multi=False)
+    if np.isinf(fval):
+        for i in reversed(range(4)):
+            if sap.verbose: print("WARNING! An integer solution satisfying the constraints could not be found. Increasing the tolerance/budget.\n")
+            # NOTE: the reference computes the relaxed tolerances and then passes the ORIGINAL ones (sap.py:170-171);
+            # kept as is, so this rung repeats STEP 0
+            _increase_tolerance(budget, eps, 10. ** -i)
+            out, fval = best_closest_integer_solution(ss, *args, budget=budget, eps=epsv, max_samples_info=(es, rhs), multi=False)
+            if not np.isinf(fval): break
+    if np.isinf(fval):
+        if max_model_samples is not None and not all([np.ceil(ss) @ ee <= rr for ee, rr in zip(es, rhs)]):
+            out = np.floor(ss)
+            if not out @ sap.e >= 1.0:
+                out = np.ceil(ss)
+        else:
+            if sap.verbose: print("WARNING! An integer solution satisfying the constraints could not be found even after increasing the tolerance/budget. Rounding up.\n")
+            out = np.ceil(ss)
+    return np.asarray(out).astype(int)
+
+
+def integer_projection_mosap(mos, samples, budget=None, eps=None, max_model_samples=None):
+    """bluest/mosap.py:212-289 without the cleanup rungs (cleanup_solution is not ported)"""
+    if budget is None and eps is None:
+        raise ValueError("Need to specify either budget or RMSE tolerance")
+    if mos.verbose: print("Integer projection...")
+    ss = samples.copy()
+    ES, rhs = mos.get_max_sample_constraints(max_model_samples)
+    args = (mos.N, mos.costs, mos.e, mos.SAPS, mos.mappings, mos.plan)
+    out, fval = best_closest_integer_solution(ss, *args, budget=budget, eps=eps, max_samples_info=(ES, rhs))
+    if np.isinf(fval):
+        for i in reversed(range(4)):
+            if mos.verbose: print("WARNING! An integer solution satisfying the constraints could not be found. Increasing the tolerance/budget.\n")
+            nb, ne = _increase_tolerance(budget, eps, 10. ** -i)
+            out, fval = best_closest_integer_solution(ss, *args, budget=nb, eps=ne, max_samples_info=(ES, rhs))
+            if not np.isinf(fval): break
+    if np.isinf(fval):
+        # mosap.py:250-287 restricted to the un-cleaned candidates: round up if allowed, else down, else up
+        up, down = np.ceil(ss), np.floor(ss)
+        if max_model_samples is not None and not all([up @ ees <= rr for ees, rr in zip(ES, rhs)]) and \
+                all([down[mos.mappings[n]] @ mos.e[mos.mappings[n]] >= 1 for n in range(mos.n_outputs)]):
+            out = down
+        else:
+            if mos.verbose: print("WARNING! An integer solution satisfying the constraints could not be found even after increasing the tolerance/budget. Rounding up.\n")
+            out = up
+    return np.asarray(out).astype(int)

@@ -169,6 +169,18 @@ int bluest_plan_combine_grad(bluest_plan_t plan, const double *grad_dev, int64_t
 int bluest_simplex_project(const double *x_dev, const double *g_dev, double lambda, double z, int64_t L,
                            double *p_dev, double *d_dev, double *stats_dev, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Part 4 -- integer projection batch (bluest/misc.py:228-311 multi, :313-382 single)
+ *
+ * The reference forms phis = basephi + psi[:, idx] @ ms for up to 2^LL integer candidates and takes
+ * pinv(phis)[:,0,0] (misc.py:293-294, 368-369).  Here: base_dev = n_out x (N*N) base information matrices,
+ * cols_dev = n_out x LL x (N*N) columns of psi for the LL free groups (zero where an output lacks the group),
+ * ms_dev = n_cand x LL candidate values (row-major), V_dev = n_cand x n_out variances (+inf where the candidate's
+ * information matrix is singular on its support or does not sample model 0).
+ * ---------------------------------------------------------------------------------------------------- */
+int bluest_intproj_eval(int N, int n_out, int LL, const double *base_dev, const double *cols_dev, const double *ms_dev,
+                        int64_t n_cand, double *V_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

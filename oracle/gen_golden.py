@@ -259,6 +259,47 @@ def gen_spg(bluest, spgmod, n, kmax, fname, maxit):
     print(fname, "it", res["it"], "count", res["count"], "f", res["f"], "gpmax", res["gpmax"], "info", res["solver_info"])
 
 
+def gen_intproj(bluest, misc, fname):
+    """integer projection known answers (misc.py:177-382): continuous allocations -> reference's best integer point"""
+    out = {}
+    # single output, n=6 all groups: continuous solution = end point of the recorded SPG run
+    G = np.load(os.path.join(OUT, "spg_traj_n6.npz"))
+    prob = synth.problem(6, 6, 1)
+    sap = bluest.SAP(prob["C"][0].copy(), 6, lists_of(prob["groups"]), prob["costs"], verbose=False)
+    B = prob["budget"]
+    sol = B * G["x"] / prob["costs"]
+    out["s_sol"] = sol
+    val, fval = misc.best_closest_integer_solution_BLUE(sol, sap.psi, prob["costs"], sap.e, budget=B)
+    out["s_budget_val"] = val; out["s_budget_fval"] = fval
+    eps = np.sqrt(sap.variance(sol))
+    val, fval = misc.best_closest_integer_solution_BLUE(sol, sap.psi, prob["costs"], sap.e, eps=eps)
+    out["s_eps"] = eps; out["s_eps_val"] = val; out["s_eps_fval"] = fval
+    lb, ub, idx = misc.get_feasible_integer_bounds(sol, 6, e=sap.e)
+    out["s_lb"] = lb; out["s_ub"] = ub; out["s_idx"] = idx
+    # multi output, n=7, k<=3, 3 outputs, a hand-made sparse continuous point with fractional entries
+    n, kmax, n_out = 7, 3, 3
+    prob = synth.problem(n, kmax, n_out)
+    groups = prob["groups"]
+    mos = bluest.MOSAP([c.copy() for c in prob["C"]], kmax, [kmax] * n_out, lists_of(groups), [lists_of(groups) for _ in range(n_out)],
+                       prob["costs"], [prob["costs"]] * n_out, verbose=False)
+    rng = np.random.RandomState(17)
+    sol = np.zeros(mos.L)
+    pick = rng.choice(mos.L, 9, replace=False)
+    sol[pick] = 0.3 + 40 * rng.rand(9)
+    sol[0] = 5.7                         # model 0 alone
+    sol[mos.L - 1] = 12.4
+    out["m_sol"] = sol
+    psis = [mos.SAPS[o].psi for o in range(n_out)]
+    B = float(sol @ prob["costs"]) * 1.0005
+    val, fval = misc.best_closest_integer_solution_BLUE_multi(sol, psis, prob["costs"], mos.e, mos.mappings, budget=B)
+    out["m_budget"] = B; out["m_budget_val"] = val; out["m_budget_fval"] = fval
+    eps = np.sqrt(np.array(mos.variances(sol))) * 1.02
+    val, fval = misc.best_closest_integer_solution_BLUE_multi(sol, psis, prob["costs"], mos.e, mos.mappings, eps=eps)
+    out["m_eps"] = eps; out["m_eps_val"] = val; out["m_eps_fval"] = fval
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, out["s_budget_fval"], out["s_eps_fval"], out["m_budget_fval"], out["m_eps_fval"], len(out["s_idx"]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cm, bluest, misc, spgmod = import_reference()
@@ -271,6 +312,7 @@ def main():
     gen_hh(bluest, "hh_paper_known_answer.npz")
     gen_spg(bluest, spgmod, 6, 6, "spg_traj_n6.npz", maxit=60)
     gen_spg(bluest, spgmod, 12, 4, "spg_traj_n12_k4.npz", maxit=40)
+    gen_intproj(bluest, misc, "intproj_known_answers.npz")
 
 
 if __name__ == "__main__":

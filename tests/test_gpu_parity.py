@@ -395,3 +395,38 @@ def test_candidate_batch(gpu):
         v1, g1, s1 = plan.eval(M[c])
         assert torch.equal(var[c], v1[0]) and torch.equal(grad[c], g1[0]) and torch.equal(st[c], s1[0])
     assert (st[3] == 1).all() and torch.isinf(var[3]).all() and torch.isinf(grad[3]).all()
+
+
+def test_integer_projection_known_answers(gpu):
+    """the reference's best integer point near a continuous allocation (misc.py:228-382),
+    candidates evaluated on the GPU (bluest_intproj_eval)"""
+    from bluest_amd import integer
+    from bluest_amd.mosap import MOSAP
+    from bluest_amd.sap import SAP
+    G = golden("intproj_known_answers.npz")
+    # single output, n=6 all groups
+    prob = synth.problem(6, 6, 1)
+    sap = SAP(prob["C"][0], 6, [g.tolist() for g in prob["groups"]], prob["costs"], verbose=False)
+    lb, ub, idx = integer.get_feasible_integer_bounds(G["s_sol"], 6, e=sap.e)
+    assert (lb == G["s_lb"]).all() and (ub == G["s_ub"]).all() and (idx == G["s_idx"]).all()
+    args = (6, prob["costs"], sap.e, [sap], [np.arange(sap.L)], sap.plan)
+    val, fval = integer.best_closest_integer_solution(G["s_sol"], *args, budget=prob["budget"], multi=False)
+    assert (val == G["s_budget_val"]).all() and abs(fval / float(G["s_budget_fval"]) - 1) < 1e-10
+    val, fval = integer.best_closest_integer_solution(G["s_sol"], *args, eps=[float(G["s_eps"])], multi=False)
+    assert (val == G["s_eps_val"]).all() and abs(fval / float(G["s_eps_fval"]) - 1) < 1e-10
+    # through the operator: solve() ladder, integer result, feasible for the budget (within the reference's 1.0001 slack)
+    out = integer.integer_projection_sap(sap, G["s_sol"], budget=prob["budget"])
+    assert out.dtype.kind == "i" and (out == G["s_budget_val"]).all()
+    # multi output, n=7, 3 outputs
+    n, kmax, n_out = 7, 3, 3
+    prob = synth.problem(n, kmax, n_out)
+    groups = prob["groups"]
+    mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in groups] for _ in range(n_out)],
+                prob["costs"], [prob["costs"]] * n_out, verbose=False)
+    args = (n, prob["costs"], mos.e, mos.SAPS, mos.mappings, mos.plan)
+    val, fval = integer.best_closest_integer_solution(G["m_sol"], *args, budget=float(G["m_budget"]))
+    assert (val == G["m_budget_val"]).all() and abs(fval / float(G["m_budget_fval"]) - 1) < 1e-10
+    val, fval = integer.best_closest_integer_solution(G["m_sol"], *args, eps=G["m_eps"])
+    assert (val == G["m_eps_val"]).all() and abs(fval / float(G["m_eps_fval"]) - 1) < 1e-10
+    # the returned objective is what MOSAP.variances gives for that integer allocation
+    assert abs(max(mos.variances(val)) / fval - 1) < 1e-10

@@ -47,7 +47,7 @@ SIGNATURES = {
     "bluest_plan_eval": [c_vp, c_vp, c_int, c_i64, c_f64, c_vp, c_vp, c_i64, c_vp, c_vp],
     "bluest_plan_combine_grad": [c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_vp, c_i64, c_vp],
     "bluest_intproj_eval": [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp],
-    "bluest_simplex_project": [c_vp, c_vp, c_f64, c_f64, c_i64, c_vp, c_vp, c_vp, c_vp],
+    "bluest_simplex_project": [c_vp, c_vp, c_f64, c_f64, c_f64, c_i64, c_vp, c_vp, c_vp, c_vp],
 }
 
 

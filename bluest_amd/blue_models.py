@@ -1,0 +1,427 @@
+"""
+BLUEProblem -- user-facing API for the sample-allocation path, mirroring bluest/blue_models.py: same constructor,
+`setup_solver()` / `solve()` signatures and return values (:448-576), same model-graph conventions (:160-179,
+:232-263: the graph adjacency is the covariance with 0 = not coupled and inf = uncorrelated), same group
+construction from cliques (:458-501, with hashing instead of the O(L_k^2) list search at :497) and group costs
+(:137-140).  The optimiser is `solver="spg"` on the GPU (the reference default "cvxopt" and its other third-party
+back-ends are outside this build); MLMC / MFMC / plain-MC drivers (:578-930) are out of scope.
+"""
+from itertools import combinations
+
+import numpy as np
+
+from .blue_fn import SerialComm, blue_fn
+from .mosap import MOSAP
+from .sap import BLUESTError
+from .spg import spg
+
+spg_default_params = {"maxit": 10000,           # bluest/blue_models.py:10-18
+                      "max_fevals": 10000 ** 2,
+                      "verbose": False,
+                      "spd_threshold": 5.0e-14,
+                      "eps": 1.0e-10,
+                      "lmbda_min": 10. ** -30,
+                      "lmbda_max": 10. ** 30,
+                      "linesearch_history_length": 10,
+                      }
+
+default_params = {                               # bluest/blue_models.py:20-31, optimiser default changed to "spg"
+    "verbose": True,
+    "comm": None,
+    "remove_uncorrelated": True,
+    "optimization_solver": "spg",
+    "covariance_estimation_samples": 100,
+    "sample_batch_size": 1,
+    "samplefile": None,
+    "outputs_to_save": None,
+    "skip_projection": False,
+    "spg_params": spg_default_params,
+}
+
+
+def next_divisible_number(x, n):
+    return n * (x // n + int(x % n > 0))
+
+
+class BLUEProblem(object):
+    def __init__(self, M, C=None, costs=None, mlmc_variances=None, datafile=None, n_outputs=1, **params):
+        """bluest/blue_models.py:43-103.  C: M x M covariance (list over outputs for n_outputs > 1); NaN = unknown
+        (estimated by sampling), inf = models that must not be coupled."""
+        import networkx as nx
+        self._nx = nx
+        self.M = M
+        self.n_outputs = n_outputs
+        self.MOSAP = None
+        self.MOSAP_output = None
+
+        self.default_params = default_params
+        self.params = default_params.copy()
+        spg_params = spg_default_params.copy()
+        spg_params.update(params.get("spg_params", {}))
+        params["spg_params"] = spg_params
+        self.params.update(params)
+
+        self.comm = self.params["comm"] if self.params["comm"] is not None else SerialComm()
+        self.mpiSize = self.comm.Get_size()
+        self.mpiRank = self.comm.Get_rank()
+        self.warning = self.mpiRank == 0
+        self.verbose = self.params["verbose"] and self.warning
+
+        if C is None: C = [np.nan * np.ones((M, M)) for n in range(n_outputs)]
+        dV = [np.nan * np.ones((M, M)) for n in range(n_outputs)] if mlmc_variances is None else mlmc_variances
+
+        if datafile is not None:
+            self.load_graph_data(datafile, costs)
+            self.check_costs(warning=True)
+        else:
+            if not isinstance(C, (list, tuple)): C = [C]
+            if not isinstance(dV, (list, tuple)): dV = [dV]
+            self.G = [self.get_model_graph(np.array(C[n], dtype=np.float64), costs=costs) for n in range(n_outputs)]
+            self.SG = [list(range(M)) for n in range(n_outputs)]
+            self.dV = dV
+            if costs is None: self.estimate_costs(self.get_comm().Get_size())
+            self.check_costs(warning=True)
+            self.estimate_missing_covariances(next_divisible_number(self.params["covariance_estimation_samples"], self.mpiSize))
+            if not self.params["skip_projection"]:
+                self.project_covariances()
+            self.check_graphs(remove_uncorrelated=self.params["remove_uncorrelated"])
+        if self.verbose: print("\nBLUE estimator ready.\n")
+
+    # ---- to be overloaded by the user (blue_models.py:105-130) --------------------------------------------
+    def evaluate(self, ls, samples, N=1):
+        raise NotImplementedError
+
+    def sampler(self, ls, N=1):
+        raise NotImplementedError
+
+    def get_models_inner_products(self):
+        return [lambda a, b: a * b for n in range(self.n_outputs)]
+
+    def get_comm(self):
+        return self.comm
+
+    # ---- utilities (blue_models.py:134-196) ----------------------------------------------------------------
+    def get_costs(self):
+        return np.array([self.G[0].nodes[l]['cost'] for l in range(self.M)])
+
+    def get_group_costs(self, groups):
+        model_costs = self.get_costs()
+        return np.array([sum(model_costs[group]) for groupsk in groups for group in groupsk])
+
+    def check_costs(self, warning=True):
+        more_expensive_models = []
+        costs = self.get_costs()
+        if costs[0] != costs.max():
+            more_expensive_models = [self.G[0].nodes[i]["model_number"] for i in np.argwhere(costs > costs[0]).flatten()]
+            if warning:
+                if self.warning: print("WARNING! Model zero is not the most expensive model. The more expensive models are: %s" % more_expensive_models)
+            else:
+                raise ValueError("Model zero is not the most expensive model. Consider removing the more expensive models %s" % more_expensive_models)
+        return more_expensive_models
+
+    def get_covariances(self):
+        return [self.get_covariance(n) for n in range(self.n_outputs)]
+
+    def get_correlations(self):
+        return [self.get_correlation(n) for n in range(self.n_outputs)]
+
+    def get_covariance(self, n=0):
+        """bluest/blue_models.py:166-179: adjacency with 0 -> NaN (cannot be coupled) and inf -> 0 (uncorrelated)"""
+        C = self._nx.adjacency_matrix(self.G[n]).toarray().astype(np.float64)
+        mask0 = C == 0
+        maskinf = np.isinf(C)
+        C[mask0] = np.nan
+        C[maskinf] = 0
+        return C
+
+    def get_correlation(self, n=0):
+        C = self.get_covariance(n)
+        s = np.sqrt(np.diag(C))
+        return C / np.outer(s, s)
+
+    def outer(self, a, b, inner):
+        L = len(a)
+        out = np.zeros((L, L))
+        for i in range(L):
+            for j in range(L):
+                out[i, j] = inner(a[i], b[j])
+        return out
+
+    # ---- model graph (blue_models.py:232-322) --------------------------------------------------------------
+    def get_model_graph(self, C, costs=None):
+        M = self.M
+        maskinf = np.isinf(C)
+        mask0 = C == 0
+        C[mask0] = np.inf
+        C[maskinf] = 0
+        G = self._nx.from_numpy_array(C)
+        if costs is not None:
+            for l in range(M):
+                G.nodes[l]['cost'] = costs[l]
+        for l in range(M):
+            G.nodes[l]['model_number'] = l
+        return G
+
+    def save_graph_data(self, filename):
+        if self.mpiRank == 0:
+            C_dict = {"C%d" % n: self._nx.adjacency_matrix(self.G[n]).toarray() for n in range(self.n_outputs)}
+            np.savez(filename, M=self.M, n_outputs=self.n_outputs, costs=self.get_costs(), **C_dict, SG=self.SG, dV=self.dV)
+        self.comm.barrier()
+
+    def load_graph_data(self, filename, costs=None):
+        data = dict(np.load(filename))
+        if self.M != int(data["M"]) or self.n_outputs > int(data["n_outputs"]):
+            raise ValueError("Loaded data number of models and/or number of outputs mismatch with the user-given values")
+        self.G = []
+        for n in range(self.n_outputs):
+            GG = self._nx.from_numpy_array(data["C%d" % n])
+            for l in range(self.M):
+                GG.nodes[l]['cost'] = data["costs"][l] if costs is None else costs[l]
+                GG.nodes[l]['model_number'] = l
+            self.G.append(GG)
+        self.SG = data["SG"].tolist()[:self.n_outputs]
+        dV = data.get("dV", None)
+        self.dV = [np.nan * np.ones((self.M, self.M)) for n in range(self.n_outputs)] if dV is None else [dV[n] for n in range(self.n_outputs)]
+
+    def check_graphs(self, remove_uncorrelated=False):
+        for n in range(self.n_outputs):
+            self.check_graph(n, remove_uncorrelated=remove_uncorrelated)
+
+    def check_graph(self, n=0, remove_uncorrelated=False):
+        if remove_uncorrelated:
+            for i in range(self.M):
+                for j in range(i, self.M):
+                    if self.G[n].has_edge(i, j) and np.isinf(self.G[n][i][j]["weight"]):
+                        self.G[n].remove_edge(i, j)
+        if not self._nx.is_connected(self.G[n]):
+            comp = self._nx.node_connected_component(self.G[n], 0)
+            self.SG[n] = comp
+            if self.warning: print("WARNING! Model graph %d is not connected. Connected graph size: %d" % (n, len(comp)))
+
+    # ---- covariance / cost estimation (blue_models.py:326-441) ----------------------------------------------
+    def estimate_missing_covariances(self, N):
+        nx = self._nx
+        C = [nx.adjacency_matrix(self.G[n]).toarray() for n in range(self.n_outputs)]
+        ls = list(np.where(np.isnan(np.sum(sum(C), 1)))[0])
+        if len(ls) == 0: return
+        if self.verbose: print("Covariance estimation with %d samples..." % N)
+        sumse, sumsc, cost, sumsd1, sumsd2 = self.blue_fn(ls, N, compute_mlmc_differences=True)
+        inners = self.get_models_inner_products()
+        C_hat = [sumsc[n] / N - self.outer(sumse[n], sumse[n], inners[n]) / N ** 2 for n in range(self.n_outputs)]
+        for n in range(self.n_outputs):
+            for i in range(len(ls)):
+                for j in range(i + 1, len(ls)):
+                    if not np.isfinite(self.dV[n][ls[i], ls[j]]):
+                        self.dV[n][ls[i], ls[j]] = sumsd2[n][i][j] / N - inners[n](sumsd1[n][i][j] / N, sumsd1[n][i][j] / N)
+        for n in range(self.n_outputs):
+            for i, j, c in self.G[n].edges(data=True):
+                if np.isnan(c['weight']):
+                    ii, jj = ls.index(i), ls.index(j)
+                    if abs(C_hat[n][ii, jj] / np.sqrt(C_hat[n][ii, ii] * C_hat[n][jj, jj])) < 1.0e-7:
+                        C_hat[n][ii, jj] = np.inf
+                    self.G[n][i][j]['weight'] = C_hat[n][ii, jj]
+
+    def project_covariances(self, bypass_error_check=False):
+        for n in range(self.n_outputs):
+            self.project_covariance(n, bypass_error_check=bypass_error_check)
+
+    def project_covariance(self, n=0, bypass_error_check=False):
+        """bluest/blue_models.py:352-433: nearest SPD matrix; with unknown (NaN) entries by SPG with the eigenvalue-clamp
+        projection -- the reference's own use of spg(), here driven by bluest_amd.spg on numpy vectors"""
+        spg_params = self.params["spg_params"]
+        spd_eps = spg_params["spd_threshold"]
+        C = self.get_covariance(n).flatten()
+        mask = (~np.isnan(C)).astype(int)
+
+        def proj(X, eps=spd_eps):
+            L = int(np.sqrt(len(X)).round())
+            X = X.reshape((L, L))
+            l, V = np.linalg.eigh((X + X.T) / 2)
+            l[l < eps] = eps
+            return (V @ np.diag(l) @ V.T).flatten()
+
+        def am(C, mask):
+            X = C.copy()
+            X[abs(mask) < 1.0e-15] = 0
+            return X * mask
+
+        def feval(x): return 0.5 * sum(am(x - C, mask ** 2) ** 2)
+        def geval(x): return am(x - C, mask ** 2)
+
+        if np.isfinite(C).all():
+            L = int(np.sqrt(len(C)).round())
+            Cm = C.reshape((L, L))
+            l, V = np.linalg.eigh(Cm)
+            l[l < spd_eps] = spd_eps
+            C_new = V @ np.diag(l) @ V.T
+            err = np.linalg.norm(Cm - C_new, 'fro')
+            if self.verbose: print("Covariance projected to be symmetric positive definite, projection error: ", err)
+        else:
+            if self.verbose: print("Running Spectral Gradient Descent for Covariance projection...")
+            x = proj(am(C, abs(mask) > 1.0e-14))
+            res = spg(feval, geval, proj, x, eps=spg_params["eps"], maxit=spg_params["maxit"], max_fevals=spg_params["max_fevals"],
+                      verbose=spg_params["verbose"] and self.warning, lmbda_min=spg_params["lmbda_min"], lmbda_max=spg_params["lmbda_max"],
+                      Hlength=spg_params["linesearch_history_length"])
+            err = res["f"]
+            if res["solver_info"] != 0:
+                raise RuntimeError("Could not find good enough Covariance projection. Solver info:\n%s" % res)
+            if err > spg_params["eps"] and not bypass_error_check:
+                if self.verbose: print("\nWARNING! Large covariance projection error. Model covariance may be singular. Leaving covariances as they are.\n")
+                return err
+            C_new = res["x"].reshape((self.M, self.M))
+            s = np.sqrt(np.diag(C_new))
+            rho_new = C_new / np.outer(s, s)
+            C_new[abs(rho_new) < 1.0e-7] = np.inf
+            C_new[np.isnan(C).reshape((self.M, self.M))] = np.nan
+        for i in range(self.M):
+            for j in range(self.M):
+                coupled = not np.isnan(C_new[i, j])
+                if self.G[n].has_edge(i, j):
+                    self.G[n][i][j]['weight'] = C_new[i, j] if coupled else 0
+                elif coupled:
+                    self.G[n].add_edge(i, j)
+                    self.G[n][i][j]['weight'] = C_new[i, j]
+        return err
+
+    def estimate_costs(self, N=1):
+        if self.verbose: print("Cost estimation via sampling...")
+        for l in range(self.M):
+            self.blue_fn([l], self.get_comm().Get_size(), verbose=False)
+            _, _, cost = self.blue_fn([l], N, verbose=False)
+            for n in range(self.n_outputs):
+                self.G[n].nodes[l]['cost'] = cost / N
+
+    def blue_fn(self, ls, N, verbose=True, compute_mlmc_differences=False):
+        return blue_fn(ls, N, self, sampler=self.sampler, inners=self.get_models_inner_products(), comm=self.get_comm(),
+                       N1=self.params["sample_batch_size"], No=self.n_outputs, compute_mlmc_differences=compute_mlmc_differences,
+                       verbose=self.verbose and verbose)
+
+    # ---- the path: setup_solver / solve (blue_models.py:448-576) ---------------------------------------------
+    def _cliques(self, n, K):
+        """all cliques of the model graph of output n up to size K, size-major and sorted (blue_models.py:465-469).
+        Complete graphs (the common case, and the benchmark configurations) are enumerated directly."""
+        G = self.G[n]
+        nodes = sorted(self.SG[n])
+        M = len(nodes)
+        edges = sum(1 for i, j in G.edges() if i != j and i in self.SG[n] and j in self.SG[n])
+        if edges == M * (M - 1) // 2:
+            return [[list(c) for c in combinations(nodes, k)] for k in range(1, K + 1)]
+        groups = [[] for k in range(K)]
+        for clique in self._nx.enumerate_all_cliques(G):
+            kn = len(clique)
+            if kn > K: break
+            if all(node in self.SG[n] for node in clique):
+                groups[kn - 1].append(sorted(clique))
+        return groups
+
+    def setup_solver(self, K=4, budget=None, eps=None, groups=None, multi_groups=None, solver=None, continuous_relaxation=False,
+                     max_model_samples=None, optimization_solver_params=None):
+        if budget is None and eps is None: raise ValueError("Need to specify either budget or RMSE tolerance")
+        elif budget is not None and eps is not None: eps = None
+        if eps is not None and isinstance(eps, (int, float, np.int64, np.float64, np.float32, np.int32)): eps = [eps for n in range(self.n_outputs)]
+        if solver is None: solver = self.params["optimization_solver"]
+        if multi_groups is not None and len(multi_groups) != self.n_outputs:
+            raise ValueError("multi_groups must be a list of groupings of the same length as the number of outputs.")
+        if groups is not None and multi_groups is None:
+            multi_groups = [[list(g) for g in groups] for n in range(self.n_outputs)]
+
+        if multi_groups is None:
+            Ks, multi_groups = [], []
+            K = min(K, self.M)
+            for n in range(self.n_outputs):
+                gs = [item for item in self._cliques(n, K) if len(item) > 0]
+                multi_groups.append(gs)
+                Ks.append(min(K, len(gs)))
+            K = max(Ks)
+        else:
+            Ks = [min(max(len(item) for item in gs), self.M) for gs in multi_groups]
+            for n in range(self.n_outputs):
+                new_groups = [[] for k in range(Ks[n])]
+                for group in multi_groups[n]:
+                    group = sorted(group)
+                    H = self.G[n].subgraph(group)
+                    if H.size() == (len(group) * (len(group) + 1)) // 2 and all(node in self.SG[n] for node in group):
+                        new_groups[len(group) - 1].append(group)
+                multi_groups[n] = new_groups
+            Ks = [min(max(len(item) for groupsk in gs for item in groupsk), self.M) for gs in multi_groups]
+            K = max(Ks)
+
+        seen = [set() for k in range(K)]                      # union over outputs, hashed (blue_models.py:493-501)
+        for n in range(self.n_outputs):
+            for k in range(Ks[n]):
+                for group in multi_groups[n][k]:
+                    seen[k].add(tuple(group))
+        groups = [sorted(list(g) for g in seen[k]) for k in range(K)]
+
+        C = self.get_covariances()
+        costs = self.get_group_costs(groups)
+        multi_costs = [self.get_group_costs(item) for item in multi_groups]
+
+        if self.verbose: print("Computing optimal sample allocation...")
+        if self.mpiRank == 0:
+            self.MOSAP = MOSAP(C, K, Ks, groups, multi_groups, costs, multi_costs, verbose=self.verbose)
+            self.MOSAP.solve(eps=eps, budget=budget, solver=solver, continuous_relaxation=continuous_relaxation,
+                             max_model_samples=max_model_samples, solver_params=optimization_solver_params)
+            if self.MOSAP.samples is None:
+                self.MOSAP_output = None
+            else:
+                Vs = self.MOSAP.variances(self.MOSAP.samples)
+                cost_BLUE = self.MOSAP.tot_cost
+                N_MC = max(C[n][0, 0] / Vs[n] for n in range(self.n_outputs))
+                cost_MC = N_MC * costs[0]
+                if self.verbose: print("\nBLUE cost: ", cost_BLUE, "MC cost: ", cost_MC, "Savings: ", cost_MC / cost_BLUE)
+                self.MOSAP_output = {'budget': budget, 'eps': eps, 'samples': self.MOSAP.samples,
+                                     'flattened_groups': self.MOSAP.flattened_groups, 'variances': Vs, 'cost': cost_BLUE}
+        else:
+            self.MOSAP_output = None
+        self.MOSAP_output = self.comm.bcast(self.MOSAP_output, root=0)
+        if self.MOSAP_output is None:
+            raise BLUESTError("MOSAP solution failed!")
+
+        which_groups = [self.MOSAP_output['flattened_groups'][item] for item in np.argwhere(self.MOSAP_output['samples'] > 0).flatten()]
+        Vs = self.MOSAP_output['variances']
+        cost_BLUE = self.MOSAP_output['cost']
+        samples = self.MOSAP_output['samples']
+        samples = samples[samples > 0].copy()
+        blue_data = {"models": which_groups, "samples": samples, "errors": np.sqrt(Vs), "total_cost": cost_BLUE}
+        if self.verbose: print("\nModel groups selected: %s\n" % which_groups)
+        if self.verbose: print("BLUE estimator setup. Max error: ", np.sqrt(max(Vs)), " Cost: ", cost_BLUE, "\n")
+        return blue_data
+
+    def solve(self, K=4, budget=None, eps=None, groups=None, multi_groups=None, solver=None, verbose=True, continuous_relaxation=False,
+              max_model_samples=None, optimization_solver_params=None):
+        if solver is None: solver = self.params["optimization_solver"]
+        kw = dict(K=K, budget=budget, eps=eps, groups=groups, multi_groups=multi_groups, solver=solver, continuous_relaxation=continuous_relaxation,
+                  max_model_samples=max_model_samples, optimization_solver_params=optimization_solver_params)
+        if self.MOSAP_output is None:
+            self.setup_solver(**kw)
+        elif budget is not None and budget != self.MOSAP_output['budget'] or eps is not None and np.any(np.asarray(eps) != np.asarray(self.MOSAP_output['eps'])):
+            self.setup_solver(**kw)
+        elif budget is None and eps is None and self.MOSAP_output['cost'] is None:
+            raise ValueError("Need to prescribe either a budget or an error tolerance to run the BLUE estimator")
+
+        if self.verbose and verbose: print("\nSampling BLUE...\n")
+        flattened_groups = self.MOSAP_output['flattened_groups']
+        sample_list = self.MOSAP_output['samples']
+        sums = [[] for n in range(self.n_outputs)]
+        for ls, N in zip(flattened_groups, sample_list):
+            if N == 0:
+                for n in range(self.n_outputs):
+                    sums[n].append([0 for l in range(len(ls))])
+                continue
+            sumse, _, _ = self.blue_fn(ls, int(N), verbose=verbose)
+            for n in range(self.n_outputs):
+                sums[n].append(sumse[n])
+        if self.mpiRank == 0:
+            mus, Vs = self.MOSAP.compute_BLUE_estimators(sums, sample_list)
+        else:
+            mus, Vs = None, None
+        mus = self.comm.bcast(mus, root=0)
+        Vs = self.comm.bcast(Vs, root=0)
+        return mus, np.sqrt(Vs), self.MOSAP_output['cost']
+
+    # ---- outside this build ------------------------------------------------------------------------------------
+    def _out_of_scope(self, *a, **k):
+        raise BLUESTError("MLMC / MFMC / plain-MC drivers of the reference are outside this GPU build (SURVEY.md section 2)")
+
+    setup_mlmc = solve_mlmc = setup_mfmc = solve_mfmc = setup_mc = solve_mc = _out_of_scope

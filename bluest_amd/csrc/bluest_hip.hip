@@ -881,58 +881,86 @@ __device__ __forceinline__ void block_sum_cnt(double &x, long long &n, ProjLds &
     n = c;
 }
 
-// ITEMS > 0: u cached in registers (L <= 1024*ITEMS); ITEMS == 0: u recomputed from x,g every pass.
+__device__ __forceinline__ void block_sum2_cnt(double &x, double &y, long long &n, ProjLds &s, int tid)
+{
+    x = wave_sum(x);
+    y = wave_sum(y);
+    n = wave_sum_ll(n);
+    __syncthreads();
+    if ((tid & 63) == 0) { s.dsum[tid >> 6] = x; s.dmax[tid >> 6] = y; s.cnt[tid >> 6] = n; }
+    __syncthreads();
+    double r = s.dsum[0], q = s.dmax[0];
+    long long c = s.cnt[0];
+    const int nw = blockDim.x >> 6;
+    for (int w = 1; w < nw; w++) { r += s.dsum[w]; q += s.dmax[w]; c += s.cnt[w]; }
+    x = r;
+    y = q;
+    n = c;
+}
+
+// p = argmin sum_i (p_i - u_i)^2 / s_i  s.t. p >= 0, sum p = z, with u = x - lambda*s*g:
+//   p_i = s_i * max(r_i - tau, 0),  r_i = x_i/s_i - lambda*g_i,  sum_i s_i max(r_i - tau, 0) = z.
+// floor == 0: s = 1 (plain Euclidean projection, the reference-style SPG step);
+// floor  > 0: s_i = max(x_i, floor) (variable "entropic" metric: the scaled SPG step).
+// ITEMS > 0: (r, s) cached in registers (L <= 1024*ITEMS); ITEMS == 0: recomputed from x,g every pass.
 template <int ITEMS>
 __global__ __launch_bounds__(1024) void k_simplex(const double *__restrict__ x, const double *__restrict__ g,
-                                                  double lambda, double z, int64_t L, double *__restrict__ p,
-                                                  double *__restrict__ d, double *__restrict__ stats)
+                                                  double lambda, double z, double floor, int64_t L,
+                                                  double *__restrict__ p, double *__restrict__ d,
+                                                  double *__restrict__ stats)
 {
     __shared__ ProjLds s;
     const int tid = threadIdx.x;
     constexpr int R = ITEMS > 0 ? ITEMS : 1;
-    double u[R];
-    auto load_u = [&](int64_t i) -> double { return g ? fma(-lambda, g[i], x[i]) : x[i]; };
+    double r[R], sc[R];
+    auto scale_of = [&](int64_t i) -> double { return floor > 0.0 ? fmax(x[i], floor) : 1.0; };
+    auto ratio_of = [&](int64_t i, double si) -> double {
+        const double xi = (floor > 0.0) ? x[i] / si : x[i];
+        return g ? fma(-lambda, g[i], xi) : xi;
+    };
 
-    double umax = -INFINITY;
+    double rmax = -INFINITY;
     if (ITEMS > 0) {
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int64_t i = (int64_t)r * 1024 + tid;
-            u[r] = (i < L) ? load_u(i) : -INFINITY;
-            umax = fmax(umax, u[r]);
+        for (int k = 0; k < R; k++) {
+            const int64_t i = (int64_t)k * 1024 + tid;
+            sc[k] = (i < L) ? scale_of(i) : 0.0;
+            r[k] = (i < L) ? ratio_of(i, sc[k]) : -INFINITY;
+            rmax = fmax(rmax, r[k]);
         }
     } else {
-        for (int64_t i = tid; i < L; i += 1024) umax = fmax(umax, load_u(i));
+        for (int64_t i = tid; i < L; i += 1024) rmax = fmax(rmax, ratio_of(i, scale_of(i)));
     }
-    umax = block_max(umax, s, tid);
+    rmax = block_max(rmax, s, tid);
     if (ITEMS > 0) {
 #pragma unroll
-        for (int r = 0; r < R; r++) u[r] -= umax;   // shift-invariance: all values <= 0, threshold in [-z, 0)
+        for (int k = 0; k < R; k++) r[k] -= rmax;   // all ratios <= 0; the threshold lies in [-z/min s, 0)
     }
-    double tau = -z;
+    double tau = (floor > 0.0) ? -z / floor : -z;
     long long prev = -1;
-    for (int iter = 0; iter < 200; iter++) {
-        double sum = 0.0;
+    for (int iter = 0; iter < 300; iter++) {
+        double s1 = 0.0, s0 = 0.0;
         long long cnt = 0;
         if (ITEMS > 0) {
 #pragma unroll
-            for (int r = 0; r < R; r++)
-                if (u[r] > tau) { sum += u[r]; cnt++; }
+            for (int k = 0; k < R; k++)
+                if (r[k] > tau) { s1 = fma(sc[k], r[k], s1); s0 += sc[k]; cnt++; }
         } else {
             for (int64_t i = tid; i < L; i += 1024) {
-                const double ui = load_u(i) - umax;
-                if (ui > tau) { sum += ui; cnt++; }
+                const double si = scale_of(i);
+                const double ri = ratio_of(i, si) - rmax;
+                if (ri > tau) { s1 = fma(si, ri, s1); s0 += si; cnt++; }
             }
         }
-        block_sum_cnt(sum, cnt, s, tid);
+        block_sum2_cnt(s1, s0, cnt, s, tid);
         if (cnt == prev || cnt == 0) break;
         prev = cnt;
-        tau = (sum - z) / (double)cnt;
+        tau = (s1 - z) / s0;
     }
     double gd = 0.0, dmax = 0.0;
     long long npos = 0;
-    auto emit = [&](int64_t i, double ui) {
-        const double pi = fmax(ui - tau, 0.0);
+    auto emit = [&](int64_t i, double ri, double si) {
+        const double pi = si * fmax(ri - tau, 0.0);
         const double di = pi - x[i];
         if (p) p[i] = pi;
         if (d) d[i] = di;
@@ -942,12 +970,12 @@ __global__ __launch_bounds__(1024) void k_simplex(const double *__restrict__ x, 
     };
     if (ITEMS > 0) {
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int64_t i = (int64_t)r * 1024 + tid;
-            if (i < L) emit(i, u[r]);
+        for (int k = 0; k < R; k++) {
+            const int64_t i = (int64_t)k * 1024 + tid;
+            if (i < L) emit(i, r[k], sc[k]);
         }
     } else {
-        for (int64_t i = tid; i < L; i += 1024) emit(i, load_u(i) - umax);
+        for (int64_t i = tid; i < L; i += 1024) { const double si = scale_of(i); emit(i, ratio_of(i, si) - rmax, si); }
     }
     block_sum_cnt(gd, npos, s, tid);
     dmax = block_max(dmax, s, tid);
@@ -1576,18 +1604,19 @@ extern "C" int bluest_plan_combine_grad(bluest_plan_t plan, const double *grad_d
 // ------------------------------------------------------------------------------------------------------
 // Part 3 host side
 // ------------------------------------------------------------------------------------------------------
-extern "C" int bluest_simplex_project(const double *x_dev, const double *g_dev, double lambda, double z, int64_t L, double *p_dev,
-                                      double *d_dev, double *stats_dev, void *stream)
+extern "C" int bluest_simplex_project(const double *x_dev, const double *g_dev, double lambda, double z, double floor, int64_t L,
+                                      double *p_dev, double *d_dev, double *stats_dev, void *stream)
 {
     int rc = require_gpu(); if (rc) return rc;
     if (!x_dev || L <= 0) return fail(BLUEST_ERR_ARG, "bad x / L");
     if (!(z > 0.0)) return fail(BLUEST_ERR_ARG, "z must be positive");
+    if (!(floor >= 0.0)) return fail(BLUEST_ERR_ARG, "floor must be >= 0");
     hipStream_t st = (hipStream_t)stream;
-#define SP(IT) hipLaunchKernelGGL((k_simplex<IT>), dim3(1), dim3(1024), 0, st, x_dev, g_dev, lambda, z, L, p_dev, d_dev, stats_dev)
+#define SP(IT) hipLaunchKernelGGL((k_simplex<IT>), dim3(1), dim3(1024), 0, st, x_dev, g_dev, lambda, z, floor, L, p_dev, d_dev, stats_dev)
     if (L <= 1024 * 4) SP(4);
     else if (L <= 1024 * 8) SP(8);
     else if (L <= 1024 * 16) SP(16);
-    else if (L <= 1024 * 32) SP(32);
+    else if (L <= 1024 * 24) SP(24);
     else SP(0);
 #undef SP
     HIP_TRY(hipGetLastError());

@@ -175,6 +175,16 @@ class MOSAP(object):
                 hessians.append(self.SAPS[n]._hessian(m_h[self.mappings[n]], delta))
         return variances, gradients, hessians
 
+    def compute_BLUE_estimators(self, sums, samples):
+        """bluest/mosap.py:113-123"""
+        out = []
+        for n in range(self.n_outputs):
+            sums_n = [sums[n][item] for item in self.mappings[n]]
+            out.append(self.SAPS[n].compute_BLUE_estimator(sums_n, samples=np.asarray(samples)[self.mappings[n]]))
+        mus = [item[0] for item in out]
+        Vars = np.array([item[1] for item in out])
+        return mus, Vars
+
     def get_max_sample_constraints(self, max_model_samples):
         """bluest/mosap.py:326-344"""
         if max_model_samples is None:

@@ -180,15 +180,16 @@ class Plan(object):
         return PHI
 
 
-def simplex_project(x, g=None, lmbda=0.0, z=1.0, want_p=True, want_d=True):
-    """p = P_simplex(x - lmbda*g), d = p - x on the GPU; returns (p, d, stats[4] device tensor)"""
+def simplex_project(x, g=None, lmbda=0.0, z=1.0, want_p=True, want_d=True, floor=0.0):
+    """p = P_simplex(x - lmbda*s*g) in the metric diag(1/s), d = p - x, on the GPU; s = 1 (floor = 0) or
+    max(x, floor).  Returns (p, d, stats[4] device tensor)"""
     require_cuda()
     L = x.numel()
     p = torch.empty_like(x) if want_p else None
     d = torch.empty_like(x) if want_d else None
     stats = torch.empty(4, dtype=torch.float64, device=x.device)
     with torch.cuda.device(x.device):
-        check(_lib.lib().bluest_simplex_project(x.data_ptr(), None if g is None else g.data_ptr(), float(lmbda), float(z), L,
+        check(_lib.lib().bluest_simplex_project(x.data_ptr(), None if g is None else g.data_ptr(), float(lmbda), float(z), float(floor), L,
                                                 None if p is None else p.data_ptr(), None if d is None else d.data_ptr(),
                                                 stats.data_ptr(), _stream()))
     return p, d, stats

@@ -13,12 +13,13 @@ from .spg import spg
 
 spg_sap_default_params = {
     "eps": 1.0e-7,            # stop when ||P(x-g)-x||_inf <= eps (objective normalised by its initial value)
-    "maxit": 20000,
+    "maxit": 2000,
     "max_fevals": 10 ** 6,
     "lmbda_min": 10. ** -30,
     "lmbda_max": 10. ** 30,
     "linesearch_history_length": 10,
     "smoothing_p": 32.0,      # multi-output: max_o V_o is replaced by the p-norm (smooth); inf = plain max
+    "scaling_floor": 1.0e-8,  # > 0: scaled SPG, steps and projections in the metric diag(1/max(x, floor)); 0: plain SPG
     "rel_tol": 1.0e-9,        # additionally stop when the objective stalls (relative decrease over a window)
     "stall_window": 200,
 }
@@ -84,8 +85,19 @@ class SpgAllocator(object):
             prm.update(params)
         plan = self.plan
         n_out = plan.n_out
-        B = float(budget) if budget is not None else 1.0
         s = np.ones(n_out) if budget is not None else np.asarray(eps, dtype=np.float64) ** 2
+        if budget is not None:
+            B = float(budget)
+        else:
+            # eps mode: pick the working budget so that the uniform start already has max_o V_o/eps_o^2 ~ 1; sample counts
+            # then have their real magnitude for the reference's absolute thresholds (|m| > 1e-6, max|m| >= 0.05)
+            B_try = 1.0e6 * float(self.costs.max())
+            m_try = torch.full((plan.L,), 1.0 / plan.L, dtype=torch.float64, device=self.dev) * (B_try / self.w)
+            v_try, _, st_try = plan.eval(m_try, want_grad=False)
+            r_try = (v_try[0].cpu().numpy() / s)
+            if not (st_try[0].cpu().numpy() == EVAL_OK).all() or not np.isfinite(r_try).all():
+                raise BLUESTError("SPG: the uniform allocation is infeasible (model 0 unsampled or singular information matrix)")
+            B = B_try * float(r_try.max())
         p = float(prm["smoothing_p"]) if n_out > 1 else np.inf
         scale = B / self.w                                         # m = scale * x
         st = {"x": None, "var": None, "status": None, "fevals": 0, "gevals": 0, "norm": 1.0}
@@ -126,13 +138,18 @@ class SpgAllocator(object):
             c = torch.from_numpy(coef / st["norm"]).to(self.dev).reshape(1, -1)
             return plan.combine_grad(grad, c, scale=scale)[0]
 
+        floor = float(prm["scaling_floor"])
+
         def proj(x):
             return simplex_project(x, want_d=False)[0]
 
         def proj_step(x, g, lmbda):
-            _, d, stats = simplex_project(x, g, lmbda, want_p=False)
+            _, d, stats = simplex_project(x, g, lmbda, want_p=False, floor=floor)
             sh = stats.cpu().numpy()
             return d, float(sh[0]), float(sh[1])
+
+        def metric_dot(s_, x_):
+            return float((s_ * s_ / torch.clamp(x_, min=floor)).sum())
 
         L = plan.L
         if x0 is None:
@@ -152,7 +169,7 @@ class SpgAllocator(object):
 
         res = spg(feval, geval, proj, x, eps=prm["eps"], maxit=prm["maxit"], max_fevals=prm["max_fevals"], verbose=self.verbose,
                   lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"], Hlength=prm["linesearch_history_length"],
-                  proj_step=proj_step, callback=stall)
+                  proj_step=proj_step, callback=stall, metric_dot=metric_dot if floor > 0 else None)
         xs = res["x"]
         m = (scale * xs)
         if budget is None:
@@ -264,6 +281,30 @@ class SAP(object):
                                                                           self.invcovs[q - 1], invPHI)
         hess += hess.T
         return hess
+
+    def compute_BLUE_estimator(self, sums, samples=None):
+        """bluest/sap.py:99-119 + bluest/misc.py:518-544 (PHIinvY0): y = sum_i R_i^T C_i^-1 sums_i (host: the sums may be
+        arbitrary user objects), mu = sum_j pinv(PHI[idx])[0,j] y_j with row 0 of the pseudo-inverse from the GPU solve"""
+        if samples is None: samples = self.samples
+        K, L, sizes, cumsizes, groups, invcovs = self.K, self.L, self.sizes, self.cumsizes, self.groups, self.invcovs
+        y = [0 for i in range(self.N)]
+        sums = [sums[cumsizes[k]:cumsizes[k + 1]] for k in range(K)]
+        for k in range(1, K + 1):
+            for i in range(sizes[k]):
+                for j in range(k):
+                    for s in range(k):
+                        y[groups[k - 1][i][j]] += invcovs[k - 1][k * k * i + k * j + s] * sums[k - 1][i][s]
+        m = np.asarray(samples, dtype=np.float64)
+        if abs(m).max() < 0.05: return np.inf
+        rec = self.plan.phi(m)
+        var, v, status = self.plan.solve(rec)
+        status_to_python(int(status[0, 0]), "compute_BLUE_estimator")
+        v = v[0, 0].cpu().numpy()
+        mu = 0
+        for j in range(self.N):
+            if v[j] != 0.0:
+                mu += v[j] * y[j]
+        return mu, float(var[0, 0])
 
     def get_max_sample_constraints(self, max_model_samples):
         """bluest/sap.py:222-240"""

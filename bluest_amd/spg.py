@@ -55,12 +55,14 @@ def linesearch(feval, x, f, g, d, Hlength, last_fval, max_fevals, count, gdotd=N
 
 
 def spg(feval, geval, proj, x, eps=1.0e-4, maxit=200, max_fevals=10 ** 5, verbose=True, lmbda_min=10. ** -30,
-        lmbda_max=10. ** 30, Hlength=10, proj_step=None, callback=None):
+        lmbda_max=10. ** 30, Hlength=10, proj_step=None, callback=None, metric_dot=None):
     """bluest/spg.py:39-132.
 
     feval(x) -> float; geval(x) -> vector; proj(x) -> vector.
     Optional `proj_step(x, g, lmbda) -> (d, gdotd, dmax)` fuses d = proj(x - lmbda*g) - x with the reductions
     g.d and max|d| (one kernel on the GPU); without it the three are formed as in the reference.
+    Optional `metric_dot(s, x) -> float` replaces s.s in the Barzilai-Borwein step by s^T D(x)^-1 s when `proj_step`
+    works in a variable diagonal metric D(x) (scaled SPG); x is the point the step s started from.
     """
     n = len(x)
     if verbose:
@@ -111,7 +113,7 @@ def spg(feval, geval, proj, x, eps=1.0e-4, maxit=200, max_fevals=10 ** 5, verbos
 
         s = xnew - x
         y = gnew - g
-        sdots = _dot(s, s)
+        sdots = _dot(s, s) if metric_dot is None else metric_dot(s, x)
         sdoty = _dot(s, y)
 
         x = xnew

@@ -161,12 +161,14 @@ int bluest_plan_combine_grad(bluest_plan_t plan, const double *grad_dev, int64_t
 /* ------------------------------------------------------------------------------------------------------
  * Part 3 -- SPG building block (NEW solver="spg"; algorithm of bluest/spg.py:39-132 with proj = simplex)
  *
- * p = P_simplex(x - lambda*g), d = p - x, where P projects onto {p >= 0, sum p = z}.
- * stats_dev[0] = g.d, stats_dev[1] = max|d|, stats_dev[2] = tau (threshold, after shifting by max),
- * stats_dev[3] = number of positive entries of p.  g_dev may be NULL (then lambda is ignored: p = P(x)).
+ * p = argmin sum_i (p_i - u_i)^2 / s_i  over {p >= 0, sum p = z},  u = x - lambda * s * g,  d = p - x.
+ *   floor == 0 : s = 1, the plain Euclidean projection P_simplex(x - lambda*g) (reference-style SPG step);
+ *   floor  > 0 : s_i = max(x_i, floor), the variable-metric ("entropic") SPG step used by solver="spg" by default.
+ * stats_dev[0] = g.d, stats_dev[1] = max|d|, stats_dev[2] = tau (threshold on the ratios, after shifting by their
+ * max), stats_dev[3] = number of positive entries of p.  g_dev may be NULL (then lambda is ignored: p = P(x)).
  * d_dev or p_dev may be NULL.
  * ---------------------------------------------------------------------------------------------------- */
-int bluest_simplex_project(const double *x_dev, const double *g_dev, double lambda, double z, int64_t L,
+int bluest_simplex_project(const double *x_dev, const double *g_dev, double lambda, double z, double floor, int64_t L,
                            double *p_dev, double *d_dev, double *stats_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------

@@ -382,3 +382,19 @@ def simplex_projection(v, z=1.0):
     rho = k[cond][-1]
     tau = css[cond][-1] / rho
     return np.maximum(u - tau, 0.0)
+
+
+def weighted_simplex_projection(u, s, z=1.0):
+    """argmin sum (p-u)^2/s over {p >= 0, sum p = z}: p = max(u - tau*s, 0) (sort on the ratios u/s).
+    Build-defined (scaled SPG step); with s = 1 it is simplex_projection."""
+    u = np.asarray(u, dtype=np.float64)
+    s = np.asarray(s, dtype=np.float64)
+    r = u / s
+    r = r - r.max()
+    order = np.argsort(-r)
+    rs, ss = r[order], s[order]
+    c1 = np.cumsum(ss * rs)
+    c0 = np.cumsum(ss)
+    taus = (c1 - z) / c0
+    k = np.nonzero(rs > taus)[0][-1]
+    return s * np.maximum(r - taus[k], 0.0)

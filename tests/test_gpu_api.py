@@ -1,0 +1,138 @@
+"""
+GPU tests of the user-facing API (BLUEProblem.setup_solver()/solve(), SAP.solve / MOSAP.solve with solver="spg"):
+the reference's return shapes and the optimality of what the SPG solver returns, judged with the CPU oracle.
+"""
+import numpy as np
+import pytest
+
+from bluest_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def support_kkt_violation(grad, w, m, rel_support=1e-6):
+    """min V(m) s.t. w.m = B, m >= 0: dV/dm_i / w_i = -lam on the support (off the support the pinv-based gradient is
+    not a certificate when whole models are unsampled: v_j = 0 there, misc.py:487)"""
+    r = grad / w
+    sup = m > rel_support * m.max()
+    lam = -(r[sup] * m[sup]).sum() / m[sup].sum()
+    return np.abs(r[sup] + lam).max() / lam
+
+
+def reference_optimum(ref, w, B, iters=3000):
+    """independent optimum by the classical multiplicative algorithm for c-optimal design (x_i <- x_i d_i^gamma / sum),
+    run on the CPU oracle; monotone, one gradient per iteration"""
+    L = ref.L
+    scale = B / w
+    best = np.inf
+    for gamma in (0.5, 1.0):
+        x = np.ones(L) / L
+        for it in range(iters):
+            V, g, _ = ref.variance_GH(scale * x, nohess=True)
+            best = min(best, V)
+            x = x * (-(scale * g)) ** gamma
+            x /= x.sum()
+    return best
+
+
+def test_sap_solve_budget_kkt(oracle):
+    from bluest_amd.sap import SAP
+    n, kmax = 8, 3
+    prob = synth.problem(n, kmax, 1)
+    sap = SAP(prob["C"][0], kmax, [g.tolist() for g in prob["groups"]], prob["costs"], verbose=False)
+    B = prob["budget"]
+    m = sap.solve(budget=B, solver="spg", continuous_relaxation=True, solver_params={"eps": 1e-9})
+    assert m is not None and m.min() >= 0 and abs(m @ prob["costs"] / B - 1) < 1e-9
+    ref = oracle.OracleSAP(prob["C"][0], kmax, prob["groups"], prob["costs"])
+    V, g, _ = ref.variance_GH(m, nohess=True)
+    assert abs(sap.variance(m) / V - 1) < 1e-10
+    assert support_kkt_violation(g, prob["costs"], m) < 1e-5, sap.solver_info
+    Vopt = reference_optimum(ref, prob["costs"], B)
+    assert V <= Vopt * (1 + 1e-5), (V, Vopt, sap.solver_info)
+    assert sap.solver_info["count"] < 2000
+    # better than the uniform-on-the-simplex start and than plain Monte Carlo with the same budget
+    m_u = B / prob["costs"] / sap.L
+    assert V < ref.variance(m_u) and V < prob["C"][0][0, 0] / (B / prob["w"][0])
+    # eps mode is the budget mode rescaled: V(m_eps) = eps^2, allocation proportional
+    eps = np.sqrt(V) * 0.5
+    m_e = sap.solve(eps=eps, solver="spg", continuous_relaxation=True, solver_params={"eps": 1e-9})
+    assert abs(ref.variance(m_e) / eps ** 2 - 1) < 1e-6
+    assert abs((m_e @ prob["costs"]) / (4 * B) - 1) < 2e-3          # cost scales like 1/eps^2 at the optimum
+    # unknown / unavailable back-ends
+    with pytest.raises(ValueError):
+        sap.solve(budget=B, solver="nope")
+    from bluest_amd import BLUESTError
+    with pytest.raises(BLUESTError):
+        sap.solve(budget=B, solver="cvxopt")
+
+
+def test_mosap_solve_integer(oracle):
+    from bluest_amd.mosap import MOSAP
+    n, kmax, n_out = 7, 3, 3
+    prob = synth.problem(n, kmax, n_out)
+    groups = prob["groups"]
+    mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in groups] for _ in range(n_out)],
+                prob["costs"], [prob["costs"]] * n_out, verbose=False)
+    B = prob["budget"]
+    mc = mos.solve(budget=B, solver="spg", continuous_relaxation=True, solver_params={"maxit": 3000})
+    assert mc is not None and abs(mc @ prob["costs"] / B - 1) < 1e-9
+    Vc = max(mos.variances(mc))
+    Vu = max(mos.variances(B / prob["costs"] / mos.L))
+    assert Vc < 0.7 * Vu
+    mi = mos.solve(budget=B, solver="spg", solver_params={"maxit": 3000})           # default: integer projection
+    assert mi.dtype.kind == "i" and mi @ prob["costs"] <= 1.0001 * B and mi @ mos.e >= 1
+    Vi = max(mos.variances(mi))
+    assert Vi < 1.2 * Vc
+    ref = oracle.OracleMOSAP(prob["C"], kmax, [kmax] * n_out, groups, [groups] * n_out, prob["costs"], [prob["costs"]] * n_out)
+    assert np.abs(np.array(ref.variances(mi.astype(np.float64))) / np.array(mos.variances(mi)) - 1).max() < 1e-10
+    assert mos.tot_cost == mi @ prob["costs"] and (mos.SAPS[1].samples == mi[mos.mappings[1]]).all()
+
+
+def test_blueproblem_tutorial_flow():
+    """tutorials/01_tutorial.py, MLBLUE part: n=5 truncated-exponential-series models, K = 5"""
+    from scipy.special import gamma
+    from bluest_amd import BLUEProblem
+    n_models = 5
+
+    def exponential_series(x, i):
+        ii = np.arange(i + 1)
+        return np.sum(x ** ii / gamma(ii + 1))
+
+    rng = np.random.RandomState(0)
+
+    class MyProblem(BLUEProblem):
+        def sampler(self, ls):
+            Z = rng.randn()
+            return [float(Z) for i in range(len(ls))]
+
+        def evaluate(self, ls, samples):
+            out = [0 for i in range(len(ls))]
+            for i in range(len(ls)):
+                if ls[i] == 0: out[i] = np.exp(samples[i])
+                elif ls[i] < n_models - 1: out[i] = exponential_series(samples[i], n_models - ls[i])
+                else: out[i] = np.log(abs(samples[i]))
+            return [out]
+
+    costs = np.array([2 ** (n_models - i) for i in range(n_models)])
+    problem = MyProblem(n_models, costs=costs, covariance_estimation_samples=200, verbose=False)
+    C = problem.get_covariance()
+    assert C.shape == (5, 5) and np.isfinite(C).all() and np.linalg.eigvalsh(C).min() > 0
+    assert (problem.get_costs() == costs).all()
+    eps = 0.05 * np.sqrt(C[0, 0])
+    data = problem.setup_solver(K=n_models, eps=eps)
+    assert sorted(data.keys()) == ["errors", "models", "samples", "total_cost"]
+    assert len(data["models"]) == len(data["samples"]) and data["samples"].dtype.kind == "i" and (data["samples"] > 0).all()
+    assert data["errors"][0] <= 1.0001 ** 0.5 * eps * 1.0001
+    assert abs(data["total_cost"] - sum(s * sum(costs[g]) for s, g in zip(data["samples"], data["models"]))) < 1e-9
+    # cheaper than plain Monte Carlo at the same tolerance
+    assert data["total_cost"] < C[0, 0] / eps ** 2 * costs[0]
+    mus, errs, tot = problem.solve(K=n_models, eps=eps)
+    assert abs(mus[0] - np.exp(0.5)) < 6 * errs[0] and abs(errs[0] - data["errors"][0]) < 1e-12 and tot == data["total_cost"]
+    # budget mode and explicit groups
+    data_b = problem.setup_solver(K=3, budget=100 * max(costs), continuous_relaxation=True)
+    assert abs(data_b["total_cost"] / (100 * max(costs)) - 1) < 1e-6
+    data_g = problem.setup_solver(groups=[[0], [1], [0, 3], [2, 4], [0, 1, 2, 3, 4]], eps=eps)
+    assert all(list(g) in ([0], [1], [0, 3], [2, 4], [0, 1, 2, 3, 4]) for g in data_g["models"])
+    from bluest_amd import BLUESTError
+    with pytest.raises(BLUESTError):
+        problem.setup_mlmc(eps=eps)

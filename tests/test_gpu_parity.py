@@ -273,6 +273,28 @@ def test_simplex_projection_vs_oracle(gpu, oracle):
         assert abs(float(stats[0]) - gv @ (want - xv)) <= 1e-12 * max(1.0, np.abs(gv).sum())
 
 
+def test_scaled_simplex_projection_vs_oracle(gpu, oracle):
+    """variable-metric step of the scaled SPG: p = argmin sum (p-u)^2/s, s = max(x, floor), u = x - lambda*s*g"""
+    torch = gpu
+    from bluest_amd.plan import simplex_project
+    rng = np.random.RandomState(5)
+    dev = torch.device("cuda")
+    for L in (7, 1000, 21699, 30000):
+        x = oracle.simplex_projection(rng.randn(L) * 0.01 + 1.0 / L)
+        x[rng.rand(L) < 0.5] = 0.0
+        x /= x.sum()
+        g = rng.randn(L) * 10 ** rng.uniform(-3, 3, size=L)
+        for lam in (1e-6, 1e-2, 1.0, 1e8):
+            for floor in (1e-8, 1e-3):
+                sc = np.maximum(x, floor)
+                want = oracle.weighted_simplex_projection(x - lam * sc * g, sc)
+                p, d, stats = simplex_project(torch.from_numpy(x).to(dev), torch.from_numpy(g).to(dev), lam, floor=floor)
+                p = p.cpu().numpy()
+                assert abs(p.sum() - 1) < 1e-12 and p.min() >= 0
+                assert np.abs(p - want).max() < 1e-12, (L, lam, floor)
+                assert abs(float(stats[0]) - g @ (want - x)) <= 1e-10 * max(1.0, np.abs(g * (want - x)).sum())
+
+
 def test_group_pinv_vs_oracle(gpu, oracle):
     """per-group pseudo-inverse (sap.py:69-79) incl. group sizes 1..12, a singular block and an unsorted group"""
     from bluest_amd import misc

@@ -205,3 +205,15 @@ def test_simplex_projection_properties(oracle):
     x = oracle.simplex_projection(v)
     tau = (v - x)[x > 0]
     assert np.ptp(tau) < 1e-12 and (v[x == 0] <= tau[0] + 1e-12).all()
+
+
+def test_weighted_simplex_projection(oracle):
+    rng = np.random.RandomState(4)
+    u = rng.randn(500)
+    assert np.allclose(oracle.weighted_simplex_projection(u, np.ones(500)), oracle.simplex_projection(u), atol=1e-15)
+    s = rng.rand(500) + 1e-6
+    p = oracle.weighted_simplex_projection(u, s)
+    assert p.min() >= 0 and abs(p.sum() - 1) < 1e-12
+    # KKT of the weighted problem: (p-u)/s = -tau on the support, >= -tau off it
+    t = ((u - p) / s)
+    assert np.ptp(t[p > 0]) < 1e-10 and (t[p == 0] <= t[p > 0].max() + 1e-10).all()

@@ -27,14 +27,40 @@ def up_to_date():
     return os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(SRC), os.path.getmtime(HDR))
 
 
+SHIM_SRC = os.path.join(HERE, "csrc", "cmisc_shim.cpp")
+
+
+def shim_path():
+    import sysconfig
+    return os.path.join(HERE, "shim", "_cmisc_bluest" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_shim(force=False, verbose=False):
+    """pybind11 module `_cmisc_bluest` (same names as the reference's native module) over libbluest_hip.so"""
+    out = shim_path()
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(SHIM_SRC), os.path.getmtime(HDR)):
+        return out
+    import pybind11
+    import sysconfig
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = ["g++", "-O2", "-shared", "-std=c++17", "-fPIC", "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"],
+           "-I" + os.path.join(ROOT, "include"), SHIM_SRC, "-o", out, "-L" + HERE, "-lbluest_hip", "-Wl,-rpath,$ORIGIN/.."]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and up_to_date():
+        build_shim(force=False, verbose=verbose)
         return LIB
     cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
            "-o", LIB, SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    build_shim(force=True, verbose=verbose)
     return LIB
 
 

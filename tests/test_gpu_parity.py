@@ -53,6 +53,28 @@ def test_cmisc_mirror_known_answers(gpu):
         misc.objectiveK_c(np.ones(N * N, dtype=np.float32), N, 3, len(g["gk"]), g["mk"], g["gk"].ravel(), g["ick"])
 
 
+def test_pybind_shim_is_a_drop_in_for_cmisc_bluest(gpu):
+    """the pybind11 module built from csrc/cmisc_shim.cpp has the reference module's name and call shapes
+    (cmisc.cpp:99-110), so `from _cmisc_bluest import ...` (misc.py:11) needs no change"""
+    import importlib.util
+    from bluest_amd import build
+    spec = importlib.util.spec_from_file_location("_cmisc_bluest", build.build_shim())
+    cm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cm)
+    G = golden("cmisc_known_answers.npz")
+    N = int(G["N"])
+    g = _split("k3q3_", G)
+    Lk, Lq = len(g["gk"]), len(g["gq"])
+    psi = np.zeros((N * N, Lk)); cm.assemble_psi_c(psi.ravel(), N, 3, Lk, g["gk"].ravel(), g["ick"])
+    PHI = np.zeros(N * N); cm.objectiveK_c(PHI, N, 3, Lk, g["mk"], g["gk"].ravel(), g["ick"])
+    PHIi = np.zeros(N * N); cm.objectiveK_c(PHIi, N, 3, Lk, g["mki"], g["gk"].ravel(), g["ick"])
+    grad = np.zeros(Lk); cm.gradK_c(grad, 3, Lk, g["gk"].ravel(), g["ick"], g["P"][0])
+    X = np.zeros((N, Lk)); cm.cleanupK_c(X.ravel(), 3, Lk, g["gk"].ravel(), g["ick"], g["P"][0])
+    hess = np.zeros((Lk, Lq)); cm.hessKQ_c(hess.ravel(), N, 3, 3, Lk, Lq, g["gk"].ravel(), g["gq"].ravel(), g["ick"], g["icq"], g["P"].ravel())
+    assert rel_err(psi, g["psi"]) == 0.0 and rel_err(PHI, g["PHI"]) < 1e-14 and rel_err(PHIi, g["PHIi"]) < 1e-14
+    assert rel_err(grad, g["grad"]) < 1e-14 and rel_err(X, g["X"]) < 1e-15 and rel_err(hess, g["hess"]) < 1e-13
+
+
 def test_cmisc_mirror_device_pointers(gpu):
     """the stateless entry points also take device pointers (no PCIe staging)"""
     import ctypes

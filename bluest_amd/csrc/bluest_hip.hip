@@ -377,8 +377,10 @@ struct TileDesc {     // 64 groups of equal size k of one output, for the gradie
 // Phi pass: one wavefront per chunk of CH = 256*iters entries; lane l owns entries [4l, 4l+4) of each 256-block.
 __global__ __launch_bounds__(256) void k_phi_chunks(const double *__restrict__ vals, const int32_t *__restrict__ cols,
                                                     int iters, int64_t n_chunks, const double *__restrict__ m,
-                                                    int64_t m_stride, int n_cand, double2 *__restrict__ partial)
+                                                    int64_t m_stride, int n_cand, double2 *__restrict__ partial,
+                                                    const int32_t *__restrict__ gate)
 {
+    if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
     const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (chunk >= n_chunks) return;
@@ -410,8 +412,9 @@ template <int OB>
 __global__ __launch_bounds__(256) void k_phi_chunks_shared(const double *__restrict__ vals, const int32_t *__restrict__ cols,
                                                            int iters, int64_t ncpo, int n_out, const double *__restrict__ m,
                                                            int64_t m_stride, int n_cand, int64_t n_chunks,
-                                                           double2 *__restrict__ partial)
+                                                           double2 *__restrict__ partial, const int32_t *__restrict__ gate)
 {
+    if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
     const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int o0 = blockIdx.y * OB;
@@ -640,9 +643,11 @@ template <int NT>
 __global__ __launch_bounds__(256) void k_solve_from_chunks(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
                                                            const double2 *__restrict__ partial, int64_t n_chunks,
                                                            double delta, int want_v, double *__restrict__ var,
-                                                           double *__restrict__ v, int32_t *__restrict__ status)
+                                                           double *__restrict__ v, int32_t *__restrict__ status,
+                                                           const int32_t *__restrict__ gate)
 {
     __shared__ SolveLds lds;
+    if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
     const int o = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
     if (tid < N) lds.amax[tid] = 0.0;
     for (int t = tid; t < N * N; t += 256) lds.phi[t] = 0.0;
@@ -815,8 +820,10 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const TileDesc *__restrict__
                                                     const double *__restrict__ tvals,
                                                     const uint8_t *__restrict__ tidx, const double *__restrict__ v,
                                                     const int32_t *__restrict__ status, int N, int n_out, int n_cand,
-                                                    double *__restrict__ grad, int64_t grad_stride)
+                                                    double *__restrict__ grad, int64_t grad_stride,
+                                                    const int32_t *__restrict__ gate)
 {
+    if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (t >= n_tiles) return;
@@ -833,8 +840,9 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const TileDesc *__restrict__
 __global__ void k_combine_grad(const double *__restrict__ grad, int64_t grad_stride, const int64_t *__restrict__ goff,
                                const int32_t *__restrict__ invmap, int64_t L, int n_out,
                                const double *__restrict__ coef, const double *__restrict__ scale, int n_cand,
-                               double *__restrict__ out, int64_t out_stride)
+                               double *__restrict__ out, int64_t out_stride, const int32_t *__restrict__ gate)
 {
+    if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
     if (j >= L || c >= n_cand) return;
@@ -849,6 +857,115 @@ __global__ void k_combine_grad(const double *__restrict__ grad, int64_t grad_str
 // ------------------------------------------------------------------------------------------------------
 // Part 3 -- simplex projection (single workgroup of 1024 threads)
 // ------------------------------------------------------------------------------------------------------
+// ---- device-resident SPG state (doubles in HBM; layout mirrored in bluest_amd/spg_device.py) -----------------------
+#define SPG_F        0    // objective at x (normalised)
+#define SPG_FNEW     1    // objective at the accepted trial point
+#define SPG_LAMBDA   2    // spectral step
+#define SPG_ALPHA    3    // line-search step of the NEXT trial
+#define SPG_GD       4    // g.d            } written by the direction kernel
+#define SPG_DMAX     5    // max|d|         }
+#define SPG_TAU      6    //                }
+#define SPG_NPOS     7    //                }
+#define SPG_ACCEPT   8    // 1 once a trial of this iteration satisfied the nonmonotone Armijo test
+#define SPG_FAIL     9    // 1 if all slots of an iteration were rejected (host continues the line search)
+#define SPG_DONE     10   // 1 = every kernel is a no-op
+#define SPG_IT       11
+#define SPG_COUNT    12   // objective evaluations
+#define SPG_NORM     13   // objective normalisation
+#define SPG_P        14   // smoothing exponent (inf = plain max)
+#define SPG_LMIN     15
+#define SPG_LMAX     16
+#define SPG_HLEN     17   // history length (<= 16)
+#define SPG_SDOTS    18
+#define SPG_SDOTY    19
+#define SPG_FTRIAL   20   // objective of the last evaluated trial
+#define SPG_EPS      21   // stop when max|P(x-g)-x| <= eps
+#define SPG_GPSTATS  24   // g.gp, max|gp| (= gpmax), tau, npos of the convergence projection
+#define SPG_HIST     32   // 16 slots
+#define SPG_COEF     64   // dF/dV_o of the accepted trial (n_out <= 64)
+#define SPG_S        128  // normalisers s_o (1 or eps_o^2)
+#define SPG_STATE_DOUBLES 256
+#define SPG_MAX_OUT  64
+
+// xnew = x + alpha*d, m = scale*xnew for the next line-search slot; sets the plan gate (bluest/spg.py:13,28)
+__global__ __launch_bounds__(1024) void k_spg_trial(const double *__restrict__ x, const double *__restrict__ d,
+                                                    const double *__restrict__ scale, const double *__restrict__ st,
+                                                    double *__restrict__ xnew, double *__restrict__ m,
+                                                    int32_t *__restrict__ enable, int64_t L)
+{
+    const bool run = st[SPG_DONE] == 0.0 && st[SPG_FAIL] == 0.0 && st[SPG_ACCEPT] == 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *enable = run ? 1 : 0;
+    if (!run) return;
+    const double alpha = st[SPG_ALPHA];
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    if (i < L) {
+        const double xn = fma(alpha, d[i], x[i]);
+        xnew[i] = xn;
+        m[i] = scale[i] * xn;
+    }
+}
+
+// objective of the trial from the per-output variances, nonmonotone Armijo test, safeguarded quadratic interpolation
+// (bluest/spg.py:9-35).  One lane does the scalar work.
+__global__ void k_spg_decide(double *__restrict__ st, const double *__restrict__ var, const int32_t *__restrict__ status,
+                             int n_out, int last_slot)
+{
+    if (threadIdx.x != 0) return;
+    if (st[SPG_DONE] != 0.0 || st[SPG_FAIL] != 0.0 || st[SPG_ACCEPT] != 0.0) return;
+    // objective F = || (V_o/s_o) ||_p / norm, coefficients dF/dV_o
+    bool ok = true;
+    double rmax = 0.0;
+    int omax = 0;
+    for (int o = 0; o < n_out; o++) {
+        const double r = var[o] / st[SPG_S + o];
+        if (status[o] != BLUEST_EVAL_OK || !isfinite(r)) ok = false;
+        if (r > rmax) { rmax = r; omax = o; }
+    }
+    double F = INFINITY;
+    const double p = st[SPG_P], norm = st[SPG_NORM];
+    double coef[SPG_MAX_OUT];
+    if (ok) {
+        if (isinf(p) || n_out == 1) {
+            F = rmax;
+            for (int o = 0; o < n_out; o++) coef[o] = (o == omax) ? 1.0 / st[SPG_S + o] : 0.0;
+        } else {
+            double tsum = 0.0;
+            for (int o = 0; o < n_out; o++) tsum += pow(var[o] / st[SPG_S + o] / rmax, p);
+            F = rmax * pow(tsum, 1.0 / p);
+            const double c0 = pow(tsum, 1.0 / p - 1.0);
+            for (int o = 0; o < n_out; o++) coef[o] = pow(var[o] / st[SPG_S + o] / rmax, p - 1.0) * c0 / st[SPG_S + o];
+        }
+        F /= norm;
+    }
+    st[SPG_COUNT] += 1.0;
+    st[SPG_FTRIAL] = F;
+    const int H = (int)st[SPG_HLEN];
+    double fmax = -INFINITY;
+    for (int h = 0; h < H; h++) fmax = fmax > st[SPG_HIST + h] ? fmax : st[SPG_HIST + h];
+    const double alpha = st[SPG_ALPHA], gd = st[SPG_GD], f = st[SPG_F];
+    if (F <= fmax + 1.0e-4 * alpha * gd) {
+        st[SPG_ACCEPT] = 1.0;
+        st[SPG_FNEW] = F;
+        for (int o = 0; o < n_out; o++) st[SPG_COEF + o] = coef[o] / norm;
+        return;
+    }
+    double a = alpha;
+    if (a <= 0.1) {
+        a *= 0.5;
+    } else {
+        double at = -0.5 * (a * a) * gd / (F - f - a * gd);
+        if (!(at >= 0.1) || at > 0.9 * a) at = 0.5 * a;   // also catches F = inf (at = -0) and NaN
+        a = at;
+    }
+    st[SPG_ALPHA] = a;
+    if (last_slot) st[SPG_FAIL] = 1.0;
+}
+
+__global__ void k_spg_gate(const double *__restrict__ st, int32_t *__restrict__ enable)
+{
+    if (threadIdx.x == 0) *enable = (st[SPG_ACCEPT] != 0.0 && st[SPG_DONE] == 0.0 && st[SPG_FAIL] == 0.0) ? 1 : 0;
+}
+
 struct ProjLds {
     double dsum[16];
     double dmax[16];
@@ -898,6 +1015,41 @@ __device__ __forceinline__ void block_sum2_cnt(double &x, double &y, long long &
     n = c;
 }
 
+// accept the step: s = xnew - x, y = gnew - g, Barzilai-Borwein step in the metric diag(1/max(x,floor)),
+// x <- xnew, g <- gnew, history update (bluest/spg.py:85-106).  One workgroup.
+__global__ __launch_bounds__(1024) void k_spg_update(double *__restrict__ x, double *__restrict__ g,
+                                                     const double *__restrict__ xnew, const double *__restrict__ gnew,
+                                                     double *__restrict__ st, double floor, int64_t L)
+{
+    __shared__ ProjLds sm;
+    const int tid = threadIdx.x;
+    if (st[SPG_DONE] != 0.0 || st[SPG_FAIL] != 0.0 || st[SPG_ACCEPT] == 0.0) return;
+    double sdots = 0.0, sdoty = 0.0;
+    long long dummy = 0;
+    for (int64_t i = tid; i < L; i += 1024) {
+        const double xi = x[i], gi = g[i], xn = xnew[i], gn = gnew[i];
+        const double sv = xn - xi, yv = gn - gi;
+        sdots += (floor > 0.0) ? sv * sv / fmax(xi, floor) : sv * sv;
+        sdoty = fma(sv, yv, sdoty);
+        x[i] = xn;
+        g[i] = gn;
+    }
+    block_sum2_cnt(sdots, sdoty, dummy, sm, tid);
+    if (tid == 0) {
+        st[SPG_SDOTS] = sdots;
+        st[SPG_SDOTY] = sdoty;
+        const double lmin = st[SPG_LMIN], lmax = st[SPG_LMAX];
+        st[SPG_LAMBDA] = (sdoty <= 0.0) ? lmax : fmin(lmax, fmax(lmin, sdots / sdoty));
+        const double it = st[SPG_IT] + 1.0;
+        st[SPG_IT] = it;
+        st[SPG_F] = st[SPG_FNEW];
+        const int H = (int)st[SPG_HLEN];
+        st[SPG_HIST + ((long long)it % H)] = st[SPG_FNEW];
+        st[SPG_ALPHA] = 1.0;
+        st[SPG_ACCEPT] = 0.0;
+    }
+}
+
 // p = argmin sum_i (p_i - u_i)^2 / s_i  s.t. p >= 0, sum p = z, with u = x - lambda*s*g:
 //   p_i = s_i * max(r_i - tau, 0),  r_i = x_i/s_i - lambda*g_i,  sum_i s_i max(r_i - tau, 0) = z.
 // floor == 0: s = 1 (plain Euclidean projection, the reference-style SPG step);
@@ -907,10 +1059,14 @@ template <int ITEMS>
 __global__ __launch_bounds__(1024) void k_simplex(const double *__restrict__ x, const double *__restrict__ g,
                                                   double lambda, double z, double floor, int64_t L,
                                                   double *__restrict__ p, double *__restrict__ d,
-                                                  double *__restrict__ stats)
+                                                  double *__restrict__ stats, double *__restrict__ spg_state, int spg_mode)
 {
     __shared__ ProjLds s;
     const int tid = threadIdx.x;
+    if (spg_state) {   // device-resident SPG: a finished / failed run is a no-op
+        if (spg_state[SPG_DONE] != 0.0 || spg_state[SPG_FAIL] != 0.0) return;
+        if (spg_mode == 1) lambda = spg_state[SPG_LAMBDA];   // direction: the step length lives in HBM
+    }
     constexpr int R = ITEMS > 0 ? ITEMS : 1;
     double r[R], sc[R];
     auto scale_of = [&](int64_t i) -> double { return floor > 0.0 ? fmax(x[i], floor) : 1.0; };
@@ -985,6 +1141,8 @@ __global__ __launch_bounds__(1024) void k_simplex(const double *__restrict__ x, 
         stats[2] = tau;
         stats[3] = (double)npos;
     }
+    // convergence projection of the device-resident SPG: gpmax = max|P(x - s*g) - x| <= eps ends the run (spg.py:68)
+    if (tid == 0 && spg_state && spg_mode == 2 && dmax <= spg_state[SPG_EPS]) spg_state[SPG_DONE] = 1.0;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1159,6 +1317,8 @@ struct bluest_plan_s {
     int max_cand = 0;
     int iters = 1;  // chunk = 256*iters entries
     bool shared = false;  // all outputs have identical groups + mapping
+    const int32_t *gate = nullptr;  // optional device word: 0 = skip the plan's kernels (bluest_plan_set_gate)
+    bool always_v = false;          // compute v in every solve (device-side SPG keeps the accepted trial's v)
     int nsym = 0;
     int64_t n_chunks = 0, n_rows = 0, n_tiles = 0, grad_len = 0;
     std::vector<int64_t> grad_off;
@@ -1504,7 +1664,7 @@ static void launch_chunks(bluest_plan_t p, const double *m, int n_cand, int64_t 
         const int64_t ncpo = p->n_chunks / n_out;
         const unsigned gx = (unsigned)((ncpo + 3) / 4);
 #define LCS(OB) hipLaunchKernelGGL((k_phi_chunks_shared<OB>), dim3(gx, (n_out + OB - 1) / OB), dim3(256), 0, st, p->d_vals, p->d_cols, \
-                                   p->iters, ncpo, n_out, m, m_stride, n_cand, p->n_chunks, p->d_partial)
+                                   p->iters, ncpo, n_out, m, m_stride, n_cand, p->n_chunks, p->d_partial, p->gate)
         if (n_out >= 8) LCS(8);
         else if (n_out >= 4) LCS(4);
         else LCS(2);
@@ -1512,7 +1672,7 @@ static void launch_chunks(bluest_plan_t p, const double *m, int n_cand, int64_t 
         return;
     }
     hipLaunchKernelGGL(k_phi_chunks, dim3((unsigned)((p->n_chunks + 3) / 4)), dim3(256), 0, st, p->d_vals, p->d_cols,
-                       p->iters, p->n_chunks, m, m_stride, n_cand, p->d_partial);
+                       p->iters, p->n_chunks, m, m_stride, n_cand, p->d_partial, p->gate);
 }
 
 extern "C" int bluest_plan_phi_chunks(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, void *stream)
@@ -1561,7 +1721,7 @@ extern "C" int bluest_plan_grad(bluest_plan_t plan, const double *v_dev, const i
     if (n_cand > 1 && grad_stride < plan->grad_len) return fail(BLUEST_ERR_ARG, "grad_stride < grad_len");
     const int n_out = (int)plan->outs.size();
     hipLaunchKernelGGL(k_grad_tiles, dim3((unsigned)((plan->n_tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, plan->d_tiles,
-                       plan->n_tiles, plan->d_tvals, plan->d_tidx, v_dev, status_dev, plan->N, n_out, n_cand, grad_dev, grad_stride);
+                       plan->n_tiles, plan->d_tvals, plan->d_tidx, v_dev, status_dev, plan->N, n_out, n_cand, grad_dev, grad_stride, plan->gate);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }
@@ -1577,14 +1737,14 @@ extern "C" int bluest_plan_eval(bluest_plan_t plan, const double *m_dev, int n_c
     const int n_out = (int)plan->outs.size();
     int32_t *status = status_dev ? status_dev : plan->d_status;
     launch_chunks(plan, m_dev, n_cand, m_stride, st);
-    const int want = (grad_dev ? 1 : 0) | g_debug_solve;
+    const int want = ((grad_dev || plan->always_v) ? 1 : 0) | g_debug_solve;
 #define LSC(NT) hipLaunchKernelGGL((k_solve_from_chunks<NT>), dim3(n_out, n_cand), dim3(256), 0, st, plan->N, n_out, plan->d_rows, \
-                                   plan->nsym, plan->d_partial, plan->n_chunks, delta, want, var_dev, plan->d_v, status)
+                                   plan->nsym, plan->d_partial, plan->n_chunks, delta, want, var_dev, plan->d_v, status, plan->gate)
     NT_DISPATCH(plan->N, LSC);
 #undef LSC
     if (grad_dev)
         hipLaunchKernelGGL(k_grad_tiles, dim3((unsigned)((plan->n_tiles + 3) / 4)), dim3(256), 0, st, plan->d_tiles, plan->n_tiles,
-                           plan->d_tvals, plan->d_tidx, plan->d_v, status, plan->N, n_out, n_cand, grad_dev, grad_stride);
+                           plan->d_tvals, plan->d_tidx, plan->d_v, status, plan->N, n_out, n_cand, grad_dev, grad_stride, plan->gate);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }
@@ -1596,7 +1756,7 @@ extern "C" int bluest_plan_combine_grad(bluest_plan_t plan, const double *grad_d
     if (!grad_dev || !coef_dev || !out_dev) return fail(BLUEST_ERR_ARG, "null pointer");
     const int n_out = (int)plan->outs.size();
     hipLaunchKernelGGL(k_combine_grad, dim3((unsigned)((plan->L + 255) / 256), n_cand), dim3(256), 0, (hipStream_t)stream, grad_dev,
-                       grad_stride, plan->d_goff, plan->d_invmap, plan->L, n_out, coef_dev, scale_dev, n_cand, out_dev, out_stride);
+                       grad_stride, plan->d_goff, plan->d_invmap, plan->L, n_out, coef_dev, scale_dev, n_cand, out_dev, out_stride, plan->gate);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }
@@ -1604,21 +1764,97 @@ extern "C" int bluest_plan_combine_grad(bluest_plan_t plan, const double *grad_d
 // ------------------------------------------------------------------------------------------------------
 // Part 3 host side
 // ------------------------------------------------------------------------------------------------------
-extern "C" int bluest_simplex_project(const double *x_dev, const double *g_dev, double lambda, double z, double floor, int64_t L,
-                                      double *p_dev, double *d_dev, double *stats_dev, void *stream)
+static int simplex_impl(const double *x_dev, const double *g_dev, double lambda, double z, double floor, int64_t L, double *p_dev,
+                        double *d_dev, double *stats_dev, double *spg_state, int spg_mode, void *stream)
 {
     int rc = require_gpu(); if (rc) return rc;
     if (!x_dev || L <= 0) return fail(BLUEST_ERR_ARG, "bad x / L");
     if (!(z > 0.0)) return fail(BLUEST_ERR_ARG, "z must be positive");
     if (!(floor >= 0.0)) return fail(BLUEST_ERR_ARG, "floor must be >= 0");
     hipStream_t st = (hipStream_t)stream;
-#define SP(IT) hipLaunchKernelGGL((k_simplex<IT>), dim3(1), dim3(1024), 0, st, x_dev, g_dev, lambda, z, floor, L, p_dev, d_dev, stats_dev)
+#define SP(IT) hipLaunchKernelGGL((k_simplex<IT>), dim3(1), dim3(1024), 0, st, x_dev, g_dev, lambda, z, floor, L, p_dev, d_dev, stats_dev, spg_state, spg_mode)
     if (L <= 1024 * 4) SP(4);
     else if (L <= 1024 * 8) SP(8);
     else if (L <= 1024 * 16) SP(16);
     else if (L <= 1024 * 24) SP(24);
     else SP(0);
 #undef SP
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_simplex_project(const double *x_dev, const double *g_dev, double lambda, double z, double floor, int64_t L,
+                                      double *p_dev, double *d_dev, double *stats_dev, void *stream)
+{
+    return simplex_impl(x_dev, g_dev, lambda, z, floor, L, p_dev, d_dev, stats_dev, nullptr, 0, stream);
+}
+
+// ---- device-resident SPG (state in HBM, control flow by predication; see include/bluest_hip.h Part 3) -----------
+extern "C" int bluest_plan_set_gate(bluest_plan_t plan, const int32_t *enable_dev, int always_v)
+{
+    if (!plan) return fail(BLUEST_ERR_ARG, "plan is NULL");
+    plan->gate = enable_dev;
+    plan->always_v = always_v != 0;
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_v_workspace(bluest_plan_t plan, const double **v_dev, const int32_t **status_dev)
+{
+    if (!plan || !plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
+    if (v_dev) *v_dev = plan->d_v;
+    if (status_dev) *status_dev = plan->d_status;
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_spg_direction(const double *x_dev, const double *g_dev, double *state_dev, double z, double floor, int64_t L,
+                                    double *d_dev, void *stream)
+{
+    if (!state_dev || !g_dev || !d_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    return simplex_impl(x_dev, g_dev, 0.0, z, floor, L, nullptr, d_dev, state_dev + SPG_GD, state_dev, 1, stream);
+}
+
+extern "C" int bluest_spg_converged(const double *x_dev, const double *g_dev, double *state_dev, double z, double floor, int64_t L,
+                                    void *stream)
+{
+    if (!state_dev || !g_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    return simplex_impl(x_dev, g_dev, 1.0, z, floor, L, nullptr, nullptr, state_dev + SPG_GPSTATS, state_dev, 2, stream);
+}
+
+extern "C" int bluest_spg_trial(const double *x_dev, const double *d_dev, const double *scale_dev, const double *state_dev,
+                                double *xnew_dev, double *m_dev, int32_t *enable_dev, int64_t L, void *stream)
+{
+    int rc = require_gpu(); if (rc) return rc;
+    if (!x_dev || !d_dev || !scale_dev || !state_dev || !xnew_dev || !m_dev || !enable_dev || L <= 0) return fail(BLUEST_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_spg_trial, dim3((unsigned)((L + 1023) / 1024)), dim3(1024), 0, (hipStream_t)stream, x_dev, d_dev, scale_dev,
+                       state_dev, xnew_dev, m_dev, enable_dev, L);
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_spg_decide(double *state_dev, const double *var_dev, const int32_t *status_dev, int n_out, int last_slot, void *stream)
+{
+    int rc = require_gpu(); if (rc) return rc;
+    if (!state_dev || !var_dev || !status_dev || n_out <= 0 || n_out > SPG_MAX_OUT) return fail(BLUEST_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_spg_decide, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, var_dev, status_dev, n_out, last_slot);
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_spg_gate(const double *state_dev, int32_t *enable_dev, void *stream)
+{
+    int rc = require_gpu(); if (rc) return rc;
+    if (!state_dev || !enable_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    hipLaunchKernelGGL(k_spg_gate, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, enable_dev);
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_spg_update(double *x_dev, double *g_dev, const double *xnew_dev, const double *gnew_dev, double *state_dev,
+                                 double floor, int64_t L, void *stream)
+{
+    int rc = require_gpu(); if (rc) return rc;
+    if (!x_dev || !g_dev || !xnew_dev || !gnew_dev || !state_dev || L <= 0) return fail(BLUEST_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_spg_update, dim3(1), dim3(1024), 0, (hipStream_t)stream, x_dev, g_dev, xnew_dev, gnew_dev, state_dev, floor, L);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }

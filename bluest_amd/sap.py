@@ -19,6 +19,9 @@ spg_sap_default_params = {
     "lmbda_max": 10. ** 30,
     "linesearch_history_length": 10,
     "smoothing_p": 32.0,      # multi-output: max_o V_o is replaced by the p-norm (smooth); inf = plain max
+    "device_loop": True,      # True: whole iteration on the GPU (spg_device.DeviceSpg); False: host-driven bluest_amd.spg.spg
+    "slots": 2,               # line-search trial points launched per iteration by the device loop
+    "check_every": 20,        # iterations between host looks at the device state
     "scaling_floor": 1.0e-8,  # > 0: scaled SPG, steps and projections in the metric diag(1/max(x, floor)); 0: plain SPG
     "rel_tol": 1.0e-9,        # additionally stop when the objective stalls (relative decrease over a window)
     "stall_window": 200,
@@ -167,9 +170,18 @@ class SpgAllocator(object):
         def stall(it, f, gpmax, lmbda):
             hist.append(f)
 
-        res = spg(feval, geval, proj, x, eps=prm["eps"], maxit=prm["maxit"], max_fevals=prm["max_fevals"], verbose=self.verbose,
-                  lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"], Hlength=prm["linesearch_history_length"],
-                  proj_step=proj_step, callback=stall, metric_dot=metric_dot if floor > 0 else None)
+        if prm["device_loop"]:
+            from .spg_device import DeviceSpg
+            dspg = DeviceSpg(plan, scale, s, p, floor, lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"],
+                             Hlength=prm["linesearch_history_length"], slots=prm["slots"], check_every=prm["check_every"])
+            res = dspg.run(x, eps=prm["eps"], maxit=prm["maxit"], max_fevals=prm["max_fevals"])
+            st["norm"] = res["norm"]
+            res["f"] = res["f"] / res["norm"]
+            st["fevals"], st["gevals"] = res["count"], res["it"] + 1
+        else:
+            res = spg(feval, geval, proj, x, eps=prm["eps"], maxit=prm["maxit"], max_fevals=prm["max_fevals"], verbose=self.verbose,
+                      lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"], Hlength=prm["linesearch_history_length"],
+                      proj_step=proj_step, callback=stall, metric_dot=metric_dot if floor > 0 else None)
         xs = res["x"]
         m = (scale * xs)
         if budget is None:

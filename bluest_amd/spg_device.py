@@ -1,0 +1,168 @@
+"""
+Device-resident SPG: the iteration of bluest/spg.py:68-106 (direction by projection, nonmonotone Armijo line search with
+safeguarded quadratic interpolation, Barzilai-Borwein step) with ALL control flow on the GPU.  The solver state is a
+256-double array in HBM; one iteration is a fixed sequence of kernels (direction, T predicated line-search slots each
+= trial point + Phi pass + solve + decision, gate, gradient, combine, update) captured once in a hipGraph and replayed.
+The host only looks at the state every `check_every` iterations (convergence test, rare line-search overflow).
+
+Same algorithm as bluest_amd.spg.spg with SpgAllocator's callbacks (tests/test_gpu_api.py compares the two
+iteration by iteration); this is what `solve(..., solver="spg")` runs by default.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+from .plan import EVAL_OK, _stream, simplex_project
+
+# state layout (csrc/bluest_hip.hip SPG_*)
+F, FNEW, LAMBDA, ALPHA, GD, DMAX, TAU, NPOS, ACCEPT, FAIL, DONE, IT, COUNT, NORM, P, LMIN, LMAX, HLEN, SDOTS, SDOTY, FTRIAL = range(21)
+EPS, GPSTATS = 21, 24
+HIST, COEF, S, STATE_DOUBLES = 32, 64, 128, 256
+
+
+class DeviceSpg(object):
+    def __init__(self, plan, scale, s_norm, p, floor, lmbda_min=1e-30, lmbda_max=1e30, Hlength=10, slots=2, check_every=20):
+        assert 1 <= Hlength <= 16 and plan.n_out <= 64
+        self.plan, self.lib, self.dev = plan, plan.lib, plan.device
+        self.L, self.n_out = plan.L, plan.n_out
+        self.scale = scale.contiguous()
+        self.s_norm = np.asarray(s_norm, dtype=np.float64)
+        self.p, self.floor = float(p), float(floor)
+        self.lmin, self.lmax, self.H = float(lmbda_min), float(lmbda_max), int(Hlength)
+        self.T, self.check_every = int(slots), int(check_every)
+        d = dict(dtype=torch.float64, device=self.dev)
+        L = self.L
+        self.x, self.g, self.d = torch.empty(L, **d), torch.empty(L, **d), torch.empty(L, **d)
+        self.xnew, self.gnew, self.m = torch.empty(L, **d), torch.empty(L, **d), torch.empty(L, **d)
+        self.var = torch.empty((1, self.n_out), **d)
+        self.status = torch.zeros((1, self.n_out), dtype=torch.int32, device=self.dev)
+        self.grad = torch.empty((1, plan.grad_len), **d)
+        self.enable = torch.ones(1, dtype=torch.int32, device=self.dev)
+        self.st = torch.zeros(STATE_DOUBLES, **d)
+        v = ctypes.c_void_p()
+        check(self.lib.bluest_plan_v_workspace(plan._h, ctypes.byref(v), None))
+        self.v_ws = v.value
+        self.graphs = None
+
+    # ---- launch sequences (captured into hipGraphs) -------------------------------------------------------------
+    def _direction(self):
+        check(self.lib.bluest_spg_direction(self.x.data_ptr(), self.g.data_ptr(), self.st.data_ptr(), 1.0, self.floor, self.L,
+                                            self.d.data_ptr(), _stream()))
+
+    def _slots(self):
+        for t in range(self.T):
+            check(self.lib.bluest_spg_trial(self.x.data_ptr(), self.d.data_ptr(), self.scale.data_ptr(), self.st.data_ptr(),
+                                            self.xnew.data_ptr(), self.m.data_ptr(), self.enable.data_ptr(), self.L, _stream()))
+            self.plan.eval(self.m, want_grad=False, out=(self.var, None, self.status))
+            check(self.lib.bluest_spg_decide(self.st.data_ptr(), self.var.data_ptr(), self.status.data_ptr(), self.n_out,
+                                             1 if t == self.T - 1 else 0, _stream()))
+
+    def _finish(self):
+        plan = self.plan
+        check(self.lib.bluest_spg_gate(self.st.data_ptr(), self.enable.data_ptr(), _stream()))
+        check(self.lib.bluest_plan_grad(plan._h, self.v_ws, self.status.data_ptr(), 1, self.grad.data_ptr(), self.grad.stride(0), _stream()))
+        check(self.lib.bluest_plan_combine_grad(plan._h, self.grad.data_ptr(), self.grad.stride(0), self.st.data_ptr() + 8 * COEF,
+                                                self.scale.data_ptr(), 1, self.gnew.data_ptr(), self.L, _stream()))
+        check(self.lib.bluest_spg_update(self.x.data_ptr(), self.g.data_ptr(), self.xnew.data_ptr(), self.gnew.data_ptr(),
+                                         self.st.data_ptr(), self.floor, self.L, _stream()))
+        check(self.lib.bluest_spg_converged(self.x.data_ptr(), self.g.data_ptr(), self.st.data_ptr(), 1.0, self.floor, self.L, _stream()))
+
+    def _iteration(self):
+        self._direction()
+        self._slots()
+        self._finish()
+
+    def _capture(self, fn):
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            saved = self.st.clone()
+            self.st[DONE] = 1.0               # warm-up outside capture with every kernel predicated off
+            fn()
+            self.st.copy_(saved)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g
+
+    # ---- host-side objective (initialisation only) ---------------------------------------------------------------
+    def _objective(self, var):
+        r = var / self.s_norm
+        if not np.isfinite(r).all():
+            return np.inf, None
+        rmax = r.max()
+        if np.isinf(self.p) or self.n_out == 1:
+            coef = np.zeros(self.n_out)
+            coef[int(np.argmax(r))] = 1.0
+            return rmax, coef / self.s_norm
+        t = (r / rmax) ** self.p
+        return rmax * t.sum() ** (1.0 / self.p), (r / rmax) ** (self.p - 1) * t.sum() ** (1.0 / self.p - 1.0) / self.s_norm
+
+    def run(self, x0, eps=1e-7, maxit=2000, max_fevals=10 ** 6, use_graph=True):
+        plan, lib, st = self.plan, self.lib, self.st
+        with torch.cuda.device(self.dev):
+            check(lib.bluest_plan_set_gate(plan._h, None, 0))
+            self.x.copy_(simplex_project(x0.to(self.dev), want_d=False)[0])
+            var, grad, status = plan.eval(self.scale * self.x)
+            if not (status[0].cpu().numpy() == EVAL_OK).all():
+                raise RuntimeError("device SPG: infeasible starting point")
+            F0, coef = self._objective(var[0].cpu().numpy())
+            norm = F0
+            self.g.copy_(plan.combine_grad(grad, torch.from_numpy(coef / norm).to(self.dev).reshape(1, -1), scale=self.scale)[0])
+            _, _, stats = simplex_project(self.x, self.g, 1.0, want_p=False, floor=self.floor)
+            gpmax = float(stats[1])
+            h = np.zeros(STATE_DOUBLES)
+            h[F] = 1.0
+            h[LAMBDA] = min(self.lmax, max(self.lmin, 1.0 / gpmax)) if gpmax > 1e-15 else 0.0
+            h[ALPHA] = 1.0
+            h[COUNT] = 1.0
+            h[NORM], h[P], h[LMIN], h[LMAX], h[HLEN] = norm, self.p, self.lmin, self.lmax, self.H
+            h[HIST:HIST + 16] = -np.inf
+            h[HIST] = 1.0
+            h[S:S + self.n_out] = self.s_norm
+            h[EPS] = eps
+            h[GPSTATS + 1] = gpmax
+            st.copy_(torch.from_numpy(h))
+            check(lib.bluest_plan_set_gate(plan._h, self.enable.data_ptr(), 1))
+            try:
+                if use_graph and self.graphs is None:
+                    self.graphs = (self._capture(self._iteration), self._capture(self._slots), self._capture(self._finish))
+                run_iter = self.graphs[0].replay if use_graph else self._iteration
+                run_slots = self.graphs[1].replay if use_graph else self._slots
+                run_finish = self.graphs[2].replay if use_graph else self._finish
+                info, it = 1, 0
+                hs = h
+                while True:
+                    if hs[DONE] != 0.0 or gpmax <= eps:
+                        info = 0
+                        break
+                    if it >= maxit:
+                        info = 1
+                        break
+                    for _ in range(min(self.check_every, maxit - it)):
+                        run_iter()
+                    hs = st.cpu().numpy()
+                    while hs[FAIL] != 0.0:                       # rare: more than T trial points needed
+                        if hs[ALPHA] < 1e-300 or hs[COUNT] >= max_fevals:
+                            info = 2
+                            break
+                        st[FAIL] = 0.0
+                        run_slots()
+                        hs = st.cpu().numpy()
+                        if hs[ACCEPT] != 0.0:
+                            run_finish()
+                            hs = st.cpu().numpy()
+                    if info == 2:
+                        break
+                    it = int(hs[IT])
+                    gpmax = float(hs[GPSTATS + 1])
+                hs = st.cpu().numpy()
+            finally:
+                check(lib.bluest_plan_set_gate(plan._h, None, 0))
+        return {"x": self.x.clone(), "f": float(hs[F]) * norm, "gpmax": gpmax, "it": int(hs[IT]), "count": int(hs[COUNT]),
+                "solver_info": info, "norm": norm}

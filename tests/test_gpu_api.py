@@ -136,3 +136,29 @@ def test_blueproblem_tutorial_flow():
     from bluest_amd import BLUESTError
     with pytest.raises(BLUESTError):
         problem.setup_mlmc(eps=eps)
+
+
+def test_device_spg_equals_host_driven_spg():
+    """the device-resident iteration (state in HBM, predicated line-search slots, hipGraph replay) is the same algorithm
+    as the host-driven driver: identical iteration / evaluation counts and objective after N iterations"""
+    from bluest_amd.mosap import MOSAP
+    n, kmax, n_out = 10, 3, 3
+    prob = synth.problem(n, kmax, n_out)
+    groups = prob["groups"]
+    mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in groups] for _ in range(n_out)],
+                prob["costs"], [prob["costs"]] * n_out, verbose=False)
+    B = prob["budget"]
+    for N in (1, 7, 40):
+        common = {"maxit": N, "eps": 0.0, "check_every": 3}
+        m_dev = mos.solve(budget=B, solver="spg", continuous_relaxation=True, solver_params=dict(common, device_loop=True, slots=1))
+        info_dev = dict(mos.solver_info)
+        m_dev3 = mos.solve(budget=B, solver="spg", continuous_relaxation=True, solver_params=dict(common, device_loop=True, slots=3))
+        info_dev3 = dict(mos.solver_info)
+        m_host = mos.solve(budget=B, solver="spg", continuous_relaxation=True, solver_params=dict(common, device_loop=False))
+        info_host = dict(mos.solver_info)
+        for info, m in ((info_dev, m_dev), (info_dev3, m_dev3)):
+            assert info["it"] == info_host["it"] == N and info["count"] == info_host["count"], (N, info, info_host)
+            # same arithmetic up to the order of the dot-product reductions; small differences grow along the trajectory
+            tol = 1e-11 if N == 1 else 1e-5
+            assert abs(info["f"] / info_host["f"] - 1) < tol
+            assert np.abs(m - m_host).max() <= 100 * tol * np.abs(m_host).max()

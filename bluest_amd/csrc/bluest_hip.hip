@@ -906,64 +906,73 @@ __global__ __launch_bounds__(1024) void k_spg_trial(const double *__restrict__ x
 }
 
 // objective of the trial from the per-output variances, nonmonotone Armijo test, safeguarded quadratic interpolation
-// (bluest/spg.py:9-35).  One lane does the scalar work.
-__global__ void k_spg_decide(double *__restrict__ st, const double *__restrict__ var, const int32_t *__restrict__ status,
-                             int n_out, int last_slot)
+// (bluest/spg.py:9-35).  One wavefront: the state is staged through LDS with coalesced loads, lane o handles output o,
+// lane 0 takes the decision.  On the last slot of an iteration it also sets the gate of the finishing launches.
+__global__ __launch_bounds__(64) void k_spg_decide(double *__restrict__ st, const double *__restrict__ var,
+                                                   const int32_t *__restrict__ status, int n_out, int last_slot,
+                                                   int32_t *__restrict__ enable)
 {
-    if (threadIdx.x != 0) return;
-    if (st[SPG_DONE] != 0.0 || st[SPG_FAIL] != 0.0 || st[SPG_ACCEPT] != 0.0) return;
-    // objective F = || (V_o/s_o) ||_p / norm, coefficients dF/dV_o
-    bool ok = true;
-    double rmax = 0.0;
-    int omax = 0;
-    for (int o = 0; o < n_out; o++) {
-        const double r = var[o] / st[SPG_S + o];
-        if (status[o] != BLUEST_EVAL_OK || !isfinite(r)) ok = false;
-        if (r > rmax) { rmax = r; omax = o; }
+    __shared__ double ls[SPG_STATE_DOUBLES];
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < SPG_STATE_DOUBLES / 64; t++) ls[t * 64 + lane] = st[t * 64 + lane];
+    __syncthreads();
+    const bool idle = ls[SPG_DONE] != 0.0 || ls[SPG_FAIL] != 0.0;
+    if (idle || ls[SPG_ACCEPT] != 0.0) {
+        if (last_slot && lane == 0) *enable = (!idle && ls[SPG_ACCEPT] != 0.0) ? 1 : 0;
+        return;
     }
-    double F = INFINITY;
-    const double p = st[SPG_P], norm = st[SPG_NORM];
-    double coef[SPG_MAX_OUT];
+    // objective F = || (V_o/s_o) ||_p / norm, coefficients dF/dV_o
+    const bool mine = lane < n_out;
+    const double so = mine ? ls[SPG_S + lane] : 1.0;
+    const double r = mine ? var[lane] / so : 0.0;
+    const bool bad = mine && (status[lane] != BLUEST_EVAL_OK || !isfinite(r));
+    const bool ok = __ballot(bad) == 0ull;
+    const double rmax = wave_max(mine ? r : -INFINITY);
+    const double p = ls[SPG_P], norm = ls[SPG_NORM];
+    double F = INFINITY, coef = 0.0;
     if (ok) {
         if (isinf(p) || n_out == 1) {
+            const unsigned long long is_max = __ballot(mine && r == rmax);
+            const int omax = __ffsll((long long)is_max) - 1;
             F = rmax;
-            for (int o = 0; o < n_out; o++) coef[o] = (o == omax) ? 1.0 / st[SPG_S + o] : 0.0;
+            coef = (lane == omax) ? 1.0 / so : 0.0;
         } else {
-            double tsum = 0.0;
-            for (int o = 0; o < n_out; o++) tsum += pow(var[o] / st[SPG_S + o] / rmax, p);
-            F = rmax * pow(tsum, 1.0 / p);
-            const double c0 = pow(tsum, 1.0 / p - 1.0);
-            for (int o = 0; o < n_out; o++) coef[o] = pow(var[o] / st[SPG_S + o] / rmax, p - 1.0) * c0 / st[SPG_S + o];
+            const double q = mine ? r / rmax : 0.0;
+            const double tq = mine ? pow(q, p - 1.0) : 0.0;       // q^(p-1); q^p = tq*q
+            const double tsum = wave_sum(tq * q);
+            const double root = pow(tsum, 1.0 / p);
+            F = rmax * root;
+            coef = tq * (root / tsum) / so;
         }
         F /= norm;
     }
-    st[SPG_COUNT] += 1.0;
-    st[SPG_FTRIAL] = F;
-    const int H = (int)st[SPG_HLEN];
+    const int H = (int)ls[SPG_HLEN];
     double fmax = -INFINITY;
-    for (int h = 0; h < H; h++) fmax = fmax > st[SPG_HIST + h] ? fmax : st[SPG_HIST + h];
-    const double alpha = st[SPG_ALPHA], gd = st[SPG_GD], f = st[SPG_F];
-    if (F <= fmax + 1.0e-4 * alpha * gd) {
-        st[SPG_ACCEPT] = 1.0;
-        st[SPG_FNEW] = F;
-        for (int o = 0; o < n_out; o++) st[SPG_COEF + o] = coef[o] / norm;
-        return;
+    for (int h = 0; h < H; h++) fmax = fmax > ls[SPG_HIST + h] ? fmax : ls[SPG_HIST + h];
+    const double alpha = ls[SPG_ALPHA], gd = ls[SPG_GD], f = ls[SPG_F];
+    const bool accept = F <= fmax + 1.0e-4 * alpha * gd;
+    if (accept && mine) st[SPG_COEF + lane] = coef / norm;
+    if (lane == 0) {
+        st[SPG_COUNT] = ls[SPG_COUNT] + 1.0;
+        st[SPG_FTRIAL] = F;
+        if (accept) {
+            st[SPG_ACCEPT] = 1.0;
+            st[SPG_FNEW] = F;
+        } else {
+            double a = alpha;
+            if (a <= 0.1) {
+                a *= 0.5;
+            } else {
+                double at = -0.5 * (a * a) * gd / (F - f - a * gd);
+                if (!(at >= 0.1) || at > 0.9 * a) at = 0.5 * a;   // also catches F = inf (at = -0) and NaN
+                a = at;
+            }
+            st[SPG_ALPHA] = a;
+            if (last_slot) st[SPG_FAIL] = 1.0;
+        }
+        if (last_slot) *enable = accept ? 1 : 0;
     }
-    double a = alpha;
-    if (a <= 0.1) {
-        a *= 0.5;
-    } else {
-        double at = -0.5 * (a * a) * gd / (F - f - a * gd);
-        if (!(at >= 0.1) || at > 0.9 * a) at = 0.5 * a;   // also catches F = inf (at = -0) and NaN
-        a = at;
-    }
-    st[SPG_ALPHA] = a;
-    if (last_slot) st[SPG_FAIL] = 1.0;
-}
-
-__global__ void k_spg_gate(const double *__restrict__ st, int32_t *__restrict__ enable)
-{
-    if (threadIdx.x == 0) *enable = (st[SPG_ACCEPT] != 0.0 && st[SPG_DONE] == 0.0 && st[SPG_FAIL] == 0.0) ? 1 : 0;
 }
 
 struct ProjLds {
@@ -1015,18 +1024,22 @@ __device__ __forceinline__ void block_sum2_cnt(double &x, double &y, long long &
     n = c;
 }
 
-// accept the step: s = xnew - x, y = gnew - g, Barzilai-Borwein step in the metric diag(1/max(x,floor)),
-// x <- xnew, g <- gnew, history update (bluest/spg.py:85-106).  One workgroup.
-__global__ __launch_bounds__(1024) void k_spg_update(double *__restrict__ x, double *__restrict__ g,
-                                                     const double *__restrict__ xnew, const double *__restrict__ gnew,
-                                                     double *__restrict__ st, double floor, int64_t L)
+// accept the step (bluest/spg.py:85-106), two launches:
+//  A (multi-block): s = xnew - x, y = gnew - g, per-block partial sums of s^T D^-1 s (D = diag(max(x,floor))) and s.y,
+//                   x <- xnew, g <- gnew;
+//  B (one wavefront): fixed-order sum of the partials, Barzilai-Borwein lambda, history, reset of the line-search state.
+#define SPG_UPD_BLOCKS_MAX 512
+__global__ __launch_bounds__(1024) void k_spg_update_a(double *__restrict__ x, double *__restrict__ g,
+                                                       const double *__restrict__ xnew, const double *__restrict__ gnew,
+                                                       const double *__restrict__ st, double floor, int64_t L,
+                                                       double2 *__restrict__ partial)
 {
     __shared__ ProjLds sm;
     const int tid = threadIdx.x;
     if (st[SPG_DONE] != 0.0 || st[SPG_FAIL] != 0.0 || st[SPG_ACCEPT] == 0.0) return;
     double sdots = 0.0, sdoty = 0.0;
     long long dummy = 0;
-    for (int64_t i = tid; i < L; i += 1024) {
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + tid; i < L; i += (int64_t)gridDim.x * 1024) {
         const double xi = x[i], gi = g[i], xn = xnew[i], gn = gnew[i];
         const double sv = xn - xi, yv = gn - gi;
         sdots += (floor > 0.0) ? sv * sv / fmax(xi, floor) : sv * sv;
@@ -1035,16 +1048,29 @@ __global__ __launch_bounds__(1024) void k_spg_update(double *__restrict__ x, dou
         g[i] = gn;
     }
     block_sum2_cnt(sdots, sdoty, dummy, sm, tid);
-    if (tid == 0) {
+    if (tid == 0) partial[blockIdx.x] = make_double2(sdots, sdoty);
+}
+
+__global__ __launch_bounds__(64) void k_spg_update_b(double *__restrict__ st, const double2 *__restrict__ partial, int nblocks)
+{
+    __shared__ double ls[64];
+    const int lane = threadIdx.x;
+    ls[lane] = st[lane];          // scalars live in st[0..63]
+    __syncthreads();
+    if (ls[SPG_DONE] != 0.0 || ls[SPG_FAIL] != 0.0 || ls[SPG_ACCEPT] == 0.0) return;
+    double a = 0.0, b = 0.0;
+    for (int t = lane; t < nblocks; t += 64) { const double2 q = partial[t]; a += q.x; b += q.y; }
+    const double sdots = wave_sum(a), sdoty = wave_sum(b);
+    if (lane == 0) {
         st[SPG_SDOTS] = sdots;
         st[SPG_SDOTY] = sdoty;
-        const double lmin = st[SPG_LMIN], lmax = st[SPG_LMAX];
+        const double lmin = ls[SPG_LMIN], lmax = ls[SPG_LMAX];
         st[SPG_LAMBDA] = (sdoty <= 0.0) ? lmax : fmin(lmax, fmax(lmin, sdots / sdoty));
-        const double it = st[SPG_IT] + 1.0;
+        const double it = ls[SPG_IT] + 1.0;
         st[SPG_IT] = it;
-        st[SPG_F] = st[SPG_FNEW];
-        const int H = (int)st[SPG_HLEN];
-        st[SPG_HIST + ((long long)it % H)] = st[SPG_FNEW];
+        st[SPG_F] = ls[SPG_FNEW];
+        const int H = (int)ls[SPG_HLEN];
+        st[SPG_HIST + ((long long)it % H)] = ls[SPG_FNEW];
         st[SPG_ALPHA] = 1.0;
         st[SPG_ACCEPT] = 0.0;
     }
@@ -1054,38 +1080,49 @@ __global__ __launch_bounds__(1024) void k_spg_update(double *__restrict__ x, dou
 //   p_i = s_i * max(r_i - tau, 0),  r_i = x_i/s_i - lambda*g_i,  sum_i s_i max(r_i - tau, 0) = z.
 // floor == 0: s = 1 (plain Euclidean projection, the reference-style SPG step);
 // floor  > 0: s_i = max(x_i, floor) (variable "entropic" metric: the scaled SPG step).
-// ITEMS > 0: (r, s) cached in registers (L <= 1024*ITEMS); ITEMS == 0: recomputed from x,g every pass.
+// ITEMS > 0: ratios r and weights s are cached in registers (L <= 512*ITEMS);
+// ITEMS == 0: everything is recomputed from x,g in every pass.
+// spg_mode 1 (direction of the device-resident SPG): lambda from the state, and the FIRST trial point of the line search
+// (alpha = 1: xnew = x + d, m = scale*xnew, gate open) is written by the same kernel.  spg_mode 2: convergence projection.
+#define SIMPLEX_BLOCK 512   // 8 wavefronts: up to 256 VGPRs per lane, so (r, s) for 48 items stay in registers
 template <int ITEMS>
-__global__ __launch_bounds__(1024) void k_simplex(const double *__restrict__ x, const double *__restrict__ g,
+__global__ __launch_bounds__(SIMPLEX_BLOCK) void k_simplex(const double *__restrict__ x, const double *__restrict__ g,
                                                   double lambda, double z, double floor, int64_t L,
                                                   double *__restrict__ p, double *__restrict__ d,
-                                                  double *__restrict__ stats, double *__restrict__ spg_state, int spg_mode)
+                                                  double *__restrict__ stats, double *__restrict__ spg_state, int spg_mode,
+                                                  const double *__restrict__ scale, double *__restrict__ xnew,
+                                                  double *__restrict__ mtrial, int32_t *__restrict__ enable)
 {
     __shared__ ProjLds s;
     const int tid = threadIdx.x;
     if (spg_state) {   // device-resident SPG: a finished / failed run is a no-op
-        if (spg_state[SPG_DONE] != 0.0 || spg_state[SPG_FAIL] != 0.0) return;
+        if (spg_state[SPG_DONE] != 0.0 || spg_state[SPG_FAIL] != 0.0) {
+            if (enable && tid == 0) *enable = 0;
+            return;
+        }
         if (spg_mode == 1) lambda = spg_state[SPG_LAMBDA];   // direction: the step length lives in HBM
     }
     constexpr int R = ITEMS > 0 ? ITEMS : 1;
+    constexpr int B = SIMPLEX_BLOCK;
     double r[R], sc[R];
-    auto scale_of = [&](int64_t i) -> double { return floor > 0.0 ? fmax(x[i], floor) : 1.0; };
-    auto ratio_of = [&](int64_t i, double si) -> double {
-        const double xi = (floor > 0.0) ? x[i] / si : x[i];
-        return g ? fma(-lambda, g[i], xi) : xi;
+    auto scale_of = [&](double xi) -> double { return floor > 0.0 ? fmax(xi, floor) : 1.0; };
+    auto ratio_of = [&](int64_t i, double xi) -> double {
+        const double q = (floor > 0.0) ? ((xi >= floor) ? 1.0 : xi / floor) : xi;
+        return g ? fma(-lambda, g[i], q) : q;
     };
 
     double rmax = -INFINITY;
     if (ITEMS > 0) {
 #pragma unroll
         for (int k = 0; k < R; k++) {
-            const int64_t i = (int64_t)k * 1024 + tid;
-            sc[k] = (i < L) ? scale_of(i) : 0.0;
-            r[k] = (i < L) ? ratio_of(i, sc[k]) : -INFINITY;
+            const int64_t i = (int64_t)k * B + tid;
+            const double xi = (i < L) ? x[i] : 0.0;
+            sc[k] = (i < L) ? scale_of(xi) : 0.0;
+            r[k] = (i < L) ? ratio_of(i, xi) : -INFINITY;
             rmax = fmax(rmax, r[k]);
         }
     } else {
-        for (int64_t i = tid; i < L; i += 1024) rmax = fmax(rmax, ratio_of(i, scale_of(i)));
+        for (int64_t i = tid; i < L; i += B) rmax = fmax(rmax, ratio_of(i, x[i]));
     }
     rmax = block_max(rmax, s, tid);
     if (ITEMS > 0) {
@@ -1099,13 +1136,17 @@ __global__ __launch_bounds__(1024) void k_simplex(const double *__restrict__ x, 
         long long cnt = 0;
         if (ITEMS > 0) {
 #pragma unroll
-            for (int k = 0; k < R; k++)
-                if (r[k] > tau) { s1 = fma(sc[k], r[k], s1); s0 += sc[k]; cnt++; }
+            for (int k = 0; k < R; k++) {
+                const bool act = r[k] > tau;
+                s1 = act ? fma(sc[k], r[k], s1) : s1;
+                s0 = act ? s0 + sc[k] : s0;
+                cnt += act ? 1 : 0;
+            }
         } else {
-            for (int64_t i = tid; i < L; i += 1024) {
-                const double si = scale_of(i);
-                const double ri = ratio_of(i, si) - rmax;
-                if (ri > tau) { s1 = fma(si, ri, s1); s0 += si; cnt++; }
+            for (int64_t i = tid; i < L; i += B) {
+                const double xi = x[i];
+                const double ri = ratio_of(i, xi) - rmax;
+                if (ri > tau) { const double si = scale_of(xi); s1 = fma(si, ri, s1); s0 += si; cnt++; }
             }
         }
         block_sum2_cnt(s1, s0, cnt, s, tid);
@@ -1120,6 +1161,7 @@ __global__ __launch_bounds__(1024) void k_simplex(const double *__restrict__ x, 
         const double di = pi - x[i];
         if (p) p[i] = pi;
         if (d) d[i] = di;
+        if (xnew) { xnew[i] = pi; mtrial[i] = scale[i] * pi; }   // x + 1.0*d = p
         if (g) gd = fma(g[i], di, gd);
         dmax = fmax(dmax, fabs(di));
         npos += (pi > 0.0);
@@ -1127,11 +1169,11 @@ __global__ __launch_bounds__(1024) void k_simplex(const double *__restrict__ x, 
     if (ITEMS > 0) {
 #pragma unroll
         for (int k = 0; k < R; k++) {
-            const int64_t i = (int64_t)k * 1024 + tid;
+            const int64_t i = (int64_t)k * B + tid;
             if (i < L) emit(i, r[k], sc[k]);
         }
     } else {
-        for (int64_t i = tid; i < L; i += 1024) { const double si = scale_of(i); emit(i, ratio_of(i, si) - rmax, si); }
+        for (int64_t i = tid; i < L; i += B) { const double xi = x[i]; emit(i, ratio_of(i, xi) - rmax, scale_of(xi)); }
     }
     block_sum_cnt(gd, npos, s, tid);
     dmax = block_max(dmax, s, tid);
@@ -1141,8 +1183,143 @@ __global__ __launch_bounds__(1024) void k_simplex(const double *__restrict__ x, 
         stats[2] = tau;
         stats[3] = (double)npos;
     }
+    if (tid == 0 && enable) *enable = 1;
     // convergence projection of the device-resident SPG: gpmax = max|P(x - s*g) - x| <= eps ends the run (spg.py:68)
     if (tid == 0 && spg_state && spg_mode == 2 && dmax <= spg_state[SPG_EPS]) spg_state[SPG_DONE] = 1.0;
+}
+
+// ---- the same projection for long vectors: one CU cannot stream x, g, p, d fast enough (a single workgroup moves
+// ~25-60 GB/s), so the streaming parts run on many CUs and only the threshold search is a single workgroup:
+//   A (multi-block) r_i, s_i -> workspace, per-block max r
+//   B (one workgroup) Michelot/Newton search for tau on (r, s) held in registers
+//   C (multi-block) p, d (and the fused first trial point), per-block partials of g.d, max|d|, #positive
+//   D (one wavefront) fold the partials -> stats, gate, convergence flag
+struct ProjWs {            // layout of the caller-provided workspace (doubles)
+    static __host__ __device__ int64_t r_off(int64_t) { return 0; }
+    static __host__ __device__ int64_t s_off(int64_t L) { return L; }
+    static __host__ __device__ int64_t part_off(int64_t L) { return 2 * L; }            // 4 doubles per block
+    static __host__ __device__ int64_t tau_off(int64_t L, int nb) { return 2 * L + 4LL * nb; }   // tau, rmax
+    static __host__ __device__ int64_t total(int64_t L, int nb) { return 2 * L + 4LL * nb + 8; }
+};
+
+__device__ __forceinline__ bool proj_idle(const double *spg_state) { return spg_state && (spg_state[SPG_DONE] != 0.0 || spg_state[SPG_FAIL] != 0.0); }
+
+__global__ __launch_bounds__(1024) void k_proj_a(const double *__restrict__ x, const double *__restrict__ g, double lambda,
+                                                 double floor, int64_t L, double *__restrict__ ws, int nb,
+                                                 const double *__restrict__ spg_state, int spg_mode)
+{
+    __shared__ ProjLds sm;
+    if (proj_idle(spg_state)) return;
+    if (spg_state && spg_mode == 1) lambda = spg_state[SPG_LAMBDA];
+    const int tid = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
+    double ri = -INFINITY;
+    if (i < L) {
+        const double xi = x[i];
+        const double si = floor > 0.0 ? fmax(xi, floor) : 1.0;
+        const double q = (floor > 0.0) ? ((xi >= floor) ? 1.0 : xi / floor) : xi;
+        ri = g ? fma(-lambda, g[i], q) : q;
+        ws[ProjWs::r_off(L) + i] = ri;
+        ws[ProjWs::s_off(L) + i] = si;
+    }
+    const double bm = block_max(ri, sm, tid);
+    if (tid == 0) ws[ProjWs::part_off(L) + 4LL * blockIdx.x] = bm;
+}
+
+template <int ITEMS>   // ITEMS*1024 >= L, or ITEMS == 0: stream (r, s) from the workspace in every pass
+__global__ __launch_bounds__(1024) void k_proj_b(double z, double floor, int64_t L, double *__restrict__ ws, int nb,
+                                                 const double *__restrict__ spg_state)
+{
+    __shared__ ProjLds sm;
+    if (proj_idle(spg_state)) return;
+    const int tid = threadIdx.x;
+    double rmax = -INFINITY;
+    for (int b = tid; b < nb; b += 1024) rmax = fmax(rmax, ws[ProjWs::part_off(L) + 4LL * b]);
+    rmax = block_max(rmax, sm, tid);
+    constexpr int R = ITEMS > 0 ? ITEMS : 1;
+    double r[R], sc[R];
+    const double *rw = ws + ProjWs::r_off(L), *sw = ws + ProjWs::s_off(L);
+    if (ITEMS > 0) {
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int64_t i = (int64_t)k * 1024 + tid;
+            r[k] = (i < L) ? rw[i] - rmax : -INFINITY;
+            sc[k] = (i < L) ? sw[i] : 0.0;
+        }
+    }
+    double tau = (floor > 0.0) ? -z / floor : -z;
+    long long prev = -1;
+    for (int iter = 0; iter < 300; iter++) {
+        double s1 = 0.0, s0 = 0.0;
+        long long cnt = 0;
+        if (ITEMS > 0) {
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                const bool act = r[k] > tau;
+                s1 = act ? fma(sc[k], r[k], s1) : s1;
+                s0 = act ? s0 + sc[k] : s0;
+                cnt += act ? 1 : 0;
+            }
+        } else {
+            for (int64_t i = tid; i < L; i += 1024) {
+                const double ri = rw[i] - rmax;
+                if (ri > tau) { const double si = sw[i]; s1 = fma(si, ri, s1); s0 += si; cnt++; }
+            }
+        }
+        block_sum2_cnt(s1, s0, cnt, sm, tid);
+        if (cnt == prev || cnt == 0) break;
+        prev = cnt;
+        tau = (s1 - z) / s0;
+    }
+    if (tid == 0) { ws[ProjWs::tau_off(L, nb)] = tau; ws[ProjWs::tau_off(L, nb) + 1] = rmax; }
+}
+
+__global__ __launch_bounds__(1024) void k_proj_c(const double *__restrict__ x, const double *__restrict__ g, int64_t L,
+                                                 double *__restrict__ ws, int nb, double *__restrict__ p, double *__restrict__ d,
+                                                 const double *__restrict__ scale, double *__restrict__ xnew,
+                                                 double *__restrict__ mtrial, const double *__restrict__ spg_state)
+{
+    __shared__ ProjLds sm;
+    if (proj_idle(spg_state)) return;
+    const int tid = threadIdx.x;
+    const double tau = ws[ProjWs::tau_off(L, nb)], rmax = ws[ProjWs::tau_off(L, nb) + 1];
+    const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
+    double gd = 0.0, dm = 0.0;
+    long long npos = 0;
+    if (i < L) {
+        const double pi = ws[ProjWs::s_off(L) + i] * fmax(ws[ProjWs::r_off(L) + i] - rmax - tau, 0.0);
+        const double di = pi - x[i];
+        if (p) p[i] = pi;
+        if (d) d[i] = di;
+        if (xnew) { xnew[i] = pi; mtrial[i] = scale[i] * pi; }
+        if (g) gd = g[i] * di;
+        dm = fabs(di);
+        npos = pi > 0.0;
+    }
+    block_sum_cnt(gd, npos, sm, tid);
+    dm = block_max(dm, sm, tid);
+    if (tid == 0) {
+        double *pp = ws + ProjWs::part_off(L) + 4LL * blockIdx.x;
+        pp[1] = gd; pp[2] = dm; pp[3] = (double)npos;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_proj_d(int64_t L, const double *__restrict__ ws, int nb, double *__restrict__ stats,
+                                               double *__restrict__ spg_state, int spg_mode, int32_t *__restrict__ enable)
+{
+    const int lane = threadIdx.x;
+    if (proj_idle(spg_state)) { if (enable && lane == 0) *enable = 0; return; }
+    double gd = 0.0, dm = 0.0, np = 0.0;
+    for (int b = lane; b < nb; b += 64) {
+        const double *pp = ws + ProjWs::part_off(L) + 4LL * b;
+        gd += pp[1]; dm = fmax(dm, pp[2]); np += pp[3];
+    }
+    gd = wave_sum(gd); dm = wave_max(dm); np = wave_sum(np);
+    if (lane == 0) {
+        if (stats) { stats[0] = gd; stats[1] = dm; stats[2] = ws[ProjWs::tau_off(L, nb)]; stats[3] = np; }
+        if (enable) *enable = 1;
+        if (spg_state && spg_mode == 2 && dm <= spg_state[SPG_EPS]) spg_state[SPG_DONE] = 1.0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1765,28 +1942,53 @@ extern "C" int bluest_plan_combine_grad(bluest_plan_t plan, const double *grad_d
 // Part 3 host side
 // ------------------------------------------------------------------------------------------------------
 static int simplex_impl(const double *x_dev, const double *g_dev, double lambda, double z, double floor, int64_t L, double *p_dev,
-                        double *d_dev, double *stats_dev, double *spg_state, int spg_mode, void *stream)
+                        double *d_dev, double *stats_dev, double *spg_state, int spg_mode, void *stream,
+                        const double *trial_scale = nullptr, double *trial_xnew = nullptr, double *trial_m = nullptr,
+                        int32_t *trial_enable = nullptr, double *ws = nullptr)
 {
     int rc = require_gpu(); if (rc) return rc;
     if (!x_dev || L <= 0) return fail(BLUEST_ERR_ARG, "bad x / L");
     if (!(z > 0.0)) return fail(BLUEST_ERR_ARG, "z must be positive");
     if (!(floor >= 0.0)) return fail(BLUEST_ERR_ARG, "floor must be >= 0");
     hipStream_t st = (hipStream_t)stream;
-#define SP(IT) hipLaunchKernelGGL((k_simplex<IT>), dim3(1), dim3(1024), 0, st, x_dev, g_dev, lambda, z, floor, L, p_dev, d_dev, stats_dev, spg_state, spg_mode)
-    if (L <= 1024 * 4) SP(4);
-    else if (L <= 1024 * 8) SP(8);
-    else if (L <= 1024 * 16) SP(16);
-    else if (L <= 1024 * 24) SP(24);
+    if (ws && L > 4096) {   // long vector: streaming parts on many CUs
+        const int nb = (int)((L + 1023) / 1024);
+        hipLaunchKernelGGL(k_proj_a, dim3(nb), dim3(1024), 0, st, x_dev, g_dev, lambda, floor, L, ws, nb, spg_state, spg_mode);
+#define PB(IT) hipLaunchKernelGGL((k_proj_b<IT>), dim3(1), dim3(1024), 0, st, z, floor, L, ws, nb, spg_state)
+        if (L <= 1024 * 8) PB(8);
+        else if (L <= 1024 * 24) PB(24);
+        else PB(0);
+#undef PB
+        hipLaunchKernelGGL(k_proj_c, dim3(nb), dim3(1024), 0, st, x_dev, g_dev, L, ws, nb, p_dev, d_dev, trial_scale, trial_xnew, trial_m,
+                           spg_state);
+        hipLaunchKernelGGL(k_proj_d, dim3(1), dim3(64), 0, st, L, ws, nb, stats_dev, spg_state, spg_mode, trial_enable);
+        HIP_TRY(hipGetLastError());
+        return BLUEST_OK;
+    }
+#define SP(IT) hipLaunchKernelGGL((k_simplex<IT>), dim3(1), dim3(SIMPLEX_BLOCK), 0, st, x_dev, g_dev, lambda, z, floor, L, p_dev, d_dev, stats_dev, spg_state, spg_mode, \
+                                  trial_scale, trial_xnew, trial_m, trial_enable)
+    if (L <= SIMPLEX_BLOCK * 4) SP(4);
+    else if (L <= SIMPLEX_BLOCK * 12) SP(12);
+    else if (L <= SIMPLEX_BLOCK * 24) SP(24);
+    else if (L <= SIMPLEX_BLOCK * 48) SP(48);
     else SP(0);
 #undef SP
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }
 
-extern "C" int bluest_simplex_project(const double *x_dev, const double *g_dev, double lambda, double z, double floor, int64_t L,
-                                      double *p_dev, double *d_dev, double *stats_dev, void *stream)
+extern "C" int bluest_simplex_workspace_doubles(int64_t L, int64_t *n)
 {
-    return simplex_impl(x_dev, g_dev, lambda, z, floor, L, p_dev, d_dev, stats_dev, nullptr, 0, stream);
+    if (!n || L <= 0) return fail(BLUEST_ERR_ARG, "bad argument");
+    *n = ProjWs::total(L, (int)((L + 1023) / 1024));
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_simplex_project(const double *x_dev, const double *g_dev, double lambda, double z, double floor, int64_t L,
+                                      double *p_dev, double *d_dev, double *stats_dev, double *work_dev, void *stream)
+{
+    return simplex_impl(x_dev, g_dev, lambda, z, floor, L, p_dev, d_dev, stats_dev, nullptr, 0, stream, nullptr, nullptr, nullptr, nullptr,
+                        work_dev);
 }
 
 // ---- device-resident SPG (state in HBM, control flow by predication; see include/bluest_hip.h Part 3) -----------
@@ -1807,17 +2009,21 @@ extern "C" int bluest_plan_v_workspace(bluest_plan_t plan, const double **v_dev,
 }
 
 extern "C" int bluest_spg_direction(const double *x_dev, const double *g_dev, double *state_dev, double z, double floor, int64_t L,
-                                    double *d_dev, void *stream)
+                                    double *d_dev, const double *scale_dev, double *xnew_dev, double *m_dev, int32_t *enable_dev,
+                                    double *work_dev, void *stream)
 {
     if (!state_dev || !g_dev || !d_dev) return fail(BLUEST_ERR_ARG, "null pointer");
-    return simplex_impl(x_dev, g_dev, 0.0, z, floor, L, nullptr, d_dev, state_dev + SPG_GD, state_dev, 1, stream);
+    if (xnew_dev && (!scale_dev || !m_dev || !enable_dev)) return fail(BLUEST_ERR_ARG, "first-trial outputs need scale, m and enable");
+    return simplex_impl(x_dev, g_dev, 0.0, z, floor, L, nullptr, d_dev, state_dev + SPG_GD, state_dev, 1, stream, scale_dev, xnew_dev,
+                        xnew_dev ? m_dev : nullptr, xnew_dev ? enable_dev : nullptr, work_dev);
 }
 
 extern "C" int bluest_spg_converged(const double *x_dev, const double *g_dev, double *state_dev, double z, double floor, int64_t L,
-                                    void *stream)
+                                    double *work_dev, void *stream)
 {
     if (!state_dev || !g_dev) return fail(BLUEST_ERR_ARG, "null pointer");
-    return simplex_impl(x_dev, g_dev, 1.0, z, floor, L, nullptr, nullptr, state_dev + SPG_GPSTATS, state_dev, 2, stream);
+    return simplex_impl(x_dev, g_dev, 1.0, z, floor, L, nullptr, nullptr, state_dev + SPG_GPSTATS, state_dev, 2, stream, nullptr, nullptr,
+                        nullptr, nullptr, work_dev);
 }
 
 extern "C" int bluest_spg_trial(const double *x_dev, const double *d_dev, const double *scale_dev, const double *state_dev,
@@ -1831,30 +2037,25 @@ extern "C" int bluest_spg_trial(const double *x_dev, const double *d_dev, const 
     return BLUEST_OK;
 }
 
-extern "C" int bluest_spg_decide(double *state_dev, const double *var_dev, const int32_t *status_dev, int n_out, int last_slot, void *stream)
+extern "C" int bluest_spg_decide(double *state_dev, const double *var_dev, const int32_t *status_dev, int n_out, int last_slot,
+                                 int32_t *enable_dev, void *stream)
 {
     int rc = require_gpu(); if (rc) return rc;
-    if (!state_dev || !var_dev || !status_dev || n_out <= 0 || n_out > SPG_MAX_OUT) return fail(BLUEST_ERR_ARG, "bad argument");
-    hipLaunchKernelGGL(k_spg_decide, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, var_dev, status_dev, n_out, last_slot);
-    HIP_TRY(hipGetLastError());
-    return BLUEST_OK;
-}
-
-extern "C" int bluest_spg_gate(const double *state_dev, int32_t *enable_dev, void *stream)
-{
-    int rc = require_gpu(); if (rc) return rc;
-    if (!state_dev || !enable_dev) return fail(BLUEST_ERR_ARG, "null pointer");
-    hipLaunchKernelGGL(k_spg_gate, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, enable_dev);
+    if (!state_dev || !var_dev || !status_dev || !enable_dev || n_out <= 0 || n_out > SPG_MAX_OUT) return fail(BLUEST_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(k_spg_decide, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, var_dev, status_dev, n_out, last_slot, enable_dev);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }
 
 extern "C" int bluest_spg_update(double *x_dev, double *g_dev, const double *xnew_dev, const double *gnew_dev, double *state_dev,
-                                 double floor, int64_t L, void *stream)
+                                 double floor, int64_t L, double *work_dev, void *stream)
 {
     int rc = require_gpu(); if (rc) return rc;
-    if (!x_dev || !g_dev || !xnew_dev || !gnew_dev || !state_dev || L <= 0) return fail(BLUEST_ERR_ARG, "bad argument");
-    hipLaunchKernelGGL(k_spg_update, dim3(1), dim3(1024), 0, (hipStream_t)stream, x_dev, g_dev, xnew_dev, gnew_dev, state_dev, floor, L);
+    if (!x_dev || !g_dev || !xnew_dev || !gnew_dev || !state_dev || !work_dev || L <= 0) return fail(BLUEST_ERR_ARG, "bad argument");
+    const int nblocks = (int)std::min<int64_t>((L + 1023) / 1024, SPG_UPD_BLOCKS_MAX);
+    hipLaunchKernelGGL(k_spg_update_a, dim3(nblocks), dim3(1024), 0, (hipStream_t)stream, x_dev, g_dev, xnew_dev, gnew_dev, state_dev, floor, L,
+                       (double2 *)work_dev);
+    hipLaunchKernelGGL(k_spg_update_b, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, (const double2 *)work_dev, nblocks);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }

@@ -14,25 +14,82 @@ from .plan import EVAL_INF, EVAL_NO_MODEL0, EVAL_OK, EVAL_SINGULAR, Plan
 from .sap import BLUESTError, SAP, SpgAllocator, indicator_vectors, normalise_groups, status_to_python
 
 
-def build_mappings(groups, multi_groups, cumsizes):
-    """mappings[n][j] = position in the global group list of the j-th group of output n (mosap.py:54-67),
-    by hashing instead of the reference's O(L_k^2) search"""
-    pos = {}
-    for k, gk in enumerate(groups):
-        base = int(cumsizes[k])
-        for j, g in enumerate(gk.tolist()):
-            pos[tuple(g)] = base + j
+def _group_keys(gk, N):
+    """one int64 key per group (mixed radix N); None if it could overflow"""
+    k = gk.shape[1]
+    if k == 0 or N ** k >= 2 ** 62:
+        return None
+    return gk @ (np.int64(N) ** np.arange(k, dtype=np.int64))
+
+
+def build_mappings(groups, multi_groups, cumsizes, N=None):
+    """mappings[n][j] = position in the global group list of the j-th group of output n (mosap.py:54-67).
+    The reference searches the list linearly for every group (O(L_k^2)); here groups are keyed by one integer and
+    located with a sorted search (vectorised), with a tuple dictionary as the fall-back for very large groups."""
+    if N is None:
+        N = 1 + max([int(g.max()) for g in groups if len(g)] + [0])
+    gkeys = []
+    for gk in groups:
+        keys = _group_keys(np.asarray(gk, dtype=np.int64).reshape(len(gk), -1), N) if len(gk) else None
+        if keys is None:
+            gkeys.append(None)
+        else:
+            order = np.argsort(keys, kind="stable")
+            gkeys.append((keys[order], order))
+    tuple_pos = None
     mappings = []
     for mg in multi_groups:
         idx = []
         for gk in mg:
-            for g in np.asarray(gk).tolist():
-                key = tuple(g)
-                if key not in pos:
-                    raise AssertionError("group %s of an output is missing from the global group list (mosap.py:60)" % (key,))
-                idx.append(pos[key])
-        mappings.append(np.array(idx, dtype=np.int64))
+            gk = np.asarray(gk, dtype=np.int64)
+            if len(gk) == 0:
+                continue
+            k = gk.shape[1]
+            base = int(cumsizes[k - 1])
+            if k <= len(groups) and len(gk) == len(groups[k - 1]) and np.array_equal(gk, groups[k - 1]):
+                idx.append(base + np.arange(len(gk), dtype=np.int64))          # identical list: identity map
+                continue
+            entry = gkeys[k - 1] if k <= len(groups) else None
+            keys = _group_keys(gk, N)
+            if entry is not None and keys is not None:
+                sk, order = entry
+                pos = np.searchsorted(sk, keys)
+                pos = np.minimum(pos, len(sk) - 1)
+                if not (sk[pos] == keys).all():
+                    missing = gk[np.nonzero(sk[pos] != keys)[0][0]]
+                    raise AssertionError("group %s of an output is missing from the global group list (mosap.py:60)" % (tuple(missing),))
+                idx.append(base + order[pos])
+            else:
+                if tuple_pos is None:
+                    tuple_pos = {}
+                    for kk, g_all in enumerate(groups):
+                        for j, g in enumerate(np.asarray(g_all).tolist()):
+                            tuple_pos[tuple(g)] = int(cumsizes[kk]) + j
+                for g in gk.tolist():
+                    if tuple(g) not in tuple_pos:
+                        raise AssertionError("group %s of an output is missing from the global group list (mosap.py:60)" % (tuple(g),))
+                    idx.append(np.array([tuple_pos[tuple(g)]], dtype=np.int64))
+        mappings.append(np.concatenate(idx) if idx else np.zeros(0, dtype=np.int64))
     return mappings
+
+
+class _LazyFlat(object):
+    """flattened_groups (list of lists, mosap.py:31-37 / sap.py:66-83) built on first use: it is only read when an
+    allocation is reported (blue_models.py:531), and materialising ~K_tot Python lists dominates the set-up time"""
+
+    def __init__(self, groups):
+        self._groups, self._flat = groups, None
+
+    def _get(self):
+        if self._flat is None:
+            self._flat = [g for gk in self._groups for g in np.asarray(gk).tolist()]
+        return self._flat
+
+    def __getitem__(self, i): return self._get()[i]
+    def __len__(self): return sum(len(g) for g in self._groups)
+    def __iter__(self): return iter(self._get())
+    def __eq__(self, other): return list(self._get()) == list(other)
+    def __repr__(self): return repr(self._get())
 
 
 class _SapView(SAP):
@@ -51,7 +108,7 @@ class _SapView(SAP):
         groups = parent.multi_groups[n]
         self.sizes = [0] + [len(g) for g in groups]
         self.groups = groups
-        self.flattened_groups = [g for gk in groups for g in gk.tolist()]
+        self.flattened_groups = _LazyFlat(groups)
         self.cumsizes = np.cumsum(self.sizes)
         self.L = int(self.cumsizes[-1])
         flat = parent.plan.invcovs[n]
@@ -96,17 +153,18 @@ class MOSAP(object):
         self.multi_groups = multi_groups
         self.multi_costs = multi_costs
 
-        self.flattened_groups = normalise_groups(groups, K)          # mosap.py:31-37 (in place)
+        normalise_groups(groups, K, flatten=False)                   # mosap.py:31-37 (in place)
+        self.flattened_groups = _LazyFlat(groups)
         self.groups = groups
         for n in range(self.n_outputs):
-            normalise_groups(multi_groups[n], Ks[n])                 # sap.py:77 (in place, via SAP.__init__)
+            normalise_groups(multi_groups[n], Ks[n], flatten=False)  # sap.py:77 (in place, via SAP.__init__)
 
         self.sizes = [0] + [len(groupsk) for groupsk in groups]
         self.cumsizes = np.cumsum(self.sizes)
         self.L = int(self.cumsizes[-1])
         self.ES = [es.astype(np.int64) for es in indicator_vectors(groups, self.N)]
         self.e = self.ES[0]
-        self.mappings = build_mappings(groups, multi_groups, self.cumsizes)  # m[mappings[n]] = m_n
+        self.mappings = build_mappings(groups, multi_groups, self.cumsizes, self.N)  # m[mappings[n]] = m_n
 
         outs = []
         for n in range(self.n_outputs):

@@ -188,8 +188,22 @@ def simplex_project(x, g=None, lmbda=0.0, z=1.0, want_p=True, want_d=True, floor
     p = torch.empty_like(x) if want_p else None
     d = torch.empty_like(x) if want_d else None
     stats = torch.empty(4, dtype=torch.float64, device=x.device)
+    work = projection_workspace(L, x.device) if L > 4096 else None
     with torch.cuda.device(x.device):
         check(_lib.lib().bluest_simplex_project(x.data_ptr(), None if g is None else g.data_ptr(), float(lmbda), float(z), float(floor), L,
                                                 None if p is None else p.data_ptr(), None if d is None else d.data_ptr(),
-                                                stats.data_ptr(), _stream()))
+                                                stats.data_ptr(), None if work is None else work.data_ptr(), _stream()))
     return p, d, stats
+
+
+_WORKSPACES = {}
+
+
+def projection_workspace(L, device):
+    """scratch for the multi-CU projection path (cached per (L, device))"""
+    key = (int(L), str(device))
+    if key not in _WORKSPACES:
+        n = ctypes.c_int64(0)
+        check(_lib.lib().bluest_simplex_workspace_doubles(int(L), ctypes.byref(n)))
+        _WORKSPACES[key] = torch.empty(n.value, dtype=torch.float64, device=device)
+    return _WORKSPACES[key]

@@ -20,7 +20,7 @@ spg_sap_default_params = {
     "linesearch_history_length": 10,
     "smoothing_p": 32.0,      # multi-output: max_o V_o is replaced by the p-norm (smooth); inf = plain max
     "device_loop": True,      # True: whole iteration on the GPU (spg_device.DeviceSpg); False: host-driven bluest_amd.spg.spg
-    "slots": 2,               # line-search trial points launched per iteration by the device loop
+    "slots": 1,               # line-search trial points launched per iteration by the device loop (more on demand)
     "check_every": 20,        # iterations between host looks at the device state
     "scaling_floor": 1.0e-8,  # > 0: scaled SPG, steps and projections in the metric diag(1/max(x, floor)); 0: plain SPG
     "rel_tol": 1.0e-9,        # additionally stop when the objective stalls (relative decrease over a window)
@@ -32,15 +32,13 @@ class BLUESTError(RuntimeError):
     pass
 
 
-def normalise_groups(groups, K):
+def normalise_groups(groups, K, flatten=True):
     """list over k of int64 arrays (L_k, k); mutates the list in place like sap.py:77 does"""
     flattened = []
     for k in range(1, K + 1):
         gk = groups[k - 1]
-        if not isinstance(gk, np.ndarray):
-            flattened += [list(g) for g in gk]
-        else:
-            flattened += gk.tolist()
+        if flatten:
+            flattened += [list(g) for g in gk] if not isinstance(gk, np.ndarray) else gk.tolist()
         groups[k - 1] = np.array(gk, dtype=np.int64).reshape((-1, k))
     return flattened
 

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import check
-from .plan import EVAL_OK, _stream, simplex_project
+from .plan import EVAL_OK, _stream, projection_workspace, simplex_project
 
 # state layout (csrc/bluest_hip.hip SPG_*)
 F, FNEW, LAMBDA, ALPHA, GD, DMAX, TAU, NPOS, ACCEPT, FAIL, DONE, IT, COUNT, NORM, P, LMIN, LMAX, HLEN, SDOTS, SDOTY, FTRIAL = range(21)
@@ -42,6 +42,8 @@ class DeviceSpg(object):
         self.grad = torch.empty((1, plan.grad_len), **d)
         self.enable = torch.ones(1, dtype=torch.int32, device=self.dev)
         self.st = torch.zeros(STATE_DOUBLES, **d)
+        self.work = torch.zeros(1024, **d)
+        self.pws = projection_workspace(L, self.dev)
         v = ctypes.c_void_p()
         check(self.lib.bluest_plan_v_workspace(plan._h, ctypes.byref(v), None))
         self.v_ws = v.value
@@ -49,31 +51,45 @@ class DeviceSpg(object):
 
     # ---- launch sequences (captured into hipGraphs) -------------------------------------------------------------
     def _direction(self):
+        """d = P_s(x - lambda s g) - x and, fused, the first trial point (alpha = 1) + open gate"""
         check(self.lib.bluest_spg_direction(self.x.data_ptr(), self.g.data_ptr(), self.st.data_ptr(), 1.0, self.floor, self.L,
-                                            self.d.data_ptr(), _stream()))
+                                            self.d.data_ptr(), self.scale.data_ptr(), self.xnew.data_ptr(), self.m.data_ptr(),
+                                            self.enable.data_ptr(), self.pws.data_ptr(), _stream()))
 
-    def _slots(self):
-        for t in range(self.T):
+    def _slot(self, t, with_trial):
+        if with_trial:
             check(self.lib.bluest_spg_trial(self.x.data_ptr(), self.d.data_ptr(), self.scale.data_ptr(), self.st.data_ptr(),
                                             self.xnew.data_ptr(), self.m.data_ptr(), self.enable.data_ptr(), self.L, _stream()))
-            self.plan.eval(self.m, want_grad=False, out=(self.var, None, self.status))
-            check(self.lib.bluest_spg_decide(self.st.data_ptr(), self.var.data_ptr(), self.status.data_ptr(), self.n_out,
-                                             1 if t == self.T - 1 else 0, _stream()))
+        self.plan.eval(self.m, want_grad=False, out=(self.var, None, self.status))
+        check(self.lib.bluest_spg_decide(self.st.data_ptr(), self.var.data_ptr(), self.status.data_ptr(), self.n_out,
+                                         1 if t == self.T - 1 else 0, self.enable.data_ptr(), _stream()))
+
+    def _slots(self):
+        """T more trial points (host continuation of a line search that overflowed the T slots of the iteration)"""
+        for t in range(self.T):
+            self._slot(t, True)
 
     def _finish(self):
         plan = self.plan
-        check(self.lib.bluest_spg_gate(self.st.data_ptr(), self.enable.data_ptr(), _stream()))
         check(self.lib.bluest_plan_grad(plan._h, self.v_ws, self.status.data_ptr(), 1, self.grad.data_ptr(), self.grad.stride(0), _stream()))
         check(self.lib.bluest_plan_combine_grad(plan._h, self.grad.data_ptr(), self.grad.stride(0), self.st.data_ptr() + 8 * COEF,
                                                 self.scale.data_ptr(), 1, self.gnew.data_ptr(), self.L, _stream()))
         check(self.lib.bluest_spg_update(self.x.data_ptr(), self.g.data_ptr(), self.xnew.data_ptr(), self.gnew.data_ptr(),
-                                         self.st.data_ptr(), self.floor, self.L, _stream()))
-        check(self.lib.bluest_spg_converged(self.x.data_ptr(), self.g.data_ptr(), self.st.data_ptr(), 1.0, self.floor, self.L, _stream()))
+                                         self.st.data_ptr(), self.floor, self.L, self.work.data_ptr(), _stream()))
+
+    def _converged(self):
+        check(self.lib.bluest_spg_converged(self.x.data_ptr(), self.g.data_ptr(), self.st.data_ptr(), 1.0, self.floor, self.L,
+                                            self.pws.data_ptr(), _stream()))
 
     def _iteration(self):
         self._direction()
-        self._slots()
+        for t in range(self.T):
+            self._slot(t, t > 0)
         self._finish()
+
+    def _iteration_checked(self):
+        self._iteration()
+        self._converged()
 
     def _capture(self, fn):
         side = torch.cuda.Stream(device=self.dev)
@@ -131,10 +147,12 @@ class DeviceSpg(object):
             check(lib.bluest_plan_set_gate(plan._h, self.enable.data_ptr(), 1))
             try:
                 if use_graph and self.graphs is None:
-                    self.graphs = (self._capture(self._iteration), self._capture(self._slots), self._capture(self._finish))
+                    self.graphs = (self._capture(self._iteration), self._capture(self._slots), self._capture(self._finish),
+                                   self._capture(self._iteration_checked))
                 run_iter = self.graphs[0].replay if use_graph else self._iteration
                 run_slots = self.graphs[1].replay if use_graph else self._slots
                 run_finish = self.graphs[2].replay if use_graph else self._finish
+                run_iter_checked = self.graphs[3].replay if use_graph else self._iteration_checked
                 info, it = 1, 0
                 hs = h
                 while True:
@@ -144,8 +162,10 @@ class DeviceSpg(object):
                     if it >= maxit:
                         info = 1
                         break
-                    for _ in range(min(self.check_every, maxit - it)):
+                    nrun = min(self.check_every, maxit - it)
+                    for _ in range(nrun - 1):
                         run_iter()
+                    run_iter_checked()                          # last one also measures gpmax (sets DONE when <= eps)
                     hs = st.cpu().numpy()
                     while hs[FAIL] != 0.0:                       # rare: more than T trial points needed
                         if hs[ALPHA] < 1e-300 or hs[COUNT] >= max_fevals:
@@ -156,6 +176,7 @@ class DeviceSpg(object):
                         hs = st.cpu().numpy()
                         if hs[ACCEPT] != 0.0:
                             run_finish()
+                            self._converged()
                             hs = st.cpu().numpy()
                     if info == 2:
                         break

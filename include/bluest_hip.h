@@ -167,9 +167,12 @@ int bluest_plan_combine_grad(bluest_plan_t plan, const double *grad_dev, int64_t
  * stats_dev[0] = g.d, stats_dev[1] = max|d|, stats_dev[2] = tau (threshold on the ratios, after shifting by their
  * max), stats_dev[3] = number of positive entries of p.  g_dev may be NULL (then lambda is ignored: p = P(x)).
  * d_dev or p_dev may be NULL.
- * ---------------------------------------------------------------------------------------------------- */
+ * work_dev: NULL, or bluest_simplex_workspace_doubles(L) doubles of scratch; with it, vectors longer than 4096 are
+ * projected by four launches whose streaming parts use many CUs (one workgroup alone moves only ~25-60 GB/s).
+ */
+int bluest_simplex_workspace_doubles(int64_t L, int64_t *n_doubles);
 int bluest_simplex_project(const double *x_dev, const double *g_dev, double lambda, double z, double floor, int64_t L,
-                           double *p_dev, double *d_dev, double *stats_dev, void *stream);
+                           double *p_dev, double *d_dev, double *stats_dev, double *work_dev, void *stream);
 
 /* Device-resident SPG iteration (bluest/spg.py:68-106 with the control flow on the GPU).  The solver state is an
  * array of BLUEST_SPG_STATE_DOUBLES doubles in HBM (layout: csrc/bluest_hip.hip SPG_*, bluest_amd/spg_device.py);
@@ -178,26 +181,30 @@ int bluest_simplex_project(const double *x_dev, const double *g_dev, double lamb
  * update -- is a fixed launch sequence that can be captured in one hipGraph and replayed without host round trips.
  *   bluest_plan_set_gate   : the plan's kernels (Phi chunks, solve, gradient, combine) skip when *enable_dev == 0;
  *                            always_v != 0 makes every solve also produce v (kept in the plan workspace)
- *   bluest_spg_direction   : d = P_s(x - lambda*s*g) - x with lambda = state[LAMBDA]; g.d, max|d|, tau, npos -> state
+ *   bluest_spg_direction   : d = P_s(x - lambda*s*g) - x with lambda = state[LAMBDA]; g.d, max|d|, tau, npos -> state;
+ *                            optionally also the first trial point (alpha = 1): xnew = x + d, m = scale*xnew, *enable = 1
  *   bluest_spg_trial       : xnew = x + alpha*d, m = scale*xnew, *enable = 1 -- unless the iteration already accepted
  *   bluest_spg_decide      : F(trial) from the per-output variances (p-norm / max), nonmonotone Armijo test
  *                            (spg.py:17,32), safeguarded quadratic interpolation of alpha (spg.py:18-26)
- *   bluest_spg_gate        : *enable = accepted && !done && !fail (gates the gradient + combine launches)
+ *                            on the last slot of an iteration also *enable = accepted (gates gradient + combine)
  *   bluest_spg_update      : s, y, Barzilai-Borwein lambda (spg.py:91-106), x <- xnew, g <- gnew, history
+ *                            (work_dev: 1024 doubles of scratch for the per-block partial sums)
  *   bluest_spg_converged   : gpmax = max|P_s(x - s*g) - x| -> state; sets state[DONE] when gpmax <= state[EPS] (spg.py:68,99-101)
  */
 #define BLUEST_SPG_STATE_DOUBLES 256
 int bluest_plan_set_gate(bluest_plan_t plan, const int32_t *enable_dev, int always_v);
 int bluest_plan_v_workspace(bluest_plan_t plan, const double **v_dev, const int32_t **status_dev);
 int bluest_spg_direction(const double *x_dev, const double *g_dev, double *state_dev, double z, double floor, int64_t L,
-                         double *d_dev, void *stream);
-int bluest_spg_converged(const double *x_dev, const double *g_dev, double *state_dev, double z, double floor, int64_t L, void *stream);
+                         double *d_dev, const double *scale_dev, double *xnew_dev, double *m_dev, int32_t *enable_dev,
+                         double *work_dev, void *stream);
+int bluest_spg_converged(const double *x_dev, const double *g_dev, double *state_dev, double z, double floor, int64_t L,
+                         double *work_dev, void *stream);
 int bluest_spg_trial(const double *x_dev, const double *d_dev, const double *scale_dev, const double *state_dev,
                      double *xnew_dev, double *m_dev, int32_t *enable_dev, int64_t L, void *stream);
-int bluest_spg_decide(double *state_dev, const double *var_dev, const int32_t *status_dev, int n_out, int last_slot, void *stream);
-int bluest_spg_gate(const double *state_dev, int32_t *enable_dev, void *stream);
+int bluest_spg_decide(double *state_dev, const double *var_dev, const int32_t *status_dev, int n_out, int last_slot,
+                      int32_t *enable_dev, void *stream);
 int bluest_spg_update(double *x_dev, double *g_dev, const double *xnew_dev, const double *gnew_dev, double *state_dev,
-                      double floor, int64_t L, void *stream);
+                      double floor, int64_t L, double *work_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Part 4 -- integer projection batch (bluest/misc.py:228-311 multi, :313-382 single)

@@ -25,10 +25,14 @@ def test_indicator_vectors_and_mappings():
     cum = np.cumsum([0, 3, 3, 1])
     mg = [[np.array([[0], [2]]), np.array([[1, 2]]), np.zeros((0, 3), dtype=np.int64)],
           [np.array([[1]]), np.array([[0, 1], [0, 2]]), np.array([[0, 1, 2]])]]
-    maps = build_mappings(groups, mg, cum)
+    maps = build_mappings(groups, mg, cum, 3)
     assert maps[0].tolist() == [0, 2, 5] and maps[1].tolist() == [1, 3, 4, 6]
     with pytest.raises(AssertionError):
-        build_mappings(groups, [[np.array([[7]])]], cum)
+        build_mappings(groups, [[np.array([[2], [1], [0]])[:0], np.array([[1, 0]])]], cum, 3)    # (1,0) is not a listed group
+    # large groups fall back to tuple keys (N^k would overflow int64)
+    big = [np.zeros((0, k), dtype=np.int64) for k in range(1, 16)] + [np.array([np.arange(16), np.arange(1, 17)])]
+    cumb = np.cumsum([0] + [len(g) for g in big])
+    assert build_mappings(big, [[np.zeros((0, k), dtype=np.int64) for k in range(1, 16)] + [np.array([np.arange(1, 17)])]], cumb, 64)[0].tolist() == [1]
 
 
 def test_spg_driver_on_numpy(oracle):

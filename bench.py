@@ -8,9 +8,12 @@ workload : BASELINE.json configs[3]: n=20 models, groups up to size 5 (K_tot=216
            synthetic Wishart covariances (bluest_amd/synth.py).  A "step" evaluates one allocation vector m for
            all 8 outputs (what one SPG iteration / one MOSAP.variance_GH call does): 3 kernel launches
            (Phi chunks -> fold+solve -> gradient tiles), inputs resident in HBM, results left in HBM.
-N > 1    : the group set is sharded across the ranks (one process per GPU); each step all-reduces the partial
-           Phi records (n_out*(n^2+2n+1) f64) over RCCL, then every rank solves redundantly and evaluates the
-           gradient of its shard.  Total work is fixed => "scaling": "strong".
+N > 1    : one process per GPU, total work fixed => "scaling": "strong".  Two shardings of the same step:
+           --shard outputs (default when N divides n_out): the outputs are independent sample-allocation problems
+             (bluest/mosap.py:39), rank r assembles outputs r*n_out/N..; NO data-path collective;
+           --shard groups (default otherwise, e.g. single-output problems): the group set is sharded, each step
+             all-reduces the partial Phi records (n_out*(n^2+2n+1) f64) over RCCL, every rank solves redundantly
+             and evaluates the gradient of its shard (bluest_amd/dist.py).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -82,6 +85,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     ap.add_argument("--graph-steps", type=int, default=40, help="steps captured per hipGraph")
+    ap.add_argument("--shard", choices=["auto", "outputs", "groups"], default="auto")
     ap.add_argument("--n", type=int, default=N_MODELS)
     ap.add_argument("--kmax", type=int, default=KMAX)
     ap.add_argument("--n-out", type=int, default=N_OUT)
@@ -97,15 +101,32 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs the torch.distributed.run launcher with --nproc-per-node %d" % (args.gpus, args.gpus))
+    # BLUEST_BENCH_BACKEND=gloo + BLUEST_BENCH_SHARE_GPU=1: rehearsal of the N>1 path with all ranks on one GPU (RCCL refuses
+    # two ranks per device); the driver's real runs use nccl = RCCL, one rank per GPU.
+    backend = os.environ.get("BLUEST_BENCH_BACKEND", "nccl")
+    if os.environ.get("BLUEST_BENCH_SHARE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     prob = synth.problem(args.n, args.kmax, args.n_out)
     L = prob["K_tot"]
+    shard = args.shard
+    if shard == "auto":
+        shard = "outputs" if (world > 1 and args.n_out % world == 0) else "groups"
+    my_outputs = list(range(args.n_out))
     if world == 1:
         plan = Plan(args.n, L, build_outputs(prob), max_candidates=1, device=dev)
+        sharded = None
+    elif shard == "outputs":
+        per = args.n_out // world
+        my_outputs = list(range(rank * per, (rank + 1) * per))
+        plan = Plan(args.n, L, [build_outputs(prob)[o] for o in my_outputs], max_candidates=1, device=dev)
         sharded = None
     else:
         from bluest_amd.dist import ShardedPlan
@@ -123,14 +144,14 @@ def main():
 
     def step(i):
         m = ring[i % len(ring)]
-        if world == 1:
+        if sharded is None:
             plan.eval(m, out=(var, grad, status))
         else:
             v2, g2, st = sharded.eval(m, rec=rec)      # phi -> all-reduce(SUM) over RCCL -> solve -> grad of the shard
             var.copy_(v2)
 
     # ---- optional hipGraph of one ring cycle (single GPU; RCCL is left eager) -----------------------
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = (sharded is None) and not args.no_graph
     cycle = max(len(ring), args.graph_steps - args.graph_steps % len(ring))
     graph = None
     if use_graph:
@@ -171,8 +192,16 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-    assert bool((status == 0).all()) or world > 1
+    assert bool((status == 0).all()) or sharded is not None
     assert bool(torch.isfinite(var).all())
+    if world > 1:
+        # self-check outside the timed region: the sharded evaluation equals the unsharded one
+        step(0)
+        full = Plan(args.n, L, build_outputs(prob), max_candidates=1, device=dev)
+        v_full, g_full, _ = full.eval(ring[0])
+        v_mine = v_full[0, my_outputs] if sharded is None else v_full[0]
+        assert float((var[0] / v_mine - 1).abs().max()) < 1e-10, "sharded evaluation disagrees with the single-GPU one"
+        del full
 
     # ---- per-kernel durations with HIP events on the launch stream (single GPU) -----------------------
     roofline = None
@@ -232,13 +261,16 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "Phi-assemblies/s", "value": args.steps * n_out / elapsed, "unit": "assemblies/s (one output: Phi(m) over all groups -> V, grad V)",
+            "metric": "Phi-assemblies/s", "value": args.steps * args.n_out / elapsed, "unit": "assemblies/s (one output: Phi(m) over all groups -> V, grad V)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "collective_backend": None if world == 1 else backend,
             "config": {"workload": "n=%d models, groups up to size %d (K_tot=%d), n_out=%d, Wishart covariances; one step = V and grad V of one allocation for all outputs"
-                                   % (args.n, args.kmax, L, n_out),
-                       "n_models": args.n, "k_max": args.kmax, "K_tot": L, "n_out": n_out, "batch": 1,
-                       "parallelism": "single GPU" if world == 1 else "group set sharded over %d GPUs, RCCL all-reduce of Phi per step" % world,
+                                   % (args.n, args.kmax, L, args.n_out),
+                       "n_models": args.n, "k_max": args.kmax, "K_tot": L, "n_out": args.n_out, "batch": 1,
+                       "parallelism": "single GPU" if world == 1 else (
+                           "outputs sharded over %d GPUs (%d per GPU), no data-path collective" % (world, len(my_outputs)) if sharded is None
+                           else "group set sharded over %d GPUs, all-reduce of the Phi records per step" % world),
                        "launch": "hipGraph replay" if graph is not None else "eager"},
             "kernels_us": kern,
         }

@@ -40,6 +40,29 @@ def build_outputs(prob):
     return [{"K": prob["kmax"], "sizes": sizes, "groups": groups, "C": prob["C"][o], "mapping": None} for o in range(prob["n_out"])]
 
 
+def sap_wallclock(prob):
+    """second half of BASELINE.json's metric: setup_solver-style wall-clock from the covariances to the continuous optimum
+    m* (MOSAP construction: group pseudo-inverses + HBM layouts, then solver="spg" on the GPU), second (warm) repetition"""
+    import torch
+    from bluest_amd.mosap import MOSAP
+    groups, n_out, kmax = prob["groups"], prob["n_out"], prob["kmax"]
+    res = None
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in groups] for _ in range(n_out)],
+                    prob["costs"], [prob["costs"]] * n_out, verbose=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        m = mos.solve(budget=prob["budget"], solver="spg", continuous_relaxation=True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        res = {"setup_s": t1 - t0, "solve_s": t2 - t1, "total_s": t2 - t0, "spg_iterations": int(mos.solver_info["it"]),
+               "objective_evaluations": int(mos.solver_info["count"]), "max_variance": float(max(mos.variances(m))),
+               "budget": float(prob["budget"]), "solver": "spg (scaled metric, device-resident loop), continuous relaxation"}
+    return res
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json, written
     by tools/pmc_traffic.py with the guide's gfx950 FETCH_SIZE correction); None if that profile is absent"""
@@ -83,6 +106,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sap", action="store_true", help="skip the SAP wall-clock leg (covariances -> continuous optimum)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     ap.add_argument("--graph-steps", type=int, default=40, help="steps captured per hipGraph")
     ap.add_argument("--shard", choices=["auto", "outputs", "groups"], default="auto")
@@ -250,7 +274,8 @@ def main():
             if t_grad >= t_chunks:
                 kname, tk, abytes, lbytes = "k_grad_tiles", max(t_grad, 1e-9), ab["grad"] * n_out, plan.grad_bytes
             else:
-                kname, tk, abytes, lbytes = "k_phi_chunks_shared", max(t_chunks, 1e-9), ab["phi"] * n_out, plan.phi_bytes
+                kname = "k_phi_chunks_shared" if n_out >= 2 else "k_phi_chunks"
+                tk, abytes, lbytes = max(t_chunks, 1e-9), ab["phi"] * n_out, plan.phi_bytes
             achieved = abytes / tk
             roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(kname),
@@ -276,6 +301,8 @@ def main():
         }
         if roofline is not None:
             out["roofline"] = roofline
+        if world == 1 and not args.no_sap:
+            out["sap_wallclock"] = sap_wallclock(prob)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(prob)
             out["cpu_baseline"] = cb

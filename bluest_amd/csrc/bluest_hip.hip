@@ -789,7 +789,7 @@ __device__ __forceinline__ void grad_tile(const TileDesc &td, const double *__re
     }
 }
 
-// generic k (9..16): entries re-read per candidate, no big register arrays
+// generic k (13..16): entries re-read per candidate, no big register arrays
 __device__ __forceinline__ void grad_tile_generic(const TileDesc &td, const double *__restrict__ tvals,
                                                   const uint8_t *__restrict__ tidx, const double *__restrict__ v,
                                                   const int32_t *__restrict__ status, int N, int n_out, int n_cand,
@@ -816,6 +816,9 @@ __device__ __forceinline__ void grad_tile_generic(const TileDesc &td, const doub
     }
 }
 
+// KU = largest group size with a fully unrolled register path in this instantiation (the host picks the smallest
+// KU covering the plan, so the common small-k plans keep a small register footprint)
+template <int KU>
 __global__ __launch_bounds__(256) void k_grad_tiles(const TileDesc *__restrict__ tiles, int64_t n_tiles,
                                                     const double *__restrict__ tvals,
                                                     const uint8_t *__restrict__ tidx, const double *__restrict__ v,
@@ -828,9 +831,9 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const TileDesc *__restrict__
     const int lane = threadIdx.x & 63;
     if (t >= n_tiles) return;
     const TileDesc td = tiles[t];
-#define GT(KK) case KK: grad_tile<KK>(td, tvals, tidx, v, status, N, n_out, n_cand, grad, grad_stride, lane); break;
+#define GT(KK) case KK: if (KK <= KU) { grad_tile<(KK <= KU ? KK : 1)>(td, tvals, tidx, v, status, N, n_out, n_cand, grad, grad_stride, lane); break; }
     switch (td.k) {
-        GT(1) GT(2) GT(3) GT(4) GT(5) GT(6) GT(7) GT(8)
+        GT(1) GT(2) GT(3) GT(4) GT(5) GT(6) GT(7) GT(8) GT(9) GT(10) GT(11) GT(12)
         default: grad_tile_generic(td, tvals, tidx, v, status, N, n_out, n_cand, grad, grad_stride, lane);
     }
 #undef GT
@@ -1834,6 +1837,20 @@ extern "C" int bluest_plan_phi_len(bluest_plan_t plan, int64_t *len)
     return BLUEST_OK;
 }
 
+static void launch_grad(bluest_plan_t plan, const double *v_dev, const int32_t *status_dev, int n_cand, double *grad_dev,
+                        int64_t grad_stride, hipStream_t st)
+{
+    const int n_out = (int)plan->outs.size();
+    int kmax = 0;
+    for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
+#define LG(KU) hipLaunchKernelGGL((k_grad_tiles<KU>), dim3((unsigned)((plan->n_tiles + 3) / 4)), dim3(256), 0, st, plan->d_tiles, plan->n_tiles, \
+                                  plan->d_tvals, plan->d_tidx, v_dev, status_dev, plan->N, n_out, n_cand, grad_dev, grad_stride, plan->gate)
+    if (kmax <= 5) LG(5);
+    else if (kmax <= 8) LG(8);
+    else LG(12);
+#undef LG
+}
+
 static void launch_chunks(bluest_plan_t p, const double *m, int n_cand, int64_t m_stride, hipStream_t st)
 {
     const int n_out = (int)p->outs.size();
@@ -1897,8 +1914,7 @@ extern "C" int bluest_plan_grad(bluest_plan_t plan, const double *v_dev, const i
     if (!v_dev || !status_dev || !grad_dev) return fail(BLUEST_ERR_ARG, "null pointer");
     if (n_cand > 1 && grad_stride < plan->grad_len) return fail(BLUEST_ERR_ARG, "grad_stride < grad_len");
     const int n_out = (int)plan->outs.size();
-    hipLaunchKernelGGL(k_grad_tiles, dim3((unsigned)((plan->n_tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, plan->d_tiles,
-                       plan->n_tiles, plan->d_tvals, plan->d_tidx, v_dev, status_dev, plan->N, n_out, n_cand, grad_dev, grad_stride, plan->gate);
+    launch_grad(plan, v_dev, status_dev, n_cand, grad_dev, grad_stride, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }
@@ -1920,8 +1936,7 @@ extern "C" int bluest_plan_eval(bluest_plan_t plan, const double *m_dev, int n_c
     NT_DISPATCH(plan->N, LSC);
 #undef LSC
     if (grad_dev)
-        hipLaunchKernelGGL(k_grad_tiles, dim3((unsigned)((plan->n_tiles + 3) / 4)), dim3(256), 0, st, plan->d_tiles, plan->n_tiles,
-                           plan->d_tvals, plan->d_tidx, plan->d_v, status, plan->N, n_out, n_cand, grad_dev, grad_stride, plan->gate);
+        launch_grad(plan, plan->d_v, status, n_cand, grad_dev, grad_stride, st);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }

@@ -267,11 +267,16 @@ def main():
             t_grad = timed(lambda: plan.grad(vv, st2, out=grad))
             t_step = timed(lambda: plan.eval(m, out=(var, grad, status)))
             kern = {"method": "hipGraph of %d back-to-back launches, HIP events around the replay, median of 20" % R,
-                    "k_phi_chunks_us": t_chunks * 1e6, "k_phi_chunks+k_solve_from_chunks_us": t_nograd * 1e6,
-                    "k_solve_from_chunks_us(by difference)": (t_nograd - t_chunks) * 1e6, "k_grad_tiles_us": t_grad * 1e6,
-                    "step_3_kernels_us": t_step * 1e6}
+                    "k_phi_chunks_us": t_chunks * 1e6, "step_us": t_step * 1e6,
+                    "k_solve_grad_us(step - chunks; fused solve+gradient, used when k_max <= 6)": (t_step - t_chunks) * 1e6,
+                    "separate_path": {"k_phi_chunks+k_solve_from_chunks_us": t_nograd * 1e6,
+                                      "k_solve_from_chunks_us(by difference)": (t_nograd - t_chunks) * 1e6,
+                                      "k_grad_tiles_us": t_grad * 1e6}}
             # dominant kernel = the longer of the two streaming passes
-            if t_grad >= t_chunks:
+            t_sg = t_step - t_chunks
+            if t_sg >= t_chunks and args.kmax <= 6:
+                kname, tk, abytes, lbytes = "k_solve_grad", max(t_sg, 1e-9), ab["grad"] * n_out, plan.grad_bytes
+            elif t_grad >= t_chunks:
                 kname, tk, abytes, lbytes = "k_grad_tiles", max(t_grad, 1e-9), ab["grad"] * n_out, plan.grad_bytes
             else:
                 kname = "k_phi_chunks_shared" if n_out >= 2 else "k_phi_chunks"

@@ -370,7 +370,7 @@ struct TileDesc {     // 64 groups of equal size k of one output, for the gradie
     int64_t val_off;  // doubles: packed-symmetric entries, [k(k+1)/2][64]
     int64_t idx_off;  // bytes:   model indices, [k][64]
     int64_t grad_off; // position of the tile's first group inside the concatenated gradient
-    int32_t n_valid;  // groups in this tile (<= 64)
+    int32_t n_valid;  // groups in this tile (<= 64); bit 30 set on the first tile of an output
     int16_t k, out;
 };
 
@@ -463,12 +463,15 @@ __global__ __launch_bounds__(256) void k_phi_chunks_shared(const double *__restr
 // e = e_last:  L y = e  =>  y = e_last / L_nn, so V = e^T A^-1 e = 1/L_nn^2 needs NO triangular solve, and
 // x = A^-1 e needs only the backward one.  Lane i holds row i of A / L in registers (static indices after full
 // unrolling); column broadcasts are v_readlane (SGPR operands), no LDS and no barriers inside the factorisation.
-#define LDA (BLUEST_MAX_MODELS + 1)
+template <int NT>   // NT >= N: LDS footprint follows the problem (6.7 KB at NT = 20), not the 64-model maximum
 struct SolveLds {
-    double phi[BLUEST_MAX_MODELS * BLUEST_MAX_MODELS];  // full symmetric Phi (no delta)
-    double lt[BLUEST_MAX_MODELS * LDA];                 // L, for the transposed read of the backward solve
-    double amax[BLUEST_MAX_MODELS];                     // per model: max |m_i| over groups containing it
-    int model_of_pos[BLUEST_MAX_MODELS];
+    static constexpr int LDA = NT + 1;
+    double phi[NT * NT];        // full symmetric Phi (no delta), row stride N
+    double lt[NT * (NT + 1)];   // L, for the transposed read of the backward solve
+    double amax[NT];            // per model: max |m_i| over groups containing it
+    double vout[NT];            // row 0 of pinv(Phi) for the fused gradient pass
+    int model_of_pos[NT];
+    int status;
 };
 
 __device__ __forceinline__ double readlane_f64(double x, int l)
@@ -489,7 +492,8 @@ __device__ __forceinline__ double rsqrt_f64(double x)
 }
 
 // fold chunk partials of rows [row_begin, row_begin+n_rows) into lds.phi / lds.amax; all threads of the block
-__device__ __forceinline__ void fold_rows(SolveLds &lds, int N, const RowDesc *__restrict__ rows, int row_begin,
+template <int NT>
+__device__ __forceinline__ void fold_rows(SolveLds<NT> &lds, int N, const RowDesc *__restrict__ rows, int row_begin,
                                           int n_rows, const double2 *__restrict__ partial, int tid, int nthreads)
 {
     for (int r = tid; r < n_rows; r += nthreads) {
@@ -550,7 +554,7 @@ __device__ __forceinline__ void chol_regs(double (&a)[NT], double (&dv)[NT], dou
 //   [ NT-nr identity pads | sampled models except the target, ascending | target ]
 // so the target always sits at the static position NT-1.
 template <int NT>
-__device__ __forceinline__ void solve_wave(SolveLds &lds, int N, double delta, bool s1, bool s2, bool big_in, bool want_v,
+__device__ __forceinline__ void solve_wave(SolveLds<NT> &lds, int N, double delta, bool s1, bool s2, bool big_in, bool want_v,
                                         double *__restrict__ var_out, double *__restrict__ v_out,
                                         int32_t *__restrict__ status_out, int lane)
 {
@@ -609,13 +613,13 @@ __device__ __forceinline__ void solve_wave(SolveLds &lds, int N, double delta, b
                 wave_lds_sync();
                 if (lane < NT) {
 #pragma unroll
-                    for (int c = 0; c < NT; c++) lds.lt[lane * LDA + c] = a[c];
+                    for (int c = 0; c < NT; c++) lds.lt[lane * SolveLds<NT>::LDA + c] = a[c];
                 }
                 wave_lds_sync();
                 double col[NT];
 #pragma unroll
                 for (int c = 0; c < NT; c++) {
-                    const double t = lds.lt[c * LDA + (lane < NT ? lane : 0)];
+                    const double t = lds.lt[c * SolveLds<NT>::LDA + (lane < NT ? lane : 0)];
                     col[c] = (c > lane) ? t : 0.0;
                 }
                 double r = (lane == NT - 1) ? dv[NT - 1] : 0.0;
@@ -646,7 +650,7 @@ __global__ __launch_bounds__(256) void k_solve_from_chunks(int N, int n_out, con
                                                            double *__restrict__ v, int32_t *__restrict__ status,
                                                            const int32_t *__restrict__ gate)
 {
-    __shared__ SolveLds lds;
+    __shared__ SolveLds<NT> lds;
     if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
     const int o = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
     if (tid < N) lds.amax[tid] = 0.0;
@@ -669,11 +673,12 @@ __global__ __launch_bounds__(256) void k_solve_from_chunks(int N, int n_out, con
 }
 
 // multi-GPU path, phase A tail: fold chunk partials into an all-reduce-able record.
+template <int NT>
 __global__ __launch_bounds__(256) void k_fold_to_record(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
                                                         const double2 *__restrict__ partial, int64_t n_chunks,
                                                         double *__restrict__ rec)
 {
-    __shared__ SolveLds lds;
+    __shared__ SolveLds<NT> lds;
     const int o = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
     if (tid < N) lds.amax[tid] = 0.0;
     for (int t = tid; t < N * N; t += 256) lds.phi[t] = 0.0;
@@ -696,7 +701,7 @@ __global__ __launch_bounds__(64) void k_solve_from_record(int N, int n_out, cons
                                                           double delta, int want_v, double *__restrict__ var,
                                                           double *__restrict__ v, int32_t *__restrict__ status)
 {
-    __shared__ SolveLds lds;
+    __shared__ SolveLds<NT> lds;
     const int o = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
     const int reclen = N * N + 2 * N + 1;
     const double *r = rec + ((int64_t)c * n_out + o) * reclen;
@@ -717,7 +722,7 @@ __global__ __launch_bounds__(64) void k_intproj(int N, int n_out, int LL, const 
                                                 const double *__restrict__ cols, const double *__restrict__ ms,
                                                 int64_t n_cand, double *__restrict__ V)
 {
-    __shared__ SolveLds lds;
+    __shared__ SolveLds<NT> lds;
     __shared__ double sms[32];
     const int64_t cand = blockIdx.x;
     const int o = blockIdx.y, lane = threadIdx.x;
@@ -784,7 +789,7 @@ __device__ __forceinline__ void grad_tile(const TileDesc &td, const double *__re
             q = fma(vj[j], t, q);
             e += K - j;
         }
-        if (lane < td.n_valid)
+        if (lane < (td.n_valid & 0xffff))
             grad[(int64_t)c * grad_stride + td.grad_off + lane] = (status[eo] == BLUEST_EVAL_INF) ? INFINITY : -q;
     }
 }
@@ -811,7 +816,7 @@ __device__ __forceinline__ void grad_tile_generic(const TileDesc &td, const doub
             q = fma(vjj, t, q);
             e += K - j;
         }
-        if (lane < td.n_valid)
+        if (lane < (td.n_valid & 0xffff))
             grad[(int64_t)c * grad_stride + td.grad_off + lane] = (status[eo] == BLUEST_EVAL_INF) ? INFINITY : -q;
     }
 }
@@ -835,6 +840,58 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const TileDesc *__restrict__
     switch (td.k) {
         GT(1) GT(2) GT(3) GT(4) GT(5) GT(6) GT(7) GT(8) GT(9) GT(10) GT(11) GT(12)
         default: grad_tile_generic(td, tvals, tidx, v, status, N, n_out, n_cand, grad, grad_stride, lane);
+    }
+#undef GT
+}
+
+// Fused solve + gradient pass (single candidate): every workgroup owns 4 tiles of ONE output, folds that output's chunk
+// partials and factorises Phi itself (redundantly with the other workgroups of the output -- ~2.5 us of one wavefront,
+// no inter-workgroup hand-off, so nothing to synchronise), then its 4 wavefronts evaluate their tiles with v read from
+// LDS.  Saves one dependent launch per evaluation.  The tile list is padded so that no workgroup straddles two outputs.
+#define FUSED_TPB 16   // tiles (= wavefronts) per workgroup of the fused kernel
+template <int NT, int KU>
+__global__ __launch_bounds__(64 * FUSED_TPB) void k_solve_grad(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
+                                                    const double2 *__restrict__ partial, double delta,
+                                                    const TileDesc *__restrict__ tiles, int64_t n_tiles,
+                                                    const double *__restrict__ tvals, const uint8_t *__restrict__ tidx,
+                                                    double *__restrict__ var, double *__restrict__ v_ws,
+                                                    int32_t *__restrict__ status, double *__restrict__ grad,
+                                                    const int32_t *__restrict__ gate)
+{
+    __shared__ SolveLds<NT> lds;
+    if (gate && *gate == 0) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t t0 = (int64_t)blockIdx.x * FUSED_TPB;
+    const TileDesc td0 = tiles[t0];
+    const int o = td0.out;
+    if (tid < N) lds.amax[tid] = 0.0;
+    for (int t = tid; t < N * N; t += 64 * FUSED_TPB) lds.phi[t] = 0.0;
+    __syncthreads();
+    fold_rows<NT>(lds, N, rows, o * nsym, nsym, partial, tid, 64 * FUSED_TPB);
+    __syncthreads();
+    const TileDesc td = tiles[t0 + wave];     // n_tiles is a multiple of FUSED_TPB per output (padded)
+    // grad_tile reads v as v[(c*n_out + td.out)*N + model] and status[c*n_out + td.out]: point both at LDS
+    const double *vl = lds.vout - (int64_t)td.out * N;
+    const int32_t *sl = &lds.status - td.out;
+    if (wave == 0) {
+        const double am = (lane < N) ? lds.amax[lane] : 0.0;
+        const bool big = wave_max(am) >= 0.05;
+        double V = 0.0;
+        int32_t st = 0;
+        solve_wave<NT>(lds, N, delta, am > 1.0e-6, am > 0.0, big, true, &V, lds.vout, &st, lane);
+        if (lane == 0) lds.status = st;
+        if (td0.n_valid & (1 << 30)) {   // first workgroup of this output publishes V, status, v
+            if (lane == 0) { var[o] = V; status[o] = st; }
+            if (lane < N) v_ws[(int64_t)o * N + lane] = lds.vout[lane];
+        }
+    }
+    // (streaming the tiles into registers BEFORE this barrier was measured slower: the 15 streaming wavefronts then sit
+    // in front of wavefront 0's fold/solve loads in the CU's memory queue)
+    __syncthreads();
+#define GT(KK) case KK: if (KK <= KU) { grad_tile<(KK <= KU ? KK : 1)>(td, tvals, tidx, vl, sl, N, n_out, 1, grad, 0, lane); break; }
+    switch (td.k) {
+        GT(1) GT(2) GT(3) GT(4) GT(5) GT(6) GT(7) GT(8) GT(9) GT(10) GT(11) GT(12)
+        default: grad_tile_generic(td, tvals, tidx, vl, sl, N, n_out, 1, grad, 0, lane);
     }
 #undef GT
 }
@@ -1733,6 +1790,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     for (int o = 0; o < n_out; o++) {
         const OutputDesc &od = plan->outs[o];
         plan->grad_off[o] = grad_len;
+        const size_t first_tile_of_output = tiles.size();
         int64_t go = 0, io = 0, li = 0;
         for (int k = 1; k <= od.K; k++) {
             const int64_t Lk = od.sizes[k - 1];
@@ -1761,6 +1819,14 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
                 tiles.push_back(td);
             }
             go += Lk * k; io += Lk * k * k; li += Lk;
+        }
+        // first tile of the output is flagged; the list is padded to a multiple of FUSED_TPB tiles per output with empty
+        // tiles so that a workgroup of the fused solve+gradient kernel never straddles two outputs
+        tiles[first_tile_of_output].n_valid |= (1 << 30);
+        while ((tiles.size() - first_tile_of_output) % FUSED_TPB) {
+            TileDesc td;
+            td.val_off = 0; td.idx_off = 0; td.grad_off = 0; td.n_valid = 0; td.k = 1; td.out = (int16_t)o;
+            tiles.push_back(td);
         }
         grad_len += od.L_o;
     }
@@ -1887,8 +1953,10 @@ extern "C" int bluest_plan_phi(bluest_plan_t plan, const double *m_dev, int n_ca
     hipStream_t st = (hipStream_t)stream;
     const int n_out = (int)plan->outs.size();
     launch_chunks(plan, m_dev, n_cand, m_stride, st);
-    hipLaunchKernelGGL(k_fold_to_record, dim3(n_out, n_cand), dim3(256), 0, st, plan->N, n_out, plan->d_rows,
-                       plan->nsym, plan->d_partial, plan->n_chunks, phi_dev);
+#define LFR(NT) hipLaunchKernelGGL((k_fold_to_record<NT>), dim3(n_out, n_cand), dim3(256), 0, st, plan->N, n_out, plan->d_rows, \
+                                   plan->nsym, plan->d_partial, plan->n_chunks, phi_dev)
+    NT_DISPATCH(plan->N, LFR);
+#undef LFR
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }
@@ -1930,6 +1998,21 @@ extern "C" int bluest_plan_eval(bluest_plan_t plan, const double *m_dev, int n_c
     const int n_out = (int)plan->outs.size();
     int32_t *status = status_dev ? status_dev : plan->d_status;
     launch_chunks(plan, m_dev, n_cand, m_stride, st);
+    int kmax = 0;
+    for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
+    // fused solve + gradient pass (2 launches per evaluation) while the unrolled tile code fits the 128-VGPR budget of a
+    // 1024-thread workgroup (group sizes <= 6); larger groups keep the three-launch path
+    if (grad_dev && n_cand == 1 && !g_debug_solve && kmax <= 6) {
+        const dim3 grid((unsigned)(plan->n_tiles / FUSED_TPB));
+#define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * FUSED_TPB), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, \
+                                        delta, plan->d_tiles, plan->n_tiles, plan->d_tvals, plan->d_tidx, var_dev, plan->d_v, status, grad_dev, plan->gate)
+#define LSG(NT) do { if (kmax <= 5) LSG2(NT, 5); else LSG2(NT, 6); } while (0)
+        NT_DISPATCH(plan->N, LSG);
+#undef LSG
+#undef LSG2
+        HIP_TRY(hipGetLastError());
+        return BLUEST_OK;
+    }
     const int want = ((grad_dev || plan->always_v) ? 1 : 0) | g_debug_solve;
 #define LSC(NT) hipLaunchKernelGGL((k_solve_from_chunks<NT>), dim3(n_out, n_cand), dim3(256), 0, st, plan->N, n_out, plan->d_rows, \
                                    plan->nsym, plan->d_partial, plan->n_chunks, delta, want, var_dev, plan->d_v, status, plan->gate)

@@ -27,7 +27,7 @@ def main(src, tag):
     os.makedirs(out_dir, exist_ok=True)
     summary = {"source": "rocprofv3 on MI355X, tools/profile.sh %s" % tag, "kernels": {}}
     # kernel-trace stats
-    stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)
+    stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
         with open(os.path.join(out_dir, "%s_kernel_stats.csv" % tag), "w") as f:
@@ -42,7 +42,7 @@ def main(src, tag):
                 summary["kernels"][k]["calls"] = int(r["Calls"])
     # PMC passes
     for counter, key in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-        files = glob.glob(os.path.join(src, key, "**", "*counter_collection.csv"), recursive=True)
+        files = sorted(glob.glob(os.path.join(src, key, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime, reverse=True)
         if not files:
             continue
         acc = defaultdict(list)

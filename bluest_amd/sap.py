@@ -18,7 +18,8 @@ spg_sap_default_params = {
     "lmbda_min": 10. ** -30,
     "lmbda_max": 10. ** 30,
     "linesearch_history_length": 10,
-    "smoothing_p": 32.0,      # multi-output: max_o V_o is replaced by the p-norm (smooth); inf = plain max
+    "smoothing_p": (32.0, 512.0),  # multi-output: max_o V_o is replaced by the p-norm (smooth; a tuple = continuation,
+                                   # each stage warm-started from the previous one); inf = plain max
     "device_loop": True,      # True: whole iteration on the GPU (spg_device.DeviceSpg); False: host-driven bluest_amd.spg.spg
     "slots": 1,               # line-search trial points launched per iteration by the device loop (more on demand)
     "check_every": 20,        # iterations between host looks at the device state
@@ -99,7 +100,9 @@ class SpgAllocator(object):
             if not (st_try[0].cpu().numpy() == EVAL_OK).all() or not np.isfinite(r_try).all():
                 raise BLUESTError("SPG: the uniform allocation is infeasible (model 0 unsampled or singular information matrix)")
             B = B_try * float(r_try.max())
-        p = float(prm["smoothing_p"]) if n_out > 1 else np.inf
+        p_list = prm["smoothing_p"] if isinstance(prm["smoothing_p"], (list, tuple)) else [prm["smoothing_p"]]
+        p_list = [float(q) for q in p_list] if n_out > 1 else [np.inf]
+        p = p_list[0]
         scale = B / self.w                                         # m = scale * x
         st = {"x": None, "var": None, "status": None, "fevals": 0, "gevals": 0, "norm": 1.0}
 
@@ -170,12 +173,19 @@ class SpgAllocator(object):
 
         if prm["device_loop"]:
             from .spg_device import DeviceSpg
-            dspg = DeviceSpg(plan, scale, s, p, floor, lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"],
-                             Hlength=prm["linesearch_history_length"], slots=prm["slots"], check_every=prm["check_every"])
-            res = dspg.run(x, eps=prm["eps"], maxit=prm["maxit"], max_fevals=prm["max_fevals"])
+            # continuation in the smoothing exponent: each stage starts from the previous optimum (p-norm -> max)
+            tot_it = tot_count = 0
+            for stage, pq in enumerate(p_list):
+                dspg = DeviceSpg(plan, scale, s, pq, floor, lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"],
+                                 Hlength=prm["linesearch_history_length"], slots=prm["slots"], check_every=prm["check_every"])
+                res = dspg.run(x, eps=prm["eps"], maxit=prm["maxit"], max_fevals=prm["max_fevals"])
+                x = res["x"]
+                tot_it += res["it"]
+                tot_count += res["count"]
             st["norm"] = res["norm"]
             res["f"] = res["f"] / res["norm"]
-            st["fevals"], st["gevals"] = res["count"], res["it"] + 1
+            res["it"], res["count"] = tot_it, tot_count
+            st["fevals"], st["gevals"] = tot_count, tot_it + len(p_list)
         else:
             res = spg(feval, geval, proj, x, eps=prm["eps"], maxit=prm["maxit"], max_fevals=prm["max_fevals"], verbose=self.verbose,
                       lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"], Hlength=prm["linesearch_history_length"],

@@ -21,6 +21,7 @@ spg_sap_default_params = {
     "smoothing_p": (32.0, 512.0),  # multi-output: max_o V_o is replaced by the p-norm (smooth; a tuple = continuation,
                                    # each stage warm-started from the previous one); inf = plain max
     "device_loop": True,      # True: whole iteration on the GPU (spg_device.DeviceSpg); False: host-driven bluest_amd.spg.spg
+                              # (the host-driven path uses the first smoothing exponent only)
     "slots": 1,               # line-search trial points launched per iteration by the device loop (more on demand)
     "check_every": 20,        # iterations between host looks at the device state
     "scaling_floor": 1.0e-8,  # > 0: scaled SPG, steps and projections in the metric diag(1/max(x, floor)); 0: plain SPG

@@ -149,7 +149,7 @@ def test_device_spg_equals_host_driven_spg():
                 prob["costs"], [prob["costs"]] * n_out, verbose=False)
     B = prob["budget"]
     for N in (1, 7, 40):
-        common = {"maxit": N, "eps": 0.0, "check_every": 3}
+        common = {"maxit": N, "eps": 0.0, "check_every": 3, "smoothing_p": 32.0}
         m_dev = mos.solve(budget=B, solver="spg", continuous_relaxation=True, solver_params=dict(common, device_loop=True, slots=1))
         info_dev = dict(mos.solver_info)
         m_dev3 = mos.solve(budget=B, solver="spg", continuous_relaxation=True, solver_params=dict(common, device_loop=True, slots=3))

@@ -1334,6 +1334,97 @@ __global__ __launch_bounds__(1024) void k_proj_b(double z, double floor, int64_t
     if (tid == 0) { ws[ProjWs::tau_off(L, nb)] = tau; ws[ProjWs::tau_off(L, nb) + 1] = rmax; }
 }
 
+// Threshold search for vectors too long for one workgroup's registers (L > 24576): every Michelot/Newton pass is a
+// multi-block launch (P: per-block partial sums over the current active set) plus a one-wavefront launch (Q: new tau,
+// convergence flag).  A fixed number of passes is enqueued; passes after convergence exit on the flag, and k_proj_b<0>
+// (single workgroup, streaming) finishes the search in the rare case the flag is still clear.
+//   ws[tau_off + 0] tau   [+1] rmax   [+2] previous active count   [+3] converged flag
+__global__ __launch_bounds__(64) void k_proj_q0(double z, double floor, int64_t L, double *__restrict__ ws, int nb,
+                                                const double *__restrict__ spg_state)
+{
+    if (proj_idle(spg_state)) return;
+    const int lane = threadIdx.x;
+    double rmax = -INFINITY;
+    for (int b = lane; b < nb; b += 64) rmax = fmax(rmax, ws[ProjWs::part_off(L) + 4LL * b]);
+    rmax = wave_max(rmax);
+    if (lane == 0) {
+        double *t = ws + ProjWs::tau_off(L, nb);
+        t[0] = (floor > 0.0) ? -z / floor : -z;
+        t[1] = rmax;
+        t[2] = -1.0;
+        t[3] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_proj_p(int64_t L, double *__restrict__ ws, int nb, const double *__restrict__ spg_state)
+{
+    __shared__ ProjLds sm;
+    if (proj_idle(spg_state)) return;
+    const double *t = ws + ProjWs::tau_off(L, nb);
+    if (t[3] != 0.0) return;
+    const double tau = t[0], rmax = t[1];
+    const int tid = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
+    double s1 = 0.0, s0 = 0.0;
+    long long cnt = 0;
+    if (i < L) {
+        const double ri = ws[ProjWs::r_off(L) + i] - rmax;
+        if (ri > tau) { const double si = ws[ProjWs::s_off(L) + i]; s1 = si * ri; s0 = si; cnt = 1; }
+    }
+    block_sum2_cnt(s1, s0, cnt, sm, tid);
+    if (tid == 0) {
+        double *pp = ws + ProjWs::part_off(L) + 4LL * blockIdx.x;
+        pp[1] = s1; pp[2] = s0; pp[3] = (double)cnt;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_proj_q(double z, int64_t L, double *__restrict__ ws, int nb, const double *__restrict__ spg_state)
+{
+    if (proj_idle(spg_state)) return;
+    double *t = ws + ProjWs::tau_off(L, nb);
+    if (t[3] != 0.0) return;
+    const int lane = threadIdx.x;
+    double s1 = 0.0, s0 = 0.0, cnt = 0.0;
+    for (int b = lane; b < nb; b += 64) {
+        const double *pp = ws + ProjWs::part_off(L) + 4LL * b;
+        s1 += pp[1]; s0 += pp[2]; cnt += pp[3];
+    }
+    s1 = wave_sum(s1); s0 = wave_sum(s0); cnt = wave_sum(cnt);
+    if (lane == 0) {
+        if (cnt == t[2] || cnt == 0.0) { t[3] = 1.0; return; }
+        t[2] = cnt;
+        t[0] = (s1 - z) / s0;
+    }
+}
+
+// finishing search (single workgroup, streaming) if the enqueued passes did not reach the fixed point
+__global__ __launch_bounds__(1024) void k_proj_b_finish(double z, int64_t L, double *__restrict__ ws, int nb,
+                                                        const double *__restrict__ spg_state)
+{
+    __shared__ ProjLds sm;
+    if (proj_idle(spg_state)) return;
+    double *t = ws + ProjWs::tau_off(L, nb);
+    if (t[3] != 0.0) return;
+    const int tid = threadIdx.x;
+    const double rmax = t[1];
+    double tau = t[0];
+    long long prev = (long long)t[2];
+    const double *rw = ws + ProjWs::r_off(L), *sw = ws + ProjWs::s_off(L);
+    for (int iter = 0; iter < 1000; iter++) {
+        double s1 = 0.0, s0 = 0.0;
+        long long cnt = 0;
+        for (int64_t i = tid; i < L; i += 1024) {
+            const double ri = rw[i] - rmax;
+            if (ri > tau) { const double si = sw[i]; s1 = fma(si, ri, s1); s0 += si; cnt++; }
+        }
+        block_sum2_cnt(s1, s0, cnt, sm, tid);
+        if (cnt == prev || cnt == 0) break;
+        prev = cnt;
+        tau = (s1 - z) / s0;
+    }
+    if (tid == 0) { t[0] = tau; t[3] = 1.0; }
+}
+
 __global__ __launch_bounds__(1024) void k_proj_c(const double *__restrict__ x, const double *__restrict__ g, int64_t L,
                                                  double *__restrict__ ws, int nb, double *__restrict__ p, double *__restrict__ d,
                                                  const double *__restrict__ scale, double *__restrict__ xnew,
@@ -2055,7 +2146,14 @@ static int simplex_impl(const double *x_dev, const double *g_dev, double lambda,
 #define PB(IT) hipLaunchKernelGGL((k_proj_b<IT>), dim3(1), dim3(1024), 0, st, z, floor, L, ws, nb, spg_state)
         if (L <= 1024 * 8) PB(8);
         else if (L <= 1024 * 24) PB(24);
-        else PB(0);
+        else {   // long vector: multi-block Newton passes, then the (normally idle) finishing search
+            hipLaunchKernelGGL(k_proj_q0, dim3(1), dim3(64), 0, st, z, floor, L, ws, nb, spg_state);
+            for (int pass = 0; pass < 12; pass++) {
+                hipLaunchKernelGGL(k_proj_p, dim3(nb), dim3(1024), 0, st, L, ws, nb, spg_state);
+                hipLaunchKernelGGL(k_proj_q, dim3(1), dim3(64), 0, st, z, L, ws, nb, spg_state);
+            }
+            hipLaunchKernelGGL(k_proj_b_finish, dim3(1), dim3(1024), 0, st, z, L, ws, nb, spg_state);
+        }
 #undef PB
         hipLaunchKernelGGL(k_proj_c, dim3(nb), dim3(1024), 0, st, x_dev, g_dev, L, ws, nb, p_dev, d_dev, trial_scale, trial_xnew, trial_m,
                            spg_state);

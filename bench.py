@@ -179,17 +179,23 @@ def main():
     cycle = max(len(ring), args.graph_steps - args.graph_steps % len(ring))
     graph = None
     if use_graph:
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for i in range(cycle):
-                step(i)
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            for i in range(cycle):
-                step(i)
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for i in range(cycle):
+                    step(i)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            # thread_local: a process-group watchdog thread may touch the runtime while we capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                for i in range(cycle):
+                    step(i)
+        except Exception as err:   # keep the benchmark alive: eager launches measure the same work
+            sys.stderr.write("hipGraph capture failed (%s); falling back to eager launches\n" % err)
+            graph = None
+            torch.cuda.synchronize()
 
     def run(nsteps):
         if graph is not None:
@@ -249,7 +255,7 @@ def main():
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     for _ in range(R):
                         fn()
                 g.replay()

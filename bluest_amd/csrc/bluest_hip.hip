@@ -2016,8 +2016,12 @@ static void launch_chunks(bluest_plan_t p, const double *m, int n_cand, int64_t 
         const unsigned gx = (unsigned)((ncpo + 3) / 4);
 #define LCS(OB) hipLaunchKernelGGL((k_phi_chunks_shared<OB>), dim3(gx, (n_out + OB - 1) / OB), dim3(256), 0, st, p->d_vals, p->d_cols, \
                                    p->iters, ncpo, n_out, m, m_stride, n_cand, p->n_chunks, p->d_partial, p->gate)
-        if (n_out >= 8) LCS(8);
-        else if (n_out >= 4) LCS(4);
+        // outputs per wavefront: sharing the column stream saves bytes, but the pass is latency-bound, so keep at least
+        // ~4096 wavefronts in flight (measured at n=20, n_out=8: OB=8 6.9 us, OB=4 5.5 us, OB=2 5.1 us, OB=1 6.1 us)
+        int ob = 8;
+        while (ob > 2 && (ncpo * ((n_out + ob - 1) / ob) < 4096 || ob > n_out)) ob /= 2;
+        if (ob == 8) LCS(8);
+        else if (ob == 4) LCS(4);
         else LCS(2);
 #undef LCS
         return;

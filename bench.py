@@ -77,27 +77,45 @@ def pmc_traffic(kernel):
         return None
 
 
-def cpu_baseline(prob, seconds=12.0):
-    """reference CPU path restated in plain C (oracle/), one host core, output 0 only (bounded sample):
-    B1 = as executed by the reference (dense psi GEMV + pinv + gradK loops, misc.py:479-495),
-    B2 = sparse objectiveK_c-style loop (cmisc.cpp:25-40) + the same solve and gradK."""
+def cpu_baseline(prob, seconds=14.0):
+    """the reference CPU path on ONE host core, output 0 only (bounded sample), same inputs:
+    R  (kind "reference", primary when oracle/_ref travelled): bluest/misc.py:479-495 as executed -- numpy psi@m (BLAS dgemv,
+       1 thread), numpy pinv, and the reference's own compiled gradK_c (oracle/_ref, built from cmisc.cpp in the build
+       container);
+    B1 (kind "port"): the same evaluation in plain C (oracle/bluest_oracle.c: dense psi GEMV + Jacobi pinv + gradK loops);
+    B2: the sparse objectiveK_c-style loop (cmisc.cpp:25-40) + the same solve and gradK."""
     from oracle import oracle as orc
     orc.build()
     sap = orc.OracleSAP(prob["C"][0], prob["kmax"], prob["groups"], prob["costs"])
     m = prob["m"][0]
     res = {}
-    for name, dense in (("B1_dense_psi", True), ("B2_sparse", False)):
-        sap.c_variance_GH(m, dense=dense)
+
+    def rate(fn, budget):
+        fn()
         t0 = time.perf_counter()
         reps = 0
-        while time.perf_counter() - t0 < seconds / 2:
-            sap.c_variance_GH(m, dense=dense)
+        while time.perf_counter() - t0 < budget:
+            fn()
             reps += 1
-        res[name] = reps / (time.perf_counter() - t0)
-    return {"value": res["B1_dense_psi"], "unit": "Phi-assemblies/s", "cores": 1, "kind": "port",
-            "sample": "output 0 of the n=20,k_max=5 workload, variance+gradient evaluations repeated for ~%.0f s on one core; "
-                      "B1 = dense psi@m + pinv + gradK as the reference executes (bluest/misc.py:479-495)" % (seconds / 2),
-            "B2_sparse_value": res["B2_sparse"], "host_cores_available": os.cpu_count()}
+        return reps / (time.perf_counter() - t0)
+
+    res["B1"] = rate(lambda: sap.c_variance_GH(m, dense=True), seconds / 3)
+    res["B2"] = rate(lambda: sap.c_variance_GH(m, dense=False), seconds / 3)
+    kind, value = "port", res["B1"]
+    if orc.ref_native() is not None:
+        try:
+            from threadpoolctl import threadpool_limits
+            with threadpool_limits(limits=1):
+                res["R"] = rate(lambda: sap.variance_GH_as_executed(m), seconds / 3)
+            kind, value = "reference", res["R"]
+        except Exception as err:
+            sys.stderr.write("cpu_baseline: reference leg unavailable (%s)\n" % err)
+    return {"value": value, "unit": "Phi-assemblies/s", "cores": 1, "kind": kind,
+            "sample": "output 0 of the n=%d,k_max=%d workload, variance+gradient evaluations repeated for ~%.0f s per leg on one core; "
+                      "reference leg = numpy psi@m (1 BLAS thread) + numpy pinv + the reference's compiled gradK_c (bluest/misc.py:479-495)"
+                      % (prob["n"], prob["kmax"], seconds / 3),
+            "as_executed_reference_value": res.get("R"), "B1_plain_C_dense_psi_value": res["B1"], "B2_plain_C_sparse_value": res["B2"],
+            "host_cores_available": os.cpu_count()}
 
 
 def main():

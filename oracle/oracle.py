@@ -53,6 +53,25 @@ def lib():
     return _LIB
 
 
+_REF = None
+
+
+def ref_native():
+    """the reference's OWN native module, compiled from /root/reference/bluest/cmisc.cpp into oracle/_ref/ by
+    `make -C oracle ref` (build container only; the binary travels to the GPU box, the source does not).  None if absent."""
+    global _REF
+    if _REF is None:
+        import glob
+        import importlib.util
+        cands = glob.glob(os.path.join(_HERE, "_ref", "_cmisc_bluest*.so"))
+        if not cands:
+            return None
+        spec = importlib.util.spec_from_file_location("_cmisc_bluest", cands[0])
+        _REF = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(_REF)
+    return _REF
+
+
 def _f(a):
     a = np.ascontiguousarray(a, dtype=np.float64)
     return a, a.ctypes.data_as(_f64p)
@@ -220,6 +239,25 @@ class OracleSAP(object):
 
     def variance_GH(self, m, delta=0, nohess=False):
         return variance_GH_full(m, self.psi, self.groups, self.sizes, self.invcovs, delta=delta, nohess=nohess)
+
+    def variance_GH_as_executed(self, m, delta=0.0):
+        """bluest/misc.py:479-495 (nohess) exactly as the reference executes it on a CPU: dense psi@m (BLAS dgemv), two
+        numpy pinv calls, and the reference's own compiled gradK_c (oracle/_ref).  Used as bench.py's cpu_baseline of kind
+        "reference".  Raises if oracle/_ref is not there."""
+        cm = ref_native()
+        if cm is None:
+            raise RuntimeError("oracle/_ref is absent")
+        K, sizes, groups, invcovs = self.K, self.sizes, self.groups, self.invcovs
+        PHI = get_phi_full(m, self.psi, delta=delta)
+        invPHI = np.linalg.pinv(PHI)
+        idx = get_nnz_rows_cols(m, groups, self.cumsizes)
+        var = np.linalg.pinv(PHI[idx])[0, 0]
+        out = []
+        for k in range(1, K + 1):
+            grad = np.zeros((sizes[k],))
+            cm.gradK_c(grad, k, sizes[k], groups[k - 1].ravel(order='C'), invcovs[k - 1], invPHI[0])
+            out.append(grad)
+        return var, -np.concatenate(out), None
 
     # ---- flat views for the pure-C twins -------------------------------------------------------
     def flat(self):

@@ -217,3 +217,21 @@ def test_weighted_simplex_projection(oracle):
     # KKT of the weighted problem: (p-u)/s = -tau on the support, >= -tau off it
     t = ((u - p) / s)
     assert np.ptp(t[p > 0]) < 1e-10 and (t[p == 0] <= t[p > 0].max() + 1e-10).all()
+
+
+def test_reference_native_module_agrees_with_restatement(oracle):
+    """oracle/_ref (the reference's own cmisc.cpp, compiled where /root/reference exists) vs the C restatement, and the
+    'as executed' evaluation used as bench.py's reference-kind CPU baseline"""
+    cm = oracle.ref_native()
+    if cm is None:
+        pytest.skip("oracle/_ref not built (no reference tree here)")
+    prob = synth.problem(10, 4, 1)
+    sap = oracle.OracleSAP(prob["C"][0], 4, prob["groups"], prob["costs"])
+    m = prob["m"][0]
+    Va, ga, _ = sap.variance_GH_as_executed(m)
+    Vb, gb, _ = sap.variance_GH(m, nohess=True)
+    assert abs(Va / Vb - 1) < 1e-14 and rel_err(ga, gb) < 1e-14
+    for k in (1, 3):
+        PHI = np.zeros(100)
+        cm.objectiveK_c(PHI, 10, k, sap.sizes[k], m[sap.cumsizes[k - 1]:sap.cumsizes[k]], sap.groups[k - 1].ravel(), sap.invcovs[k - 1])
+        assert rel_err(PHI, oracle.objectiveK(10, k, sap.sizes[k], m[sap.cumsizes[k - 1]:sap.cumsizes[k]], sap.groups[k - 1], sap.invcovs[k - 1])) < 1e-15

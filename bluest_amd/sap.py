@@ -25,8 +25,8 @@ spg_sap_default_params = {
     "slots": 1,               # line-search trial points launched per iteration by the device loop (more on demand)
     "check_every": 20,        # iterations between host looks at the device state
     "scaling_floor": 1.0e-8,  # > 0: scaled SPG, steps and projections in the metric diag(1/max(x, floor)); 0: plain SPG
-    "rel_tol": 1.0e-9,        # additionally stop when the objective stalls (relative decrease over a window)
-    "stall_window": 200,
+    "rel_tol": 2.0e-6,        # device loop: also stop when f decreased by less than rel_tol*f over the last
+    "stall_window": 100,      #              stall_window iterations (the flat optimum keeps the projected gradient ~1e-4)
 }
 
 
@@ -179,7 +179,8 @@ class SpgAllocator(object):
             for stage, pq in enumerate(p_list):
                 dspg = DeviceSpg(plan, scale, s, pq, floor, lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"],
                                  Hlength=prm["linesearch_history_length"], slots=prm["slots"], check_every=prm["check_every"])
-                res = dspg.run(x, eps=prm["eps"], maxit=prm["maxit"], max_fevals=prm["max_fevals"])
+                res = dspg.run(x, eps=prm["eps"], maxit=prm["maxit"], max_fevals=prm["max_fevals"], rel_tol=prm["rel_tol"],
+                               stall_window=prm["stall_window"])
                 x = res["x"]
                 tot_it += res["it"]
                 tot_count += res["count"]

@@ -119,7 +119,7 @@ class DeviceSpg(object):
         t = (r / rmax) ** self.p
         return rmax * t.sum() ** (1.0 / self.p), (r / rmax) ** (self.p - 1) * t.sum() ** (1.0 / self.p - 1.0) / self.s_norm
 
-    def run(self, x0, eps=1e-7, maxit=2000, max_fevals=10 ** 6, use_graph=True):
+    def run(self, x0, eps=1e-7, maxit=2000, max_fevals=10 ** 6, use_graph=True, rel_tol=0.0, stall_window=100):
         plan, lib, st = self.plan, self.lib, self.st
         with torch.cuda.device(self.dev):
             check(lib.bluest_plan_set_gate(plan._h, None, 0))
@@ -155,8 +155,15 @@ class DeviceSpg(object):
                 run_iter_checked = self.graphs[3].replay if use_graph else self._iteration_checked
                 info, it = 1, 0
                 hs = h
+                trace = [(0, 1.0)]                                  # (iteration, normalised objective) at the host checks
                 while True:
                     if hs[DONE] != 0.0 or gpmax <= eps:
+                        info = 0
+                        break
+                    # objective stall: the scaled projected-gradient norm does not vanish on this degenerate problem (many
+                    # allocations share the optimal variance), so also stop when f stopped moving over `stall_window` iterations
+                    old = [f for (i, f) in trace if i <= it - stall_window]
+                    if rel_tol > 0.0 and old and old[-1] - trace[-1][1] <= rel_tol * abs(trace[-1][1]):
                         info = 0
                         break
                     if it >= maxit:
@@ -182,6 +189,7 @@ class DeviceSpg(object):
                         break
                     it = int(hs[IT])
                     gpmax = float(hs[GPSTATS + 1])
+                    trace.append((it, float(hs[F])))
                 hs = st.cpu().numpy()
             finally:
                 check(lib.bluest_plan_set_gate(plan._h, None, 0))

@@ -1035,53 +1035,60 @@ __global__ __launch_bounds__(64) void k_spg_decide(double *__restrict__ st, cons
     }
 }
 
+// Workgroup reductions for the projection / SPG kernels: wavefront butterflies, one LDS hand-off and ONE barrier per call.
+// The LDS slots are double-buffered by the caller-held phase bit, so a wavefront that is already in the next reduction
+// cannot overwrite values a slower wavefront is still reading (it would first have to pass the barrier in between).
+// Every wavefront folds the <= 16 per-wavefront partials itself with the same butterfly: identical results everywhere.
 struct ProjLds {
-    double dsum[16];
-    double dmax[16];
-    long long cnt[16];
+    double d0[2][16];
+    double d1[2][16];
+    long long c[2][16];
 };
 
-__device__ __forceinline__ double block_max(double x, ProjLds &s, int tid)
+__device__ __forceinline__ double block_max(double x, ProjLds &s, int tid, int &ph)
 {
     x = wave_max(x);
+    const int lane = tid & 63, nw = blockDim.x >> 6;
+    if (lane == 0) s.d0[ph][tid >> 6] = x;
     __syncthreads();
-    if ((tid & 63) == 0) s.dmax[tid >> 6] = x;
-    __syncthreads();
-    double r = s.dmax[0];
-    const int nw = blockDim.x >> 6;
-    for (int w = 1; w < nw; w++) r = fmax(r, s.dmax[w]);
-    return r;
+    double r = (lane < nw) ? s.d0[ph][lane] : -INFINITY;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) r = fmax(r, __shfl_xor(r, off, WAVE));
+    ph ^= 1;
+    return __shfl(r, 0, WAVE);
 }
-__device__ __forceinline__ void block_sum_cnt(double &x, long long &n, ProjLds &s, int tid)
+__device__ __forceinline__ void block_sum_cnt(double &x, long long &n, ProjLds &s, int tid, int &ph)
 {
     x = wave_sum(x);
     n = wave_sum_ll(n);
+    const int lane = tid & 63, nw = blockDim.x >> 6;
+    if (lane == 0) { s.d0[ph][tid >> 6] = x; s.c[ph][tid >> 6] = n; }
     __syncthreads();
-    if ((tid & 63) == 0) { s.dsum[tid >> 6] = x; s.cnt[tid >> 6] = n; }
-    __syncthreads();
-    double r = s.dsum[0];
-    long long c = s.cnt[0];
-    const int nw = blockDim.x >> 6;
-    for (int w = 1; w < nw; w++) { r += s.dsum[w]; c += s.cnt[w]; }
-    x = r;
-    n = c;
+    double r = (lane < nw) ? s.d0[ph][lane] : 0.0;
+    long long c = (lane < nw) ? s.c[ph][lane] : 0;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) { r += __shfl_xor(r, off, WAVE); c += __shfl_xor(c, off, WAVE); }
+    ph ^= 1;
+    x = __shfl(r, 0, WAVE);
+    n = __shfl(c, 0, WAVE);
 }
-
-__device__ __forceinline__ void block_sum2_cnt(double &x, double &y, long long &n, ProjLds &s, int tid)
+__device__ __forceinline__ void block_sum2_cnt(double &x, double &y, long long &n, ProjLds &s, int tid, int &ph)
 {
     x = wave_sum(x);
     y = wave_sum(y);
     n = wave_sum_ll(n);
+    const int lane = tid & 63, nw = blockDim.x >> 6;
+    if (lane == 0) { s.d0[ph][tid >> 6] = x; s.d1[ph][tid >> 6] = y; s.c[ph][tid >> 6] = n; }
     __syncthreads();
-    if ((tid & 63) == 0) { s.dsum[tid >> 6] = x; s.dmax[tid >> 6] = y; s.cnt[tid >> 6] = n; }
-    __syncthreads();
-    double r = s.dsum[0], q = s.dmax[0];
-    long long c = s.cnt[0];
-    const int nw = blockDim.x >> 6;
-    for (int w = 1; w < nw; w++) { r += s.dsum[w]; q += s.dmax[w]; c += s.cnt[w]; }
-    x = r;
-    y = q;
-    n = c;
+    double r = (lane < nw) ? s.d0[ph][lane] : 0.0;
+    double q = (lane < nw) ? s.d1[ph][lane] : 0.0;
+    long long c = (lane < nw) ? s.c[ph][lane] : 0;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) { r += __shfl_xor(r, off, WAVE); q += __shfl_xor(q, off, WAVE); c += __shfl_xor(c, off, WAVE); }
+    ph ^= 1;
+    x = __shfl(r, 0, WAVE);
+    y = __shfl(q, 0, WAVE);
+    n = __shfl(c, 0, WAVE);
 }
 
 // accept the step (bluest/spg.py:85-106), two launches:
@@ -1095,6 +1102,7 @@ __global__ __launch_bounds__(1024) void k_spg_update_a(double *__restrict__ x, d
                                                        double2 *__restrict__ partial)
 {
     __shared__ ProjLds sm;
+    int ph = 0;
     const int tid = threadIdx.x;
     if (st[SPG_DONE] != 0.0 || st[SPG_FAIL] != 0.0 || st[SPG_ACCEPT] == 0.0) return;
     double sdots = 0.0, sdoty = 0.0;
@@ -1107,7 +1115,7 @@ __global__ __launch_bounds__(1024) void k_spg_update_a(double *__restrict__ x, d
         x[i] = xn;
         g[i] = gn;
     }
-    block_sum2_cnt(sdots, sdoty, dummy, sm, tid);
+    block_sum2_cnt(sdots, sdoty, dummy, sm, tid, ph);
     if (tid == 0) partial[blockIdx.x] = make_double2(sdots, sdoty);
 }
 
@@ -1154,6 +1162,7 @@ __global__ __launch_bounds__(SIMPLEX_BLOCK) void k_simplex(const double *__restr
                                                   double *__restrict__ mtrial, int32_t *__restrict__ enable)
 {
     __shared__ ProjLds s;
+    int ph = 0;
     const int tid = threadIdx.x;
     if (spg_state) {   // device-resident SPG: a finished / failed run is a no-op
         if (spg_state[SPG_DONE] != 0.0 || spg_state[SPG_FAIL] != 0.0) {
@@ -1184,7 +1193,7 @@ __global__ __launch_bounds__(SIMPLEX_BLOCK) void k_simplex(const double *__restr
     } else {
         for (int64_t i = tid; i < L; i += B) rmax = fmax(rmax, ratio_of(i, x[i]));
     }
-    rmax = block_max(rmax, s, tid);
+    rmax = block_max(rmax, s, tid, ph);
     if (ITEMS > 0) {
 #pragma unroll
         for (int k = 0; k < R; k++) r[k] -= rmax;   // all ratios <= 0; the threshold lies in [-z/min s, 0)
@@ -1209,7 +1218,7 @@ __global__ __launch_bounds__(SIMPLEX_BLOCK) void k_simplex(const double *__restr
                 if (ri > tau) { const double si = scale_of(xi); s1 = fma(si, ri, s1); s0 += si; cnt++; }
             }
         }
-        block_sum2_cnt(s1, s0, cnt, s, tid);
+        block_sum2_cnt(s1, s0, cnt, s, tid, ph);
         if (cnt == prev || cnt == 0) break;
         prev = cnt;
         tau = (s1 - z) / s0;
@@ -1235,8 +1244,8 @@ __global__ __launch_bounds__(SIMPLEX_BLOCK) void k_simplex(const double *__restr
     } else {
         for (int64_t i = tid; i < L; i += B) { const double xi = x[i]; emit(i, ratio_of(i, xi) - rmax, scale_of(xi)); }
     }
-    block_sum_cnt(gd, npos, s, tid);
-    dmax = block_max(dmax, s, tid);
+    block_sum_cnt(gd, npos, s, tid, ph);
+    dmax = block_max(dmax, s, tid, ph);
     if (tid == 0 && stats) {
         stats[0] = gd;
         stats[1] = dmax;
@@ -1268,6 +1277,7 @@ __global__ __launch_bounds__(1024) void k_proj_a(const double *__restrict__ x, c
                                                  const double *__restrict__ spg_state, int spg_mode)
 {
     __shared__ ProjLds sm;
+    int ph = 0;
     if (proj_idle(spg_state)) return;
     if (spg_state && spg_mode == 1) lambda = spg_state[SPG_LAMBDA];
     const int tid = threadIdx.x;
@@ -1280,7 +1290,7 @@ __global__ __launch_bounds__(1024) void k_proj_a(const double *__restrict__ x, c
         ri = g ? fma(-lambda, g[i], q) : q;
         reinterpret_cast<double2 *>(ws)[i] = make_double2(ri, si);   // interleaved (r, s): one 16-byte access per item
     }
-    const double bm = block_max(ri, sm, tid);
+    const double bm = block_max(ri, sm, tid, ph);
     if (tid == 0) ws[ProjWs::part_off(L) + 4LL * blockIdx.x] = bm;
 }
 
@@ -1289,11 +1299,12 @@ __global__ __launch_bounds__(1024) void k_proj_b(double z, double floor, int64_t
                                                  const double *__restrict__ spg_state)
 {
     __shared__ ProjLds sm;
+    int ph = 0;
     if (proj_idle(spg_state)) return;
     const int tid = threadIdx.x;
     double rmax = -INFINITY;
     for (int b = tid; b < nb; b += 1024) rmax = fmax(rmax, ws[ProjWs::part_off(L) + 4LL * b]);
-    rmax = block_max(rmax, sm, tid);
+    rmax = block_max(rmax, sm, tid, ph);
     constexpr int R = ITEMS > 0 ? ITEMS : 1;
     double r[R], sc[R];
     const double2 *rs = reinterpret_cast<const double2 *>(ws);
@@ -1326,7 +1337,7 @@ __global__ __launch_bounds__(1024) void k_proj_b(double z, double floor, int64_t
                 if (ri > tau) { s1 = fma(q.y, ri, s1); s0 += q.y; cnt++; }
             }
         }
-        block_sum2_cnt(s1, s0, cnt, sm, tid);
+        block_sum2_cnt(s1, s0, cnt, sm, tid, ph);
         if (cnt == prev || cnt == 0) break;
         prev = cnt;
         tau = (s1 - z) / s0;
@@ -1359,6 +1370,7 @@ __global__ __launch_bounds__(64) void k_proj_q0(double z, double floor, int64_t 
 __global__ __launch_bounds__(1024) void k_proj_p(int64_t L, double *__restrict__ ws, int nb, const double *__restrict__ spg_state)
 {
     __shared__ ProjLds sm;
+    int ph = 0;
     if (proj_idle(spg_state)) return;
     const double *t = ws + ProjWs::tau_off(L, nb);
     if (t[3] != 0.0) return;
@@ -1372,7 +1384,7 @@ __global__ __launch_bounds__(1024) void k_proj_p(int64_t L, double *__restrict__
         const double ri = q.x - rmax;
         if (ri > tau) { s1 = q.y * ri; s0 = q.y; cnt = 1; }
     }
-    block_sum2_cnt(s1, s0, cnt, sm, tid);
+    block_sum2_cnt(s1, s0, cnt, sm, tid, ph);
     if (tid == 0) {
         double *pp = ws + ProjWs::part_off(L) + 4LL * blockIdx.x;
         pp[1] = s1; pp[2] = s0; pp[3] = (double)cnt;
@@ -1403,6 +1415,7 @@ __global__ __launch_bounds__(1024) void k_proj_b_finish(double z, int64_t L, dou
                                                         const double *__restrict__ spg_state)
 {
     __shared__ ProjLds sm;
+    int ph = 0;
     if (proj_idle(spg_state)) return;
     double *t = ws + ProjWs::tau_off(L, nb);
     if (t[3] != 0.0) return;
@@ -1419,7 +1432,7 @@ __global__ __launch_bounds__(1024) void k_proj_b_finish(double z, int64_t L, dou
             const double ri = q.x - rmax;
             if (ri > tau) { s1 = fma(q.y, ri, s1); s0 += q.y; cnt++; }
         }
-        block_sum2_cnt(s1, s0, cnt, sm, tid);
+        block_sum2_cnt(s1, s0, cnt, sm, tid, ph);
         if (cnt == prev || cnt == 0) break;
         prev = cnt;
         tau = (s1 - z) / s0;
@@ -1433,6 +1446,7 @@ __global__ __launch_bounds__(1024) void k_proj_c(const double *__restrict__ x, c
                                                  double *__restrict__ mtrial, const double *__restrict__ spg_state)
 {
     __shared__ ProjLds sm;
+    int ph = 0;
     if (proj_idle(spg_state)) return;
     const int tid = threadIdx.x;
     const double tau = ws[ProjWs::tau_off(L, nb)], rmax = ws[ProjWs::tau_off(L, nb) + 1];
@@ -1450,8 +1464,8 @@ __global__ __launch_bounds__(1024) void k_proj_c(const double *__restrict__ x, c
         dm = fabs(di);
         npos = pi > 0.0;
     }
-    block_sum_cnt(gd, npos, sm, tid);
-    dm = block_max(dm, sm, tid);
+    block_sum_cnt(gd, npos, sm, tid, ph);
+    dm = block_max(dm, sm, tid, ph);
     if (tid == 0) {
         double *pp = ws + ProjWs::part_off(L) + 4LL * blockIdx.x;
         pp[1] = gd; pp[2] = dm; pp[3] = (double)npos;

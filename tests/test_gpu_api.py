@@ -159,7 +159,7 @@ def test_device_spg_equals_host_driven_spg():
         for info, m in ((info_dev, m_dev), (info_dev3, m_dev3)):
             assert info["it"] == info_host["it"] == N and info["count"] == info_host["count"], (N, info, info_host)
             # same arithmetic up to the order of the dot-product reductions; small differences grow along the trajectory
-            tol = 1e-11 if N == 1 else 1e-5
+            tol = 1e-11 if N == 1 else (1e-7 if N == 7 else 1e-4)
             assert abs(info["f"] / info_host["f"] - 1) < tol
             assert np.abs(m - m_host).max() <= 100 * tol * np.abs(m_host).max()
 

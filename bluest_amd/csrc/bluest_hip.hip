@@ -1119,6 +1119,39 @@ __global__ __launch_bounds__(1024) void k_spg_update_a(double *__restrict__ x, d
     if (tid == 0) partial[blockIdx.x] = make_double2(sdots, sdoty);
 }
 
+// A with the gradient fold fused in: gnew_j = scale_j * sum_o coef_o * grad_o[local_o(j)] is formed on the fly (no gnew
+// vector, one launch less per iteration).
+__global__ __launch_bounds__(1024) void k_spg_update_a_fused(double *__restrict__ x, double *__restrict__ g,
+                                                             const double *__restrict__ xnew, const double *__restrict__ grad,
+                                                             const int64_t *__restrict__ goff, const int32_t *__restrict__ invmap,
+                                                             int n_out, const double *__restrict__ scale,
+                                                             const double *__restrict__ st, double floor, int64_t L,
+                                                             double2 *__restrict__ partial)
+{
+    __shared__ ProjLds sm;
+    int ph = 0;
+    const int tid = threadIdx.x;
+    if (st[SPG_DONE] != 0.0 || st[SPG_FAIL] != 0.0 || st[SPG_ACCEPT] == 0.0) return;
+    double sdots = 0.0, sdoty = 0.0;
+    long long dummy = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + tid; i < L; i += (int64_t)gridDim.x * 1024) {
+        double gn = 0.0;
+        for (int o = 0; o < n_out; o++) {
+            const int32_t li = invmap[(int64_t)o * L + i];
+            if (li >= 0) gn = fma(st[SPG_COEF + o], grad[goff[o] + li], gn);
+        }
+        gn *= scale[i];
+        const double xi = x[i], gi = g[i], xn = xnew[i];
+        const double sv = xn - xi, yv = gn - gi;
+        sdots += (floor > 0.0) ? sv * sv / fmax(xi, floor) : sv * sv;
+        sdoty = fma(sv, yv, sdoty);
+        x[i] = xn;
+        g[i] = gn;
+    }
+    block_sum2_cnt(sdots, sdoty, dummy, sm, tid, ph);
+    if (tid == 0) partial[blockIdx.x] = make_double2(sdots, sdoty);
+}
+
 __global__ __launch_bounds__(64) void k_spg_update_b(double *__restrict__ st, const double2 *__restrict__ partial, int nblocks)
 {
     __shared__ double ls[64];
@@ -2260,6 +2293,20 @@ extern "C" int bluest_spg_decide(double *state_dev, const double *var_dev, const
     int rc = require_gpu(); if (rc) return rc;
     if (!state_dev || !var_dev || !status_dev || !enable_dev || n_out <= 0 || n_out > SPG_MAX_OUT) return fail(BLUEST_ERR_ARG, "bad argument");
     hipLaunchKernelGGL(k_spg_decide, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, var_dev, status_dev, n_out, last_slot, enable_dev);
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_spg_update_fused(bluest_plan_t plan, double *x_dev, double *g_dev, const double *xnew_dev, const double *grad_dev,
+                                       const double *scale_dev, double *state_dev, double floor, double *work_dev, void *stream)
+{
+    int rc = plan_ready(plan, 1); if (rc) return rc;
+    if (!x_dev || !g_dev || !xnew_dev || !grad_dev || !scale_dev || !state_dev || !work_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    const int64_t L = plan->L;
+    const int nblocks = (int)std::min<int64_t>((L + 1023) / 1024, SPG_UPD_BLOCKS_MAX);
+    hipLaunchKernelGGL(k_spg_update_a_fused, dim3(nblocks), dim3(1024), 0, (hipStream_t)stream, x_dev, g_dev, xnew_dev, grad_dev, plan->d_goff,
+                       plan->d_invmap, (int)plan->outs.size(), scale_dev, state_dev, floor, L, (double2 *)work_dev);
+    hipLaunchKernelGGL(k_spg_update_b, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, (const double2 *)work_dev, nblocks);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }

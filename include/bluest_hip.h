@@ -205,6 +205,10 @@ int bluest_spg_decide(double *state_dev, const double *var_dev, const int32_t *s
                       int32_t *enable_dev, void *stream);
 int bluest_spg_update(double *x_dev, double *g_dev, const double *xnew_dev, const double *gnew_dev, double *state_dev,
                       double floor, int64_t L, double *work_dev, void *stream);
+/* the same with the gradient fold of bluest_plan_combine_grad fused in (coefficients from state[COEF..]): gnew is formed on
+ * the fly from the per-output gradients grad_dev (single candidate) */
+int bluest_spg_update_fused(bluest_plan_t plan, double *x_dev, double *g_dev, const double *xnew_dev, const double *grad_dev,
+                            const double *scale_dev, double *state_dev, double floor, double *work_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Part 4 -- integer projection batch (bluest/misc.py:228-311 multi, :313-382 single)

@@ -105,8 +105,18 @@ class BLUEProblem(object):
         return np.array([self.G[0].nodes[l]['cost'] for l in range(self.M)])
 
     def get_group_costs(self, groups):
+        """cost of a group = sum of its models' costs (blue_models.py:137-140), one vectorised sum per group size"""
         model_costs = self.get_costs()
-        return np.array([sum(model_costs[group]) for groupsk in groups for group in groupsk])
+        out = []
+        for groupsk in groups:
+            if len(groupsk) == 0:
+                continue
+            gk = np.asarray(groupsk)
+            if gk.dtype != object and gk.ndim == 2:
+                out.append(model_costs[gk].sum(axis=1))
+            else:                                   # ragged list (mixed sizes in one bucket): the reference's loop
+                out.append(np.array([sum(model_costs[group]) for group in groupsk]))
+        return np.concatenate(out) if out else np.zeros(0)
 
     def check_costs(self, warning=True):
         more_expensive_models = []
@@ -305,7 +315,12 @@ class BLUEProblem(object):
         M = len(nodes)
         edges = sum(1 for i, j in G.edges() if i != j and i in self.SG[n] and j in self.SG[n])
         if edges == M * (M - 1) // 2:
-            return [[list(c) for c in combinations(nodes, k)] for k in range(1, K + 1)]
+            # complete graph: every k-subset is a clique; built once per (node set, K) as integer arrays and copied per output
+            key = (tuple(nodes), K)
+            cache = self.__dict__.setdefault("_clique_cache", {})
+            if key not in cache:
+                cache[key] = [np.array(list(combinations(nodes, k)), dtype=np.int64).reshape(-1, k) for k in range(1, K + 1)]
+            return [g.copy() for g in cache[key]]
         groups = [[] for k in range(K)]
         for clique in self._nx.enumerate_all_cliques(G):
             kn = len(clique)
@@ -346,12 +361,20 @@ class BLUEProblem(object):
             Ks = [min(max(len(item) for groupsk in gs for item in groupsk), self.M) for gs in multi_groups]
             K = max(Ks)
 
-        seen = [set() for k in range(K)]                      # union over outputs, hashed (blue_models.py:493-501)
-        for n in range(self.n_outputs):
-            for k in range(Ks[n]):
-                for group in multi_groups[n][k]:
-                    seen[k].add(tuple(group))
-        groups = [sorted(list(g) for g in seen[k]) for k in range(K)]
+        def same(a, b):
+            return len(a) == len(b) and all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a, b))
+
+        if all(same(multi_groups[n], multi_groups[0]) for n in range(1, self.n_outputs)):
+            # identical lists: the union is the (sorted) list itself
+            groups = [np.array(sorted(map(tuple, np.asarray(gk).tolist())), dtype=np.int64).reshape(-1, k + 1) if len(gk) else []
+                      for k, gk in enumerate(multi_groups[0])]
+        else:
+            seen = [set() for k in range(K)]                  # union over outputs, hashed (blue_models.py:493-501)
+            for n in range(self.n_outputs):
+                for k in range(Ks[n]):
+                    for group in np.asarray(multi_groups[n][k]).tolist():
+                        seen[k].add(tuple(group))
+            groups = [sorted(list(g) for g in seen[k]) for k in range(K)]
 
         C = self.get_covariances()
         costs = self.get_group_costs(groups)

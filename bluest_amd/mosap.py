@@ -74,22 +74,26 @@ def build_mappings(groups, multi_groups, cumsizes, N=None):
 
 
 class _LazyFlat(object):
-    """flattened_groups (list of lists, mosap.py:31-37 / sap.py:66-83) built on first use: it is only read when an
-    allocation is reported (blue_models.py:531), and materialising ~K_tot Python lists dominates the set-up time"""
+    """flattened_groups (list of lists, mosap.py:31-37 / sap.py:66-83) without materialising ~K_tot Python lists: items are
+    produced on demand (it is only read for the few groups of a reported allocation, blue_models.py:531)"""
 
     def __init__(self, groups):
-        self._groups, self._flat = groups, None
+        self._groups = groups
+        self._cum = np.cumsum([0] + [len(g) for g in groups])
 
-    def _get(self):
-        if self._flat is None:
-            self._flat = [g for gk in self._groups for g in np.asarray(gk).tolist()]
-        return self._flat
+    def __getitem__(self, i):
+        i = int(i)
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        k = int(np.searchsorted(self._cum, i, side="right")) - 1
+        return np.asarray(self._groups[k][i - int(self._cum[k])]).tolist()
 
-    def __getitem__(self, i): return self._get()[i]
-    def __len__(self): return sum(len(g) for g in self._groups)
-    def __iter__(self): return iter(self._get())
-    def __eq__(self, other): return list(self._get()) == list(other)
-    def __repr__(self): return repr(self._get())
+    def __len__(self): return int(self._cum[-1])
+    def __iter__(self): return (g for gk in self._groups for g in np.asarray(gk).tolist())
+    def __eq__(self, other): return list(self) == list(other)
+    def __repr__(self): return repr(list(self))
 
 
 class _SapView(SAP):

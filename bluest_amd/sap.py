@@ -25,6 +25,7 @@ spg_sap_default_params = {
     "slots": 1,               # line-search trial points launched per iteration by the device loop (more on demand)
     "check_every": 20,        # iterations between host looks at the device state
     "scaling_floor": 1.0e-8,  # > 0: scaled SPG, steps and projections in the metric diag(1/max(x, floor)); 0: plain SPG
+    "prune_tol": 1.0e-7,      # drop the smallest entries holding less than this share of the budget (0 = keep everything)
     "rel_tol": 2.0e-6,        # device loop: also stop when f decreased by less than rel_tol*f over the last
     "stall_window": 100,      #              stall_window iterations (the flat optimum keeps the projected gradient ~1e-4)
 }
@@ -193,6 +194,24 @@ class SpgAllocator(object):
                       lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"], Hlength=prm["linesearch_history_length"],
                       proj_step=proj_step, callback=stall, metric_dot=metric_dot if floor > 0 else None)
         xs = res["x"]
+        # prune the dust: SPG iterates keep thousands of entries with a negligible share of the budget (the reference's SDP
+        # returns a sparse point); drop the smallest entries whose cumulative cost share is below prune_tol and give their
+        # budget to the rest -- changes the objective by O(prune_tol), checked below
+        tol = float(prm["prune_tol"])
+        pruned = 0
+        if tol > 0.0:
+            xs_sorted, order = torch.sort(xs)
+            cum = torch.cumsum(xs_sorted, 0)
+            k = int((cum <= tol).sum())
+            if 0 < k < L:
+                xp = xs.clone()
+                xp[order[:k]] = 0.0
+                xp = xp / xp.sum()
+                vp, _, sp = plan.eval(scale * xp, want_grad=False)
+                v0, _, _ = plan.eval(scale * xs, want_grad=False)
+                ok = bool((sp == EVAL_OK).all()) and float(((vp[0] / v0[0]).max())) <= 1.0 + 10.0 * tol
+                if ok:
+                    xs, pruned = xp, k
         m = (scale * xs)
         if budget is None:
             # rescale so that max_o V_o/eps_o^2 = 1 (V homogeneous of degree -1)
@@ -200,7 +219,7 @@ class SpgAllocator(object):
             r = (var[0].cpu().numpy() / s).max()
             m = m * r
         self.info = {"it": res["it"], "count": res["count"], "gpmax": res["gpmax"], "f": res["f"] * st["norm"],
-                     "solver_info": res["solver_info"], "fevals": st["fevals"], "gevals": st["gevals"]}
+                     "solver_info": res["solver_info"], "fevals": st["fevals"], "gevals": st["gevals"], "pruned": pruned}
         return m.cpu().numpy()
 
 

@@ -160,15 +160,17 @@ def best_closest_integer_solution(sol, N, w, e, saps, mappings, plan, budget=Non
     """bluest/misc.py:177-226 (multi) and :313-321 (single: LL <= 24 or ValueError)"""
     lb_full, ub_full, idx_full = get_feasible_integer_bounds(sol, N, e=e)
     LL = len(idx_full)
-    if not multi:
-        if LL > 24:
-            raise ValueError('Too many dimensions to brute-force it')
+    if not multi and LL <= 24:
         return _search(sol, N, w, e, saps, mappings, plan, budget, eps, max_samples_info, lb_full, ub_full, idx_full, False)
-    if LL <= LL_max:
+    if not multi:
+        # the reference raises ValueError('Too many dimensions to brute-force it') here (misc.py:320-321); with the candidate
+        # batch on the GPU the randomised search of the multi-output version (misc.py:192-226) is affordable instead
+        LL_max = 15
+    if multi and LL <= LL_max:
         return _search(sol, N, w, e, saps, mappings, plan, budget, eps, max_samples_info, lb_full, ub_full, idx_full, True)
     # misc.py:192-226: brute-force a random subset of LL_max entries, randomise the rest, up to 250 trials
     print('WARNING! Too many dimensions to brute-force it. Randomising search. Note: result might not be optimal.')
-    rng = np.random if rng is None else rng
+    rng = np.random.RandomState(0) if rng is None else rng      # reproducible (the reference uses the global numpy state)
     best_val, best_fval, trial = None, np.inf, 0
     while best_val is None and trial < 250:
         trial += 1
@@ -179,7 +181,7 @@ def best_closest_integer_solution(sol, N, w, e, saps, mappings, plan, budget=Non
         comb = rng.randint(2, size=len(rest))
         r_sol[idx_full[rest]] = r_bnds[comb, np.arange(len(rest))]
         best_val, best_fval = _search(r_sol, N, w, e, saps, mappings, plan, budget, eps, max_samples_info,
-                                      lb_full[brute], ub_full[brute], idx_full[brute], True)
+                                      lb_full[brute], ub_full[brute], idx_full[brute], multi)
     if best_val is None:
         print("Unable to find feasible integer solution.")
         return None, np.inf

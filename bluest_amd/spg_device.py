@@ -152,6 +152,7 @@ class DeviceSpg(object):
                 run_finish = self.graphs[2].replay if use_graph else self._finish
                 run_iter_checked = self.graphs[3].replay if use_graph else self._iteration_checked
                 info, it = 1, 0
+                stalled = False
                 hs = h
                 trace = [(0, 1.0)]                                  # (iteration, normalised objective) at the host checks
                 while True:
@@ -163,6 +164,7 @@ class DeviceSpg(object):
                     old = [f for (i, f) in trace if i <= it - stall_window]
                     if rel_tol > 0.0 and old and old[-1] - trace[-1][1] <= rel_tol * abs(trace[-1][1]):
                         info = 0
+                        stalled = True
                         break
                     if it >= maxit:
                         info = 1
@@ -192,4 +194,4 @@ class DeviceSpg(object):
             finally:
                 check(lib.bluest_plan_set_gate(plan._h, None, 0))
         return {"x": self.x.clone(), "f": float(hs[F]) * norm, "gpmax": gpmax, "it": int(hs[IT]), "count": int(hs[COUNT]),
-                "solver_info": info, "norm": norm}
+                "solver_info": info, "norm": norm, "stalled": stalled}

@@ -474,3 +474,54 @@ def test_integer_projection_known_answers(gpu):
     assert (val == G["m_eps_val"]).all() and abs(fval / float(G["m_eps_fval"]) - 1) < 1e-10
     # the returned objective is what MOSAP.variances gives for that integer allocation
     assert abs(max(mos.variances(val)) / fval - 1) < 1e-10
+
+
+def _oracle_eval(oracle, C, K, groups, m, delta=0.0):
+    sap = oracle.OracleSAP(C, K, groups, np.ones(sum(len(g) for g in groups)))
+    V, g, _ = sap.variance_GH(m, delta=delta, nohess=True)
+    return V, g, sap.get_phi(m, delta=delta)
+
+
+def test_edge_shapes_vs_oracle(gpu, oracle):
+    """empty size buckets, a single model, unsorted / overlapping groups, the maximum sizes of the C-ABI (n = 64, k = 16)"""
+    from bluest_amd.sap import SAP
+    rng = np.random.RandomState(8)
+    # (a) size buckets 2 and 4 empty
+    C, _ = synth.wishart_covariance(7)
+    groups = [np.array([[0], [3], [6]]), np.zeros((0, 2), dtype=np.int64), np.array([[0, 2, 5], [1, 3, 4], [4, 5, 6]]),
+              np.zeros((0, 4), dtype=np.int64), np.array([[0, 1, 2, 3, 6]])]
+    m = 1 + 9 * rng.rand(7)
+    sap = SAP(C, 5, [g.copy() for g in groups], np.ones(7), verbose=False)
+    V, g, PHI = _oracle_eval(oracle, C, 5, groups, m)
+    Vg, gg, _ = sap.variance_GH(m, nohess=True)
+    assert abs(Vg / V - 1) < TOL and rel_err(gg, g) < TOL and rel_err(sap.get_phi(m), PHI) < TOL
+    # (b) one model, one group
+    C1 = np.array([[2.5]])
+    sap1 = SAP(C1, 1, [np.array([[0]])], np.ones(1), verbose=False)
+    assert abs(sap1.variance(np.array([4.0])) / (2.5 / 4.0) - 1) < 1e-14
+    assert abs(sap1.variance_GH(np.array([4.0]), nohess=True)[1][0] / (-2.5 / 16.0) - 1) < 1e-14
+    # (c) groups listed with unsorted members and the same subset twice (the reference loops do not care)
+    groups_u = [np.array([[2], [0]]), np.array([[3, 1], [1, 3], [0, 2]])]
+    m_u = np.array([2.0, 3.0, 1.5, 0.5, 4.0])
+    C4, _ = synth.wishart_covariance(4)
+    sap_u = SAP(C4, 2, [g.copy() for g in groups_u], np.ones(5), verbose=False)
+    V, g, PHI = _oracle_eval(oracle, C4, 2, groups_u, m_u)
+    Vg, gg, _ = sap_u.variance_GH(m_u, nohess=True)
+    assert abs(Vg / V - 1) < TOL and rel_err(gg, g) < TOL and rel_err(sap_u.get_phi(m_u), PHI) < TOL
+    # (d) maximum sizes: n = 64 models, groups of 16
+    n = 64
+    C64, _ = synth.wishart_covariance(n)
+    g16 = np.array([np.sort(rng.choice(n, 16, replace=False)) for _ in range(150)] + [np.arange(16)], dtype=np.int64)
+    g1 = np.arange(n, dtype=np.int64).reshape(-1, 1)
+    groups_big = [g1] + [np.zeros((0, k), dtype=np.int64) for k in range(2, 16)] + [g16]
+    m_big = 1 + 9 * rng.rand(n + len(g16))
+    sap_big = SAP(C64, 16, [g.copy() for g in groups_big], np.ones(len(m_big)), verbose=False)
+    V, g, PHI = _oracle_eval(oracle, C64, 16, groups_big, m_big)
+    Vg, gg, _ = sap_big.variance_GH(m_big, nohess=True)
+    assert abs(Vg / V - 1) < 1e-9 and rel_err(gg, g) < 1e-9 and rel_err(sap_big.get_phi(m_big), PHI) < 1e-12
+    # (e) out-of-range arguments are refused by the C-ABI, not executed
+    from bluest_amd import _lib
+    with pytest.raises(_lib.BluestHipError):
+        SAP(np.eye(3), 1, [np.array([[0], [5]])], np.ones(2), verbose=False)          # model index 5 >= n
+    with pytest.raises(_lib.BluestHipError):
+        SAP(np.eye(70), 1, [np.arange(70).reshape(-1, 1)], np.ones(70), verbose=False)  # n > BLUEST_MAX_MODELS

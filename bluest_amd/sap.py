@@ -16,7 +16,10 @@ spg_sap_default_params = {
     "maxit": 4000,            # total iteration budget over all stages and restarts
     "max_fevals": 10 ** 6,
     "lmbda_min": 10. ** -30,
-    "lmbda_max": 10. ** 30,
+    "lmbda_max": 10. ** 3,    # cap of the spectral step (objective normalised to 1, x on the unit simplex).  The reference's
+                              # 1e30 (meant for its covariance projection) makes every s.y <= 0 event -- frequent on this flat
+                              # optimum -- a jump to a vertex followed by ~13 backtracking evaluations; 1e3 was the best of
+                              # {1e30, 1e6, 1e3, 1e1} in both speed and objective at K_tot = 245505
     "linesearch_history_length": 10,
     "smoothing_p": (32.0, 512.0),  # multi-output: max_o V_o is replaced by the p-norm (smooth; a tuple = continuation,
                                    # each stage warm-started from the previous one); inf = plain max

@@ -21,9 +21,9 @@ def short(name):
     return name.split("(")[0].split("<")[0]
 
 
-def main(src, tag):
+def main(src, tag, out_dir=None):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out_dir = os.path.join(root, "profiles")
+    out_dir = out_dir or os.path.join(root, "profiles")
     os.makedirs(out_dir, exist_ok=True)
     summary = {"source": "rocprofv3 on MI355X, tools/profile.sh %s" % tag, "kernels": {}}
     # kernel-trace stats
@@ -71,4 +71,4 @@ def main(src, tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r01")
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r01", sys.argv[3] if len(sys.argv) > 3 else None)

@@ -36,6 +36,14 @@
 // error plumbing
 // ------------------------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
+#ifdef BLUEST_PHASE_TIMING   // experiment builds only (tools/phase_timing.py): 100 MHz timestamps of one workgroup's phases
+__device__ long long g_phase[3][12];
+#define PHASE(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1)) \
+        g_phase[blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 2 : 1)][i] = wall_clock64(); } while (0)
+extern "C" int bluest_debug_phase_times(long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(long long) * 36) == hipSuccess ? 0 : 1; }
+#else
+#define PHASE(i)
+#endif
 static int g_debug_solve = getenv("BLUEST_DEBUG_SOLVE") ? atoi(getenv("BLUEST_DEBUG_SOLVE")) : 0;  // timing experiments only
 
 static int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -530,22 +538,39 @@ __device__ __forceinline__ void wave_lds_sync()
 
 __device__ __forceinline__ int uniform_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
-// Right-looking Cholesky of an NT x NT matrix whose row `lane` sits in a[0..NT) (lower triangle used), straight-line
-// code: no predicates, no LDS, no barriers.  On return a[c] (c <= lane) = L[lane][c]; dv[j] = 1/L[j][j]
-// (wave-uniform).  Non-positive pivots are reported through `bad` (NaNs simply propagate).
+__device__ __forceinline__ double rcp_f64(double x)
+{   // v_rcp_f64 seed + Newton steps (y <- y + y*(1 - x y)): full double accuracy for normal x
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
+
+// Gauss-Jordan elimination (no pivoting: the matrix is symmetric positive definite) of an NT x NT matrix whose row
+// `lane` sits in a[0..NT), straight-line code: no predicates, no LDS, no barriers.  Step j subtracts multiples of row j
+// from ALL other rows (the lanes above the diagonal are there anyway, so eliminating upwards is free and replaces the
+// backward substitution of a Cholesky solve).  Only columns c > j are touched.  The pivots are the same Schur-complement
+// diagonals a Cholesky factorisation squares-roots, so "not positive definite" is detected identically.
+// The right-hand side is e_last and never stored: it stays e_last until the last step, hence on return
+//   x_last = 1/p_last,   x_i = -a[NT-1](lane i, before the last step) / (p_i p_last)   (i != last)
+// with p_i = pivot i; rinv_mine = 1/p_lane, last_pivot = p_last.
 template <int NT>
-__device__ __forceinline__ void chol_regs(double (&a)[NT], double (&dv)[NT], double &last_pivot, int &bad)
+__device__ __forceinline__ void gj_regs(double (&a)[NT], int lane, double &rinv_mine, double &last_pivot, int &bad)
 {
 #pragma unroll
     for (int j = 0; j < NT; j++) {
         const double piv = readlane_f64(a[j], j);
         bad |= (!(piv > 0.0) || !isfinite(piv)) ? 1 : 0;
-        const double dinv = rsqrt_f64(piv);
-        if (j == NT - 1) last_pivot = piv;
-        dv[j] = dinv;
-        a[j] *= dinv;
+        const double rinv = rcp_f64(piv);
+        rinv_mine = (lane == j) ? rinv : rinv_mine;
+        if (j == NT - 1) { last_pivot = piv; break; }
+        const double f = (lane == j) ? 0.0 : -a[j] * rinv;
 #pragma unroll
-        for (int c = j + 1; c < NT; c++) a[c] = fma(-a[j], readlane_f64(a[j], c), a[c]);
+        for (int c = j + 1; c < NT; c++) a[c] = fma(f, readlane_f64(a[c], j), a[c]);
     }
 }
 
@@ -563,7 +588,10 @@ __device__ __forceinline__ void solve_wave(SolveLds<NT> &lds, int N, double delt
     const unsigned long long mask2 = (delta != 0.0) ? __ballot(lane < N) : __ballot(lane < N && s2);
     const bool big = uniform_i(big_in ? 1 : 0) != 0;
     int status = BLUEST_EVAL_OK;
-    double V = 0.0, vmine = 0.0;
+    double V = 0.0, vfill = 0.0, xpos = 0.0;
+    int xrow = -1;
+    unsigned long long xmask = 0ull;
+    bool have_x = false;
     if (!big) {
         status = BLUEST_EVAL_INF;
         V = INFINITY;
@@ -575,69 +603,64 @@ __device__ __forceinline__ void solve_wave(SolveLds<NT> &lds, int N, double delt
         const int npass = (mask1 == mask2 || !want_v) ? 1 : 2;
         for (int pass = 0; pass < npass; pass++) {
             const unsigned long long mask = (pass == 0) ? mask1 : mask2;
-            if (pass == 1 && !(mask & 1ull)) { vmine = 0.0; break; }   // row 0 of pinv(Phi) is zero
+            if (pass == 1 && !(mask & 1ull)) break;                     // row 0 of pinv(Phi) is zero
             const int nr = __popcll(mask);
             const int npad = NT - nr;
             const int target = __ffsll((long long)mask) - 1;           // smallest sampled model, ordered LAST
-            const bool mine = lane < N && ((mask >> lane) & 1ull);
-            const int pos = (lane == target) ? NT - 1 : npad + __popcll(mask & ((1ull << lane) - 1ull)) - 1;
-            wave_lds_sync();
-            if (lane < NT) lds.model_of_pos[lane] = -1;
-            wave_lds_sync();
-            if (mine) lds.model_of_pos[pos] = lane;
-            wave_lds_sync();
-            const int rowm = (lane < NT) ? lds.model_of_pos[lane] : -1;
-            double a[NT], dv[NT];
+            // model at each position: wave-uniform scalar arithmetic on the mask (no LDS round trips), my own row's model
+            // picked up on the way
+            int colm[NT];
+            int rowm = -1;
+            unsigned long long rest = mask & (mask - 1ull);            // sampled models except the target, ascending
 #pragma unroll
             for (int c = 0; c < NT; c++) {
-                const int colm = lds.model_of_pos[c];                  // broadcast read
-                const bool real = rowm >= 0 && colm >= 0;
-                const double x = lds.phi[real ? rowm * N + colm : 0];
+                if (c == NT - 1) {
+                    colm[c] = target;
+                } else {
+                    const bool take = c >= npad;
+                    colm[c] = take ? (int)__ffsll((long long)rest) - 1 : -1;
+                    rest = take ? (rest & (rest - 1ull)) : rest;
+                }
+                rowm = (lane == c) ? colm[c] : rowm;
+            }
+            double a[NT];
+            PHASE(9);
+#pragma unroll
+            for (int c = 0; c < NT; c++) {
+                const bool real = rowm >= 0 && colm[c] >= 0;
+                const double x = lds.phi[real ? rowm * N + colm[c] : 0];
                 const double diag = (c == lane) ? 1.0 : 0.0;
                 a[c] = real ? ((c == lane) ? x + delta : x) : diag;    // pads: identity
             }
-            double last_pivot = 1.0;
+            double last_pivot = 1.0, rinv_mine = 0.0;
             int bad = 0;
-            chol_regs<NT>(a, dv, last_pivot, bad);
+            PHASE(5);
+            gj_regs<NT>(a, lane, rinv_mine, last_pivot, bad);
+            PHASE(6);
             if (uniform_i(bad)) {
                 if (status == BLUEST_EVAL_OK) status = BLUEST_EVAL_SINGULAR;
                 if (pass == 0) V = NAN;
-                vmine = NAN;
+                vfill = NAN;
+                have_x = false;
                 continue;
             }
-            if (pass == 0) V = 1.0 / last_pivot;     // = 1/L_nn^2 = (A^-1)_{target,target}
+            if (pass == 0) V = 1.0 / last_pivot;     // = (A^-1)_{target,target}
             if (want_v && pass == npass - 1) {
-                if (!(mask & 1ull)) { vmine = 0.0; continue; }
-                // x = A^-1 e_last: y = L^-1 e_last = e_last/L_nn, then L^T x = y backwards.
-                // Lane i needs column i of L below the diagonal: transpose once through LDS.
-                wave_lds_sync();
-                if (lane < NT) {
-#pragma unroll
-                    for (int c = 0; c < NT; c++) lds.lt[lane * SolveLds<NT>::LDA + c] = a[c];
-                }
-                wave_lds_sync();
-                double col[NT];
-#pragma unroll
-                for (int c = 0; c < NT; c++) {
-                    const double t = lds.lt[c * SolveLds<NT>::LDA + (lane < NT ? lane : 0)];
-                    col[c] = (c > lane) ? t : 0.0;
-                }
-                double r = (lane == NT - 1) ? dv[NT - 1] : 0.0;
-                double xmine = 0.0;
-#pragma unroll
-                for (int c = NT - 1; c >= 0; c--) {
-                    const double xc = readlane_f64(r, c) * dv[c];
-                    xmine = (lane == c) ? xc : xmine;
-                    r = fma(-col[c], xc, r);
-                }
-                wave_lds_sync();
-                lds.lt[lane] = xmine;                // x in permuted order, indexed by position
-                wave_lds_sync();
-                vmine = mine ? lds.lt[pos] : 0.0;
+                const double rl = readlane_f64(rinv_mine, NT - 1);
+                xpos = (lane == NT - 1) ? rl : -a[NT - 1] * rinv_mine * rl;   // x = A^-1 e_last at position `lane`
+                xrow = rowm;
+                xmask = mask;
+                vfill = 0.0;
+                have_x = (mask & 1ull) != 0ull;      // row 0 of pinv(Phi) is zero when model 0 is not in the support
             }
         }
     }
-    if (lane < N && want_v) v_out[lane] = vmine;
+    PHASE(7);
+    if (want_v) {   // v in model order: the support scattered from position order, zero (NaN if singular) elsewhere
+        if (lane < N && !(have_x && ((xmask >> lane) & 1ull))) v_out[lane] = vfill;
+        if (have_x && lane < NT && xrow >= 0) v_out[xrow] = xpos;
+        wave_lds_sync();
+    }
     if (lane == 0) { *var_out = V; *status_out = status; }
 }
 
@@ -861,14 +884,17 @@ __global__ __launch_bounds__(64 * FUSED_TPB) void k_solve_grad(int N, int n_out,
     __shared__ SolveLds<NT> lds;
     if (gate && *gate == 0) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    PHASE(0);
     const int64_t t0 = (int64_t)blockIdx.x * FUSED_TPB;
     const TileDesc td0 = tiles[t0];
     const int o = td0.out;
     if (tid < N) lds.amax[tid] = 0.0;
     for (int t = tid; t < N * N; t += 64 * FUSED_TPB) lds.phi[t] = 0.0;
     __syncthreads();
+    PHASE(1);
     fold_rows<NT>(lds, N, rows, o * nsym, nsym, partial, tid, 64 * FUSED_TPB);
     __syncthreads();
+    PHASE(2);
     const TileDesc td = tiles[t0 + wave];     // n_tiles is a multiple of FUSED_TPB per output (padded)
     // grad_tile reads v as v[(c*n_out + td.out)*N + model] and status[c*n_out + td.out]: point both at LDS
     const double *vl = lds.vout - (int64_t)td.out * N;
@@ -878,12 +904,14 @@ __global__ __launch_bounds__(64 * FUSED_TPB) void k_solve_grad(int N, int n_out,
         const bool big = wave_max(am) >= 0.05;
         double V = 0.0;
         int32_t st = 0;
+        PHASE(8);
         solve_wave<NT>(lds, N, delta, am > 1.0e-6, am > 0.0, big, true, &V, lds.vout, &st, lane);
         if (lane == 0) lds.status = st;
         if (td0.n_valid & (1 << 30)) {   // first workgroup of this output publishes V, status, v
             if (lane == 0) { var[o] = V; status[o] = st; }
             if (lane < N) v_ws[(int64_t)o * N + lane] = lds.vout[lane];
         }
+        PHASE(3);
     }
     // (streaming the tiles into registers BEFORE this barrier was measured slower: the 15 streaming wavefronts then sit
     // in front of wavefront 0's fold/solve loads in the CU's memory queue)
@@ -894,6 +922,7 @@ __global__ __launch_bounds__(64 * FUSED_TPB) void k_solve_grad(int N, int n_out,
         default: grad_tile_generic(td, tvals, tidx, vl, sl, N, n_out, 1, grad, 0, lane);
     }
 #undef GT
+    PHASE(4);
 }
 
 // out[c][j] = scale[j] * sum_o coef[c][o] * grad_o[c][invmap_o[j]]

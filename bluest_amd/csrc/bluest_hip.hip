@@ -41,8 +41,26 @@ __device__ long long g_phase[3][12];
 #define PHASE(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1)) \
         g_phase[blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 2 : 1)][i] = wall_clock64(); } while (0)
 extern "C" int bluest_debug_phase_times(long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(long long) * 36) == hipSuccess ? 0 : 1; }
+// kernel spans in a chain of evaluations: [step % 16][kernel][begin, end] (min / max over a sample of workgroups)
+__device__ unsigned long long g_span[16][2][2];
+__device__ int g_step;
+#define SPAN_SAMPLED() (threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x < 8 || blockIdx.x + 8 >= gridDim.x || (blockIdx.x & 31) == 0))
+#define SPAN_BEGIN(kid) const int span_step_ = g_step & 15; \
+    do { if (SPAN_SAMPLED()) atomicMin(&g_span[span_step_][kid][0], (unsigned long long)wall_clock64()); } while (0)
+#define SPAN_END(kid, bump) do { if (SPAN_SAMPLED()) atomicMax(&g_span[span_step_][kid][1], (unsigned long long)wall_clock64()); \
+        if (bump && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_step = g_step + 1; } while (0)
+extern "C" int bluest_debug_span_reset(void)
+{
+    unsigned long long h[16][2][2];
+    for (int i = 0; i < 16; i++) for (int k = 0; k < 2; k++) { h[i][k][0] = ~0ull; h[i][k][1] = 0ull; }
+    int z = 0;
+    return (hipMemcpyToSymbol(HIP_SYMBOL(g_span), h, sizeof(h)) == hipSuccess && hipMemcpyToSymbol(HIP_SYMBOL(g_step), &z, sizeof(z)) == hipSuccess) ? 0 : 1;
+}
+extern "C" int bluest_debug_span_read(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : 1; }
 #else
 #define PHASE(i)
+#define SPAN_BEGIN(kid)
+#define SPAN_END(kid, bump)
 #endif
 static int g_debug_solve = getenv("BLUEST_DEBUG_SOLVE") ? atoi(getenv("BLUEST_DEBUG_SOLVE")) : 0;  // timing experiments only
 
@@ -427,6 +445,7 @@ __global__ __launch_bounds__(256) void k_phi_chunks_shared(const double *__restr
     const int lane = threadIdx.x & 63;
     const int o0 = blockIdx.y * OB;
     if (chunk >= ncpo) return;
+    SPAN_BEGIN(0);
     const int64_t CH = (int64_t)iters * 256;
     const int64_t base = chunk * CH + lane * 4;
     for (int c = 0; c < n_cand; c++) {
@@ -462,6 +481,7 @@ __global__ __launch_bounds__(256) void k_phi_chunks_shared(const double *__restr
             if (lane == 0 && o0 + oo < n_out) partial[(int64_t)c * n_chunks + (int64_t)(o0 + oo) * ncpo + chunk] = make_double2(t, amax);
         }
     }
+    SPAN_END(0, false);
 }
 
 // ---- solve: one workgroup of 256 threads folds the chunk partials, then wavefront 0 factorises in REGISTERS ----
@@ -817,6 +837,27 @@ __device__ __forceinline__ void grad_tile(const TileDesc &td, const double *__re
     }
 }
 
+// the quadratic form of one group from a tile already in registers: q = v_g^T S v_g (packed symmetric S, K static)
+template <int K, int NE, int KU>
+__device__ __forceinline__ double tile_form(const double (&s)[NE], const int (&gi)[KU], const double *__restrict__ vc)
+{
+    double vj[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) vj[j] = vc[gi[j]];
+    double q = 0.0;
+    int e = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        double t = 0.0;
+#pragma unroll
+        for (int l = j + 1; l < K; l++) t = fma(s[e + (l - j)], vj[l], t);
+        t = fma(s[e], vj[j], 2.0 * t);
+        q = fma(vj[j], t, q);
+        e += K - j;
+    }
+    return q;
+}
+
 // generic k (13..16): entries re-read per candidate, no big register arrays
 __device__ __forceinline__ void grad_tile_generic(const TileDesc &td, const double *__restrict__ tvals,
                                                   const uint8_t *__restrict__ tidx, const double *__restrict__ v,
@@ -871,9 +912,9 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const TileDesc *__restrict__
 // partials and factorises Phi itself (redundantly with the other workgroups of the output -- ~2.5 us of one wavefront,
 // no inter-workgroup hand-off, so nothing to synchronise), then its 4 wavefronts evaluate their tiles with v read from
 // LDS.  Saves one dependent launch per evaluation.  The tile list is padded so that no workgroup straddles two outputs.
-#define FUSED_TPB 16   // tiles (= wavefronts) per workgroup of the fused kernel
+#define FUSED_TPB 15   // tiles per workgroup of the fused kernel: wavefront 0 solves, wavefronts 1..15 own one tile each
 template <int NT, int KU>
-__global__ __launch_bounds__(64 * FUSED_TPB) void k_solve_grad(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
+__global__ __launch_bounds__(64 * (FUSED_TPB + 1)) void k_solve_grad(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
                                                     const double2 *__restrict__ partial, double delta,
                                                     const TileDesc *__restrict__ tiles, int64_t n_tiles,
                                                     const double *__restrict__ tvals, const uint8_t *__restrict__ tidx,
@@ -881,24 +922,28 @@ __global__ __launch_bounds__(64 * FUSED_TPB) void k_solve_grad(int N, int n_out,
                                                     int32_t *__restrict__ status, double *__restrict__ grad,
                                                     const int32_t *__restrict__ gate)
 {
+    constexpr int NTHREADS = 64 * (FUSED_TPB + 1);
+    constexpr int NE = KU * (KU + 1) / 2;
     __shared__ SolveLds<NT> lds;
     if (gate && *gate == 0) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    SPAN_BEGIN(1);
     PHASE(0);
     const int64_t t0 = (int64_t)blockIdx.x * FUSED_TPB;
     const TileDesc td0 = tiles[t0];
     const int o = td0.out;
     if (tid < N) lds.amax[tid] = 0.0;
-    for (int t = tid; t < N * N; t += 64 * FUSED_TPB) lds.phi[t] = 0.0;
+    for (int t = tid; t < N * N; t += NTHREADS) lds.phi[t] = 0.0;
     __syncthreads();
     PHASE(1);
-    fold_rows<NT>(lds, N, rows, o * nsym, nsym, partial, tid, 64 * FUSED_TPB);
+    fold_rows<NT>(lds, N, rows, o * nsym, nsym, partial, tid, NTHREADS);
     __syncthreads();
     PHASE(2);
-    const TileDesc td = tiles[t0 + wave];     // n_tiles is a multiple of FUSED_TPB per output (padded)
-    // grad_tile reads v as v[(c*n_out + td.out)*N + model] and status[c*n_out + td.out]: point both at LDS
-    const double *vl = lds.vout - (int64_t)td.out * N;
-    const int32_t *sl = &lds.status - td.out;
+    // the list is padded to a multiple of FUSED_TPB tiles per output, so every tile of this workgroup belongs to output o
+    const TileDesc td = tiles[t0 + (wave > 0 ? wave - 1 : 0)];
+    const int k = td.k;
+    double s[NE];
+    int gi[KU];
     if (wave == 0) {
         const double am = (lane < N) ? lds.amax[lane] : 0.0;
         const bool big = wave_max(am) >= 0.05;
@@ -912,17 +957,34 @@ __global__ __launch_bounds__(64 * FUSED_TPB) void k_solve_grad(int N, int n_out,
             if (lane < N) v_ws[(int64_t)o * N + lane] = lds.vout[lane];
         }
         PHASE(3);
+    } else if (k <= KU) {
+        // stream the tile into registers while wavefront 0 factorises (after the fold, so these loads do not queue in front of it)
+        const double *vals = tvals + td.val_off + lane;
+        const uint8_t *idx = tidx + td.idx_off + lane;
+        const int ne = k * (k + 1) / 2;
+#pragma unroll
+        for (int j = 0; j < KU; j++) if (j < k) gi[j] = idx[j * 64];
+#pragma unroll
+        for (int e = 0; e < NE; e++) if (e < ne) s[e] = vals[e * 64];
     }
-    // (streaming the tiles into registers BEFORE this barrier was measured slower: the 15 streaming wavefronts then sit
-    // in front of wavefront 0's fold/solve loads in the CU's memory queue)
     __syncthreads();
-#define GT(KK) case KK: if (KK <= KU) { grad_tile<(KK <= KU ? KK : 1)>(td, tvals, tidx, vl, sl, N, n_out, 1, grad, 0, lane); break; }
-    switch (td.k) {
+    if (wave == 0) { SPAN_END(1, true); return; }
+    const bool valid = lane < (td.n_valid & 0xffff);
+    const bool inf = lds.status == BLUEST_EVAL_INF;
+    double *gout = grad + td.grad_off + lane;
+#define GT(KK) case KK: if (KK <= KU) { const double q = tile_form<(KK <= KU ? KK : 1)>(s, gi, lds.vout); if (valid) *gout = inf ? INFINITY : -q; break; }
+    switch (k) {
         GT(1) GT(2) GT(3) GT(4) GT(5) GT(6) GT(7) GT(8) GT(9) GT(10) GT(11) GT(12)
-        default: grad_tile_generic(td, tvals, tidx, vl, sl, N, n_out, 1, grad, 0, lane);
+        default: {
+            // grad_tile reads v as v[(c*n_out + td.out)*N + model] and status[c*n_out + td.out]: point both at LDS
+            const double *vl = lds.vout - (int64_t)td.out * N;
+            const int32_t *sl = &lds.status - td.out;
+            grad_tile_generic(td, tvals, tidx, vl, sl, N, n_out, 1, grad, 0, lane);
+        }
     }
 #undef GT
     PHASE(4);
+    SPAN_END(1, false);
 }
 
 // out[c][j] = scale[j] * sum_o coef[c][o] * grad_o[c][invmap_o[j]]
@@ -2178,7 +2240,7 @@ extern "C" int bluest_plan_eval(bluest_plan_t plan, const double *m_dev, int n_c
     // 1024-thread workgroup (group sizes <= 6); larger groups keep the three-launch path
     if (grad_dev && n_cand == 1 && !g_debug_solve && kmax <= 6) {
         const dim3 grid((unsigned)(plan->n_tiles / FUSED_TPB));
-#define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * FUSED_TPB), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, \
+#define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (FUSED_TPB + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, \
                                         delta, plan->d_tiles, plan->n_tiles, plan->d_tvals, plan->d_tidx, var_dev, plan->d_v, status, grad_dev, plan->gate)
 #define LSG(NT) do { if (kmax <= 5) LSG2(NT, 5); else LSG2(NT, 6); } while (0)
         NT_DISPATCH(plan->N, LSG);

@@ -912,9 +912,13 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const TileDesc *__restrict__
 // partials and factorises Phi itself (redundantly with the other workgroups of the output -- ~2.5 us of one wavefront,
 // no inter-workgroup hand-off, so nothing to synchronise), then its 4 wavefronts evaluate their tiles with v read from
 // LDS.  Saves one dependent launch per evaluation.  The tile list is padded so that no workgroup straddles two outputs.
-#define FUSED_TPB 15   // tiles per workgroup of the fused kernel: wavefront 0 solves, wavefronts 1..15 own one tile each
+// tiles per workgroup of the fused kernel: wavefront 0 solves, wavefronts 1..TPB own one tile each.  15 (1024 threads,
+// 128 VGPRs) while the register-resident matrix (2 NT VGPRs) and tile (KU (KU+1) + KU VGPRs) fit, else 7 (512 threads, 256 VGPRs)
+__host__ __device__ constexpr int fused_tpb(int NT, int KU) { return (NT <= 26 && KU <= 8) ? 15 : 7; }
+static int pick_nt(int N) { return N <= 8 ? 8 : N <= 12 ? 12 : N <= 16 ? 16 : N <= 20 ? 20 : N <= 26 ? 26 : N <= 32 ? 32 : N <= 48 ? 48 : 64; }
+static int pick_ku(int kmax) { return kmax <= 5 ? 5 : kmax <= 6 ? 6 : kmax <= 8 ? 8 : 12; }
 template <int NT, int KU>
-__global__ __launch_bounds__(64 * (FUSED_TPB + 1)) void k_solve_grad(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
+__global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
                                                     const double2 *__restrict__ partial, double delta,
                                                     const TileDesc *__restrict__ tiles, int64_t n_tiles,
                                                     const double *__restrict__ tvals, const uint8_t *__restrict__ tidx,
@@ -922,6 +926,7 @@ __global__ __launch_bounds__(64 * (FUSED_TPB + 1)) void k_solve_grad(int N, int 
                                                     int32_t *__restrict__ status, double *__restrict__ grad,
                                                     const int32_t *__restrict__ gate)
 {
+    constexpr int FUSED_TPB = fused_tpb(NT, KU);
     constexpr int NTHREADS = 64 * (FUSED_TPB + 1);
     constexpr int NE = KU * (KU + 1) / 2;
     __shared__ SolveLds<NT> lds;
@@ -1786,6 +1791,7 @@ struct bluest_plan_s {
     int max_cand = 0;
     int iters = 1;  // chunk = 256*iters entries
     bool shared = false;  // all outputs have identical groups + mapping
+    int fused_tpb = 15;   // tiles per workgroup of k_solve_grad for this plan (tile list is padded to it per output)
     const int32_t *gate = nullptr;  // optional device word: 0 = skip the plan's kernels (bluest_plan_set_gate)
     bool always_v = false;          // compute v in every solve (device-side SPG keeps the accepted trial's v)
     int nsym = 0;
@@ -2014,6 +2020,11 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     }
 
     // ---- gradient pass: group-major tiles ------------------------------------------------------------
+    {
+        int kmax_all = 0;
+        for (const auto &od : plan->outs) kmax_all = std::max(kmax_all, od.K);
+        plan->fused_tpb = fused_tpb(pick_nt(N), pick_ku(kmax_all));
+    }
     std::vector<TileDesc> tiles;
     std::vector<double> tvals;
     std::vector<uint8_t> tidx;
@@ -2055,7 +2066,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
         // first tile of the output is flagged; the list is padded to a multiple of FUSED_TPB tiles per output with empty
         // tiles so that a workgroup of the fused solve+gradient kernel never straddles two outputs
         tiles[first_tile_of_output].n_valid |= (1 << 30);
-        while ((tiles.size() - first_tile_of_output) % FUSED_TPB) {
+        while ((tiles.size() - first_tile_of_output) % plan->fused_tpb) {
             TileDesc td;
             td.val_off = 0; td.idx_off = 0; td.grad_off = 0; td.n_valid = 0; td.k = 1; td.out = (int16_t)o;
             tiles.push_back(td);
@@ -2236,13 +2247,12 @@ extern "C" int bluest_plan_eval(bluest_plan_t plan, const double *m_dev, int n_c
     launch_chunks(plan, m_dev, n_cand, m_stride, st);
     int kmax = 0;
     for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
-    // fused solve + gradient pass (2 launches per evaluation) while the unrolled tile code fits the 128-VGPR budget of a
-    // 1024-thread workgroup (group sizes <= 6); larger groups keep the three-launch path
-    if (grad_dev && n_cand == 1 && !g_debug_solve && kmax <= 6) {
-        const dim3 grid((unsigned)(plan->n_tiles / FUSED_TPB));
-#define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (FUSED_TPB + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, \
+    // fused solve + gradient pass (2 launches per evaluation); groups larger than 12 take the generic tile code inside it
+    if (grad_dev && n_cand == 1 && !g_debug_solve) {
+        const dim3 grid((unsigned)(plan->n_tiles / plan->fused_tpb));
+#define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, \
                                         delta, plan->d_tiles, plan->n_tiles, plan->d_tvals, plan->d_tidx, var_dev, plan->d_v, status, grad_dev, plan->gate)
-#define LSG(NT) do { if (kmax <= 5) LSG2(NT, 5); else LSG2(NT, 6); } while (0)
+#define LSG(NT) do { if (kmax <= 5) LSG2(NT, 5); else if (kmax <= 6) LSG2(NT, 6); else if (kmax <= 8) LSG2(NT, 8); else LSG2(NT, 12); } while (0)
         NT_DISPATCH(plan->N, LSG);
 #undef LSG
 #undef LSG2

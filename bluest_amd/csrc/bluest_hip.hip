@@ -519,31 +519,36 @@ __device__ __forceinline__ double rsqrt_f64(double x)
     return y;
 }
 
-// fold chunk partials of rows [row_begin, row_begin+n_rows) into lds.phi / lds.amax; all threads of the block
+// fold chunk partials of rows [row_begin, row_begin+n_rows) into lds.phi / lds.amax; all threads of the block.
+// FOUR adjacent lanes share a row: lane q sums chunks q, q+4, q+8, ... (up to 8 independent loads in flight, so a row of
+// <= 32 chunks costs ONE memory round trip), then the quad combines as (s0+s1)+(s2+s3) -- a fixed order, so the result
+// is deterministic and identical in every kernel that folds.  nthreads must be a multiple of 4.
 template <int NT>
 __device__ __forceinline__ void fold_rows(SolveLds<NT> &lds, int N, const RowDesc *__restrict__ rows, int row_begin,
                                           int n_rows, const double2 *__restrict__ partial, int tid, int nthreads)
 {
-    for (int r = tid; r < n_rows; r += nthreads) {
+    const int q = tid & 3;
+    for (int r = tid >> 2; r < n_rows; r += nthreads >> 2) {
         const RowDesc rd = rows[row_begin + r];
         const double2 *p = partial + rd.first_chunk;
+        const int n = rd.n_chunks;
         double s = 0.0, am = 0.0;
-        int c = 0;
-        for (; c + 8 <= rd.n_chunks; c += 8) {   // 8 loads in flight, summed in chunk order
-            const double2 p0 = p[c], p1 = p[c + 1], p2 = p[c + 2], p3 = p[c + 3];
-            const double2 p4 = p[c + 4], p5 = p[c + 5], p6 = p[c + 6], p7 = p[c + 7];
-            s += p0.x; s += p1.x; s += p2.x; s += p3.x; s += p4.x; s += p5.x; s += p6.x; s += p7.x;
-            am = fmax(fmax(fmax(am, fmax(p0.y, p1.y)), fmax(p2.y, p3.y)), fmax(fmax(p4.y, p5.y), fmax(p6.y, p7.y)));
+        for (int c0 = q; c0 < n; c0 += 32) {
+            double2 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = (c0 + 4 * i < n) ? p[c0 + 4 * i] : make_double2(0.0, 0.0);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { s += v[i].x; am = fmax(am, v[i].y); }
         }
-        for (; c + 2 <= rd.n_chunks; c += 2) {
-            const double2 p0 = p[c], p1 = p[c + 1];
-            s += p0.x; s += p1.x;
-            am = fmax(am, fmax(p0.y, p1.y));
+        s += __shfl_xor(s, 1);
+        am = fmax(am, __shfl_xor(am, 1));
+        s += __shfl_xor(s, 2);
+        am = fmax(am, __shfl_xor(am, 2));
+        if (q == 0) {
+            lds.phi[rd.a * N + rd.b] = s;
+            lds.phi[rd.b * N + rd.a] = s;
+            if (rd.a == rd.b) lds.amax[rd.a] = am;
         }
-        if (c < rd.n_chunks) { const double2 p0 = p[c]; s += p0.x; am = fmax(am, p0.y); }
-        lds.phi[rd.a * N + rd.b] = s;
-        lds.phi[rd.b * N + rd.a] = s;
-        if (rd.a == rd.b) lds.amax[rd.a] = am;
     }
 }
 
@@ -684,10 +689,14 @@ __device__ __forceinline__ void solve_wave(SolveLds<NT> &lds, int N, double delt
     if (lane == 0) { *var_out = V; *status_out = status; }
 }
 
-// fused: fold chunk partials + solve.  grid = (n_out, n_cand), block = 256 (fold) -> wavefront 0 (solve).
+// threads of the fold + solve workgroups: 1024 (one quad per row for up to 256 rows per pass) while the register-resident
+// matrix of the solving wavefront fits the 128-VGPR budget that comes with it, else 256
+__host__ __device__ constexpr int fold_threads(int NT) { return NT <= 26 ? 1024 : 256; }
+
+// fused: fold chunk partials + solve.  grid = (n_out, n_cand), block = fold_threads (fold) -> wavefront 0 (solve).
 // want_v: bit0 = also produce v (gradient wanted); bit1 / bit2 = timing diagnostics (fold only / solve twice).
 template <int NT>
-__global__ __launch_bounds__(256) void k_solve_from_chunks(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
+__global__ __launch_bounds__(fold_threads(NT)) void k_solve_from_chunks(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
                                                            const double2 *__restrict__ partial, int64_t n_chunks,
                                                            double delta, int want_v, double *__restrict__ var,
                                                            double *__restrict__ v, int32_t *__restrict__ status,
@@ -697,9 +706,9 @@ __global__ __launch_bounds__(256) void k_solve_from_chunks(int N, int n_out, con
     if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
     const int o = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
     if (tid < N) lds.amax[tid] = 0.0;
-    for (int t = tid; t < N * N; t += 256) lds.phi[t] = 0.0;
+    for (int t = tid; t < N * N; t += fold_threads(NT)) lds.phi[t] = 0.0;
     __syncthreads();
-    fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, 256);
+    fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, fold_threads(NT));
     __syncthreads();
     if (tid >= WAVE) return;   // single wavefront from here on
     const int lane = tid;
@@ -717,20 +726,20 @@ __global__ __launch_bounds__(256) void k_solve_from_chunks(int N, int n_out, con
 
 // multi-GPU path, phase A tail: fold chunk partials into an all-reduce-able record.
 template <int NT>
-__global__ __launch_bounds__(256) void k_fold_to_record(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
+__global__ __launch_bounds__(fold_threads(NT)) void k_fold_to_record(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
                                                         const double2 *__restrict__ partial, int64_t n_chunks,
                                                         double *__restrict__ rec)
 {
     __shared__ SolveLds<NT> lds;
     const int o = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
     if (tid < N) lds.amax[tid] = 0.0;
-    for (int t = tid; t < N * N; t += 256) lds.phi[t] = 0.0;
+    for (int t = tid; t < N * N; t += fold_threads(NT)) lds.phi[t] = 0.0;
     __syncthreads();
-    fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, 256);
+    fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, fold_threads(NT));
     __syncthreads();
     const int reclen = N * N + 2 * N + 1;
     double *r = rec + ((int64_t)c * n_out + o) * reclen;
-    for (int t = tid; t < N * N; t += 256) r[t] = lds.phi[t];
+    for (int t = tid; t < N * N; t += fold_threads(NT)) r[t] = lds.phi[t];
     if (tid >= WAVE) return;
     const double am = (tid < N) ? lds.amax[tid] : 0.0;
     if (tid < N) { r[N * N + tid] = (am > 1.0e-6) ? 1.0 : 0.0; r[N * N + N + tid] = (am > 0.0) ? 1.0 : 0.0; }
@@ -2200,7 +2209,7 @@ extern "C" int bluest_plan_phi(bluest_plan_t plan, const double *m_dev, int n_ca
     hipStream_t st = (hipStream_t)stream;
     const int n_out = (int)plan->outs.size();
     launch_chunks(plan, m_dev, n_cand, m_stride, st);
-#define LFR(NT) hipLaunchKernelGGL((k_fold_to_record<NT>), dim3(n_out, n_cand), dim3(256), 0, st, plan->N, n_out, plan->d_rows, \
+#define LFR(NT) hipLaunchKernelGGL((k_fold_to_record<NT>), dim3(n_out, n_cand), dim3(fold_threads(NT)), 0, st, plan->N, n_out, plan->d_rows, \
                                    plan->nsym, plan->d_partial, plan->n_chunks, phi_dev)
     NT_DISPATCH(plan->N, LFR);
 #undef LFR
@@ -2260,7 +2269,7 @@ extern "C" int bluest_plan_eval(bluest_plan_t plan, const double *m_dev, int n_c
         return BLUEST_OK;
     }
     const int want = ((grad_dev || plan->always_v) ? 1 : 0) | g_debug_solve;
-#define LSC(NT) hipLaunchKernelGGL((k_solve_from_chunks<NT>), dim3(n_out, n_cand), dim3(256), 0, st, plan->N, n_out, plan->d_rows, \
+#define LSC(NT) hipLaunchKernelGGL((k_solve_from_chunks<NT>), dim3(n_out, n_cand), dim3(fold_threads(NT)), 0, st, plan->N, n_out, plan->d_rows, \
                                    plan->nsym, plan->d_partial, plan->n_chunks, delta, want, var_dev, plan->d_v, status, plan->gate)
     NT_DISPATCH(plan->N, LSC);
 #undef LSC

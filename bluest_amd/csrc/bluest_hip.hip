@@ -594,8 +594,13 @@ __device__ __forceinline__ void gj_regs(double (&a)[NT], int lane, double &rinv_
         rinv_mine = (lane == j) ? rinv : rinv_mine;
         if (j == NT - 1) { last_pivot = piv; break; }
         const double f = (lane == j) ? 0.0 : -a[j] * rinv;
+        // pivot row first (scalar registers), then the updates: the broadcasts do not depend on each other, so issuing
+        // them in a block hides the VALU-writes-SGPR -> VALU-reads-it wait states that a readlane/fma ping-pong pays
+        double u[NT];
 #pragma unroll
-        for (int c = j + 1; c < NT; c++) a[c] = fma(f, readlane_f64(a[c], j), a[c]);
+        for (int c = j + 1; c < NT; c++) u[c] = readlane_f64(a[c], j);
+#pragma unroll
+        for (int c = j + 1; c < NT; c++) a[c] = fma(f, u[c], a[c]);
     }
 }
 

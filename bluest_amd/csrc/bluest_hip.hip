@@ -637,22 +637,17 @@ __device__ __forceinline__ void solve_wave(SolveLds<NT> &lds, int N, double delt
             const int nr = __popcll(mask);
             const int npad = NT - nr;
             const int target = __ffsll((long long)mask) - 1;           // smallest sampled model, ordered LAST
-            // model at each position: wave-uniform scalar arithmetic on the mask (no LDS round trips), my own row's model
-            // picked up on the way
+            // model at each position = inverse of "position of each model": every lane sends (its model + 1) to its
+            // position with one ds_permute (a bijection of the 64 lanes: sampled models -> their positions, everything else ->
+            // the pad / unused positions, carrying 0), then the columns' models are lane broadcasts of the result
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            const bool mine = lane < N && ((mask >> lane) & 1ull);
+            const int jfree = lane - below;                            // rank among the lanes that are not sampled models
+            const int dest = mine ? ((lane == target) ? NT - 1 : npad + below - 1) : (jfree < npad ? jfree : NT + (jfree - npad));
+            const int rowm = __builtin_amdgcn_ds_permute(dest << 2, mine ? lane + 1 : 0) - 1;
             int colm[NT];
-            int rowm = -1;
-            unsigned long long rest = mask & (mask - 1ull);            // sampled models except the target, ascending
 #pragma unroll
-            for (int c = 0; c < NT; c++) {
-                if (c == NT - 1) {
-                    colm[c] = target;
-                } else {
-                    const bool take = c >= npad;
-                    colm[c] = take ? (int)__ffsll((long long)rest) - 1 : -1;
-                    rest = take ? (rest & (rest - 1ull)) : rest;
-                }
-                rowm = (lane == c) ? colm[c] : rowm;
-            }
+            for (int c = 0; c < NT; c++) colm[c] = __builtin_amdgcn_readlane(rowm, c);
             double a[NT];
             PHASE(9);
 #pragma unroll

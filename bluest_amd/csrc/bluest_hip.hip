@@ -564,11 +564,9 @@ __device__ __forceinline__ void wave_lds_sync()
 __device__ __forceinline__ int uniform_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 __device__ __forceinline__ double rcp_f64(double x)
-{   // v_rcp_f64 seed + Newton steps (y <- y + y*(1 - x y)): full double accuracy for normal x
+{   // v_rcp_f64 seed + two Newton steps (y <- y + y*(1 - x y)), the refinement the compiler's own f64 division uses
     double y = __builtin_amdgcn_rcp(x);
     double e = fma(-x, y, 1.0);
-    y = fma(y, e, y);
-    e = fma(-x, y, 1.0);
     y = fma(y, e, y);
     e = fma(-x, y, 1.0);
     y = fma(y, e, y);
@@ -718,7 +716,7 @@ __global__ __launch_bounds__(fold_threads(NT)) void k_solve_from_chunks(int N, i
         return;
     }
     const double am = (lane < N) ? lds.amax[lane] : 0.0;
-    const bool big = wave_max(am) >= 0.05;
+    const bool big = __ballot(am >= 0.05) != 0ull;   // max |m| >= 0.05 (misc.py:464)
     const int reps = (want_v & 4) ? 2 : 1;   // diagnostics: run the solve twice
     for (int rep = 0; rep < reps; rep++)
         solve_wave<NT>(lds, N, delta, am > 1.0e-6, am > 0.0, big, (want_v & 1) != 0, var + e, v + e * N, status + e, lane);
@@ -929,7 +927,7 @@ static int pick_ku(int kmax) { return kmax <= 5 ? 5 : kmax <= 6 ? 6 : kmax <= 8 
 template <int NT, int KU>
 __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
                                                     const double2 *__restrict__ partial, double delta,
-                                                    const TileDesc *__restrict__ tiles, int64_t n_tiles,
+                                                    const TileDesc *__restrict__ tiles, int64_t n_tiles, int bpo,
                                                     const double *__restrict__ tvals, const uint8_t *__restrict__ tidx,
                                                     double *__restrict__ var, double *__restrict__ v_ws,
                                                     int32_t *__restrict__ status, double *__restrict__ grad,
@@ -944,8 +942,11 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
     SPAN_BEGIN(1);
     PHASE(0);
     const int64_t t0 = (int64_t)blockIdx.x * FUSED_TPB;
-    const TileDesc td0 = tiles[t0];
-    const int o = td0.out;
+    // which output, and am I its first workgroup: arithmetic when every output has the same number of workgroups (bpo > 0,
+    // the usual case), else from the first tile's descriptor (one more dependent load in front of the fold)
+    int o, first;
+    if (bpo > 0) { o = blockIdx.x / bpo; first = (blockIdx.x % bpo) == 0; }
+    else { const TileDesc td0 = tiles[t0]; o = td0.out; first = (td0.n_valid >> 30) & 1; }
     if (tid < N) lds.amax[tid] = 0.0;
     for (int t = tid; t < N * N; t += NTHREADS) lds.phi[t] = 0.0;
     __syncthreads();
@@ -960,13 +961,13 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
     int gi[KU];
     if (wave == 0) {
         const double am = (lane < N) ? lds.amax[lane] : 0.0;
-        const bool big = wave_max(am) >= 0.05;
+        const bool big = __ballot(am >= 0.05) != 0ull;   // max |m| >= 0.05 (misc.py:464)
         double V = 0.0;
         int32_t st = 0;
         PHASE(8);
         solve_wave<NT>(lds, N, delta, am > 1.0e-6, am > 0.0, big, true, &V, lds.vout, &st, lane);
         if (lane == 0) lds.status = st;
-        if (td0.n_valid & (1 << 30)) {   // first workgroup of this output publishes V, status, v
+        if (first) {   // first workgroup of this output publishes V, status, v
             if (lane == 0) { var[o] = V; status[o] = st; }
             if (lane < N) v_ws[(int64_t)o * N + lane] = lds.vout[lane];
         }
@@ -1800,6 +1801,7 @@ struct bluest_plan_s {
     int max_cand = 0;
     int iters = 1;  // chunk = 256*iters entries
     bool shared = false;  // all outputs have identical groups + mapping
+    int fused_bpo = 0;    // workgroups of k_solve_grad per output when that is the same for every output, else 0
     int fused_tpb = 15;   // tiles per workgroup of k_solve_grad for this plan (tile list is padded to it per output)
     const int32_t *gate = nullptr;  // optional device word: 0 = skip the plan's kernels (bluest_plan_set_gate)
     bool always_v = false;          // compute v in every solve (device-side SPG keeps the accepted trial's v)
@@ -2080,6 +2082,9 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
             td.val_off = 0; td.idx_off = 0; td.grad_off = 0; td.n_valid = 0; td.k = 1; td.out = (int16_t)o;
             tiles.push_back(td);
         }
+        const int bpo = (int)((tiles.size() - first_tile_of_output) / plan->fused_tpb);
+        if (o == 0) plan->fused_bpo = bpo;
+        else if (plan->fused_bpo != bpo) plan->fused_bpo = 0;
         grad_len += od.L_o;
     }
     plan->grad_len = grad_len;
@@ -2260,7 +2265,7 @@ extern "C" int bluest_plan_eval(bluest_plan_t plan, const double *m_dev, int n_c
     if (grad_dev && n_cand == 1 && !g_debug_solve) {
         const dim3 grid((unsigned)(plan->n_tiles / plan->fused_tpb));
 #define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, \
-                                        delta, plan->d_tiles, plan->n_tiles, plan->d_tvals, plan->d_tidx, var_dev, plan->d_v, status, grad_dev, plan->gate)
+                                        delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->d_tvals, plan->d_tidx, var_dev, plan->d_v, status, grad_dev, plan->gate)
 #define LSG(NT) do { if (kmax <= 5) LSG2(NT, 5); else if (kmax <= 6) LSG2(NT, 6); else if (kmax <= 8) LSG2(NT, 8); else LSG2(NT, 12); } while (0)
         NT_DISPATCH(plan->N, LSG);
 #undef LSG

@@ -1402,11 +1402,22 @@ __global__ __launch_bounds__(SIMPLEX_BLOCK) void k_simplex(const double *__restr
 //   B (one workgroup) Michelot/Newton search for tau on (r, s) held in registers
 //   C (multi-block) p, d (and the fused first trial point), per-block partials of g.d, max|d|, #positive
 //   D (one wavefront) fold the partials -> stats, gate, convergence flag
+// Mailboxes of the single-launch projection (k_proj_fused) inside the workspace.  The workspace should be ZERO-FILLED
+// once before its first use (tag 0 is never sent, so an all-zero mailbox reads as "nothing there yet").
+struct FusedProj {
+    static constexpr int MAXB = 256;      // workgroups (<= compute units: all of them are resident at once)
+    static constexpr int MAXP = 60;       // Newton passes per search
+    static constexpr int EPOCH_STEP = 64; // tags used per launch (passes + final statistics)
+    // a mailbox = 8 x 64-bit words = four doubles, each split into two (tag << 32 | 32 payload bits) words
+    // doubles: [0, 2*MAXB*8) double-buffered pass mailboxes   [.., +MAXB*8) final-statistics mailboxes
+    static constexpr int PART = 0, FIN = 2 * MAXB * 8, DOUBLES = FIN + MAXB * 8;
+};
 struct ProjWs {            // layout of the caller-provided workspace (doubles)
     // [0, 2L): interleaved (r_i, s_i) pairs
     static __host__ __device__ int64_t part_off(int64_t L) { return 2 * L; }            // 4 doubles per block
     static __host__ __device__ int64_t tau_off(int64_t L, int nb) { return 2 * L + 4LL * nb; }   // tau, rmax
-    static __host__ __device__ int64_t total(int64_t L, int nb) { return 2 * L + 4LL * nb + 8; }
+    static __host__ __device__ int64_t sync_off(int64_t L, int nb) { return 2 * L + 4LL * nb + 16; }   // single-launch path
+    static __host__ __device__ int64_t total(int64_t L, int nb) { return sync_off(L, nb) + FusedProj::DOUBLES; }
 };
 
 __device__ __forceinline__ bool proj_idle(const double *spg_state) { return spg_state && (spg_state[SPG_DONE] != 0.0 || spg_state[SPG_FAIL] != 0.0); }
@@ -1431,11 +1442,38 @@ __global__ __launch_bounds__(1024) void k_proj_a(const double *__restrict__ x, c
     }
     const double bm = block_max(ri, sm, tid, ph);
     if (tid == 0) ws[ProjWs::part_off(L) + 4LL * blockIdx.x] = bm;
+    if (tid == 0 && blockIdx.x == 0) ws[ProjWs::tau_off(L, nb) + 8] = g ? lambda : 0.0;   // for the warm start of the search
+}
+
+// Warm start: the search is Newton's method on the convex piecewise-linear function sum_i s_i max(r_i - tau, 0) - z, which
+// converges from ANY starting point with a non-empty active set (one step lands left of the root, then it climbs
+// monotonically; active sets are nested, so "same count twice" still means "same set").  With r_i = q_i - lambda g_i and
+// q_i = 1 on the support, entry i is active iff g_i < theta := (1 - tau_abs)/lambda -- the multiplier of the simplex
+// constraint, which settles as SPG converges while lambda (the spectral step) jumps around.  So every search starts from
+// the previous theta of its kind (ws[tau_off + 4 + mode]) and typically needs 2-3 passes instead of 10-15; an unusable hint
+// (not finite, empty active set) falls back to the cold start with everything active.  Without a gradient the hint is the
+// previous absolute threshold itself.
+//   ws[tau_off + 0] tau  [+1] rmax  [+2] previous active count  [+3] converged flag  [+4..6] hints  [+7] cold-start fallback
+//   [+8] lambda of this projection (0: no gradient)  [+9] passes so far (diagnostics)  [+10] searches so far
+__device__ __forceinline__ double proj_start(const double *t, int mode, double rmax, double cold, bool &warm)
+{
+    const double lambda = t[8];
+    const double hint_abs = (lambda > 0.0) ? 1.0 - lambda * t[4 + mode] : t[4 + mode];
+    const double hint = hint_abs - rmax;
+    warm = isfinite(hint) && hint > cold && hint < 0.0;
+    return warm ? hint : cold;
+}
+__device__ __forceinline__ void proj_remember(double *t, int mode, double tau_abs, int passes)
+{
+    const double lambda = t[8];
+    t[4 + mode] = (lambda > 0.0) ? (1.0 - tau_abs) / lambda : tau_abs;
+    t[9] += (double)passes;
+    t[10] += 1.0;
 }
 
 template <int ITEMS>   // ITEMS*1024 >= L, or ITEMS == 0: stream (r, s) from the workspace in every pass
 __global__ __launch_bounds__(1024) void k_proj_b(double z, double floor, int64_t L, double *__restrict__ ws, int nb,
-                                                 const double *__restrict__ spg_state)
+                                                 const double *__restrict__ spg_state, int mode)
 {
     __shared__ ProjLds sm;
     int ph = 0;
@@ -1456,11 +1494,16 @@ __global__ __launch_bounds__(1024) void k_proj_b(double z, double floor, int64_t
             sc[k] = q.y;
         }
     }
-    double tau = (floor > 0.0) ? -z / floor : -z;
+    double *t = ws + ProjWs::tau_off(L, nb);
+    const double cold = (floor > 0.0) ? -z / floor : -z;
+    bool warm;
+    double tau = proj_start(t, mode, rmax, cold, warm);
     long long prev = -1;
+    int passes = 0;
     for (int iter = 0; iter < 300; iter++) {
         double s1 = 0.0, s0 = 0.0;
         long long cnt = 0;
+        passes++;
         if (ITEMS > 0) {
 #pragma unroll
             for (int k = 0; k < R; k++) {
@@ -1477,11 +1520,12 @@ __global__ __launch_bounds__(1024) void k_proj_b(double z, double floor, int64_t
             }
         }
         block_sum2_cnt(s1, s0, cnt, sm, tid, ph);
+        if (cnt == 0 && warm) { warm = false; tau = cold; prev = -1; continue; }   // hint right of every r_i: cold start
         if (cnt == prev || cnt == 0) break;
         prev = cnt;
         tau = (s1 - z) / s0;
     }
-    if (tid == 0) { ws[ProjWs::tau_off(L, nb)] = tau; ws[ProjWs::tau_off(L, nb) + 1] = rmax; }
+    if (tid == 0) { t[0] = tau; t[1] = rmax; proj_remember(t, mode, tau + rmax, passes); }
 }
 
 // Threshold search for vectors too long for one workgroup's registers (L > 24576): every Michelot/Newton pass is a
@@ -1490,7 +1534,7 @@ __global__ __launch_bounds__(1024) void k_proj_b(double z, double floor, int64_t
 // (single workgroup, streaming) finishes the search in the rare case the flag is still clear.
 //   ws[tau_off + 0] tau   [+1] rmax   [+2] previous active count   [+3] converged flag
 __global__ __launch_bounds__(64) void k_proj_q0(double z, double floor, int64_t L, double *__restrict__ ws, int nb,
-                                                const double *__restrict__ spg_state)
+                                                const double *__restrict__ spg_state, int mode)
 {
     if (proj_idle(spg_state)) return;
     const int lane = threadIdx.x;
@@ -1499,10 +1543,13 @@ __global__ __launch_bounds__(64) void k_proj_q0(double z, double floor, int64_t 
     rmax = wave_max(rmax);
     if (lane == 0) {
         double *t = ws + ProjWs::tau_off(L, nb);
-        t[0] = (floor > 0.0) ? -z / floor : -z;
+        const double cold = (floor > 0.0) ? -z / floor : -z;
+        bool warm;
+        t[0] = proj_start(t, mode, rmax, cold, warm);
         t[1] = rmax;
         t[2] = -1.0;
         t[3] = 0.0;
+        t[7] = warm ? cold : 0.0;   // non-zero: the cold start to fall back to if the hint's active set is empty
     }
 }
 
@@ -1530,7 +1577,8 @@ __global__ __launch_bounds__(1024) void k_proj_p(int64_t L, double *__restrict__
     }
 }
 
-__global__ __launch_bounds__(64) void k_proj_q(double z, int64_t L, double *__restrict__ ws, int nb, const double *__restrict__ spg_state)
+__global__ __launch_bounds__(64) void k_proj_q(double z, int64_t L, double *__restrict__ ws, int nb, const double *__restrict__ spg_state,
+                                               int mode)
 {
     if (proj_idle(spg_state)) return;
     double *t = ws + ProjWs::tau_off(L, nb);
@@ -1543,7 +1591,9 @@ __global__ __launch_bounds__(64) void k_proj_q(double z, int64_t L, double *__re
     }
     s1 = wave_sum(s1); s0 = wave_sum(s0); cnt = wave_sum(cnt);
     if (lane == 0) {
-        if (cnt == t[2] || cnt == 0.0) { t[3] = 1.0; return; }
+        if (cnt == 0.0 && t[7] != 0.0) { t[0] = t[7]; t[7] = 0.0; t[2] = -1.0; return; }   // unusable hint: cold start
+        t[9] += 1.0;
+        if (cnt == t[2] || cnt == 0.0) { t[3] = 1.0; proj_remember(t, mode, t[0] + t[1], 0); return; }
         t[2] = cnt;
         t[0] = (s1 - z) / s0;
     }
@@ -1551,7 +1601,7 @@ __global__ __launch_bounds__(64) void k_proj_q(double z, int64_t L, double *__re
 
 // finishing search (single workgroup, streaming) if the enqueued passes did not reach the fixed point
 __global__ __launch_bounds__(1024) void k_proj_b_finish(double z, int64_t L, double *__restrict__ ws, int nb,
-                                                        const double *__restrict__ spg_state)
+                                                        const double *__restrict__ spg_state, int mode)
 {
     __shared__ ProjLds sm;
     int ph = 0;
@@ -1560,7 +1610,7 @@ __global__ __launch_bounds__(1024) void k_proj_b_finish(double z, int64_t L, dou
     if (t[3] != 0.0) return;
     const int tid = threadIdx.x;
     const double rmax = t[1];
-    double tau = t[0];
+    double tau = t[0], cold = t[7];
     long long prev = (long long)t[2];
     const double2 *rs = reinterpret_cast<const double2 *>(ws);
     for (int iter = 0; iter < 1000; iter++) {
@@ -1572,11 +1622,12 @@ __global__ __launch_bounds__(1024) void k_proj_b_finish(double z, int64_t L, dou
             if (ri > tau) { s1 = fma(q.y, ri, s1); s0 += q.y; cnt++; }
         }
         block_sum2_cnt(s1, s0, cnt, sm, tid, ph);
+        if (cnt == 0 && cold != 0.0) { tau = cold; cold = 0.0; prev = -1; continue; }   // unusable hint: cold start
         if (cnt == prev || cnt == 0) break;
         prev = cnt;
         tau = (s1 - z) / s0;
     }
-    if (tid == 0) { t[0] = tau; t[3] = 1.0; }
+    if (tid == 0) { t[0] = tau; t[3] = 1.0; proj_remember(t, mode, tau + rmax, 100); }   // 100: the fallback ran (diagnostics)
 }
 
 __global__ __launch_bounds__(1024) void k_proj_c(const double *__restrict__ x, const double *__restrict__ g, int64_t L,
@@ -1626,6 +1677,191 @@ __global__ __launch_bounds__(64) void k_proj_d(int64_t L, const double *__restri
         if (stats) { stats[0] = gd; stats[1] = dm; stats[2] = ws[ProjWs::tau_off(L, nb)]; stats[3] = np; }
         if (enable) *enable = 1;
         if (spg_state && spg_mode == 2 && dm <= spg_state[SPG_EPS]) spg_state[SPG_DONE] = 1.0;
+    }
+}
+
+// ---- single-launch projection: A + threshold search + C + D in ONE kernel -----------------------------------------
+// nb <= (number of compute units) workgroups of 1024 threads, so every workgroup is resident and waiting on each other
+// cannot starve anybody.  Workgroups talk through MAILBOXES in HBM, with no read-modify-write atomics and no fences:
+// a message of four doubles is stored as eight 64-bit words, each word = (tag << 32 | 32 payload bits).  Aligned 64-bit
+// stores and loads are single-copy atomic, so a reader that sees the expected tag in ALL eight words has the complete
+// message of exactly this launch and pass, whatever order the words became visible in; stale or half-written mailboxes
+// simply fail the tag check and are polled again (device-coherent loads, s_sleep back-off).  Tags advance by EPOCH_STEP
+// per launch (kept in the workspace), so nothing ever has to be reset.  Every wait is bounded: after PROJ_SPIN_LIMIT polls
+// a workgroup gives up, the projection returns NaN and a sticky error flag is raised, so every wavefront terminates.
+// All workgroups fold the messages in the same fixed order, hence compute bit-identical thresholds and take identical
+// branches.  (r, s) of ITEMS entries per thread stay in registers over the whole search.
+#define PROJ_SPIN_LIMIT 400000u
+__device__ __forceinline__ void mailbox_send(double *box, unsigned int tag, double v0, double v1, double v2, double v3)
+{   // called by lanes 0..7 of one wavefront: one coalesced 64-byte store
+    const int l = threadIdx.x & 7;
+    const double v = (l < 2) ? v0 : (l < 4) ? v1 : (l < 6) ? v2 : v3;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const unsigned long long half = (l & 1) ? (bits >> 32) : (bits & 0xffffffffull);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(box) + l, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+// every thread with `active` polls its own mailbox; returns (uniformly for the workgroup) whether all of them arrived
+__device__ __forceinline__ bool mailbox_recv(const double *box, unsigned int tag, bool active, double (&v)[4])
+{
+    int ok = 1;
+    v[0] = v[1] = v[2] = v[3] = 0.0;
+    if (active) {
+        const unsigned long long *w = reinterpret_cast<const unsigned long long *>(box);
+        unsigned int spins = 0;
+        for (;;) {
+            unsigned long long q[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) q[i] = __hip_atomic_load(w + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool all = true;
+#pragma unroll
+            for (int i = 0; i < 8; i++) all = all && (unsigned int)(q[i] >> 32) == tag;
+            if (all) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[i] = __longlong_as_double((long long)((q[2 * i] & 0xffffffffull) | (q[2 * i + 1] << 32)));
+                break;
+            }
+            if (++spins > PROJ_SPIN_LIMIT) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return __syncthreads_and(ok) != 0;
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(1024) void k_proj_fused(const double *__restrict__ x, const double *__restrict__ g, double lambda,
+                                                     double z, double floor, int64_t L, double *__restrict__ ws, int nb_ws,
+                                                     double *__restrict__ p, double *__restrict__ d,
+                                                     double *__restrict__ stats, double *__restrict__ spg_state, int spg_mode,
+                                                     const double *__restrict__ scale, double *__restrict__ xnew,
+                                                     double *__restrict__ mtrial, int32_t *__restrict__ enable, int maxp)
+{
+    __shared__ ProjLds sm;
+    int ph = 0;
+    const int tid = threadIdx.x, nb = gridDim.x, b = blockIdx.x;
+    double *t = ws + ProjWs::tau_off(L, nb_ws);
+    double *sy = ws + ProjWs::sync_off(L, nb_ws);
+    if (proj_idle(spg_state) || t[12] != 0.0) {   // t[12]: sticky "a wait timed out" flag
+        if (enable && b == 0 && tid == 0) *enable = 0;
+        return;
+    }
+    const unsigned int epoch = (unsigned int)t[11];   // tags of this launch: epoch + 1 ... epoch + EPOCH_STEP
+    if (spg_state && spg_mode == 1) lambda = spg_state[SPG_LAMBDA];
+    const int mode = (spg_mode >= 0 && spg_mode <= 2) ? spg_mode : 0;
+    const double hint_raw = t[4 + mode];
+
+    // ---- A: ratios and weights into registers ----
+    double r[ITEMS], sc[ITEMS];
+    double rmax = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const int64_t i = ((int64_t)k * nb + b) * 1024 + tid;
+        r[k] = -INFINITY; sc[k] = 0.0;
+        if (i < L) {
+            const double xi = x[i];
+            sc[k] = floor > 0.0 ? fmax(xi, floor) : 1.0;
+            const double q = (floor > 0.0) ? ((xi >= floor) ? 1.0 : xi / floor) : xi;
+            r[k] = g ? fma(-lambda, g[i], q) : q;
+            rmax = fmax(rmax, r[k]);
+        }
+    }
+
+    // ---- B: warm-started Newton search for tau (see proj_start).  The search runs in coordinates shifted by the grid-wide
+    // max r (differences r_i - rmax are exact where it matters, tau stays small), but no barrier is spent on that maximum:
+    // pass 0 picks its active set with the hint in absolute coordinates (tau0 = -inf without a hint: everything active,
+    // Michelot's first step), each workgroup sums relative to ITS OWN max m_b and publishes (s1_b, s0_b, count_b, m_b);
+    // after the barrier everybody re-bases the partials to rmax = max_b m_b:  S1 = sum_b s1_b + s0_b (m_b - rmax).
+    const bool use_theta = g != nullptr && lambda > 0.0;
+    const double hint = use_theta ? 1.0 - lambda * hint_raw : hint_raw;
+    const double mb = block_max(rmax, sm, tid, ph);          // this workgroup's max r
+    bool ok = true, first = true;
+    double tau = isfinite(hint) ? hint : -INFINITY;          // pass 0: absolute; later passes: relative to rmax
+    long long prev = -1;
+    int passes = 0;
+    rmax = mb;
+    for (int iter = 0; iter < maxp; iter++) {
+        double s1 = 0.0, s0 = 0.0;
+        long long cnt = 0;
+        passes++;
+        const double ref = first ? mb : 0.0;                 // later passes: r[] is already shifted
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const bool act = r[k] > tau;
+            s1 = act ? fma(sc[k], r[k] - ref, s1) : s1;
+            s0 = act ? s0 + sc[k] : s0;
+            cnt += act ? 1 : 0;
+        }
+        block_sum2_cnt(s1, s0, cnt, sm, tid, ph);
+        const unsigned int tag = epoch + 1u + (unsigned int)iter;
+        if (tid < 8) mailbox_send(sy + FusedProj::PART + ((iter & 1) * FusedProj::MAXB + b) * 8, tag, s1, s0, (double)cnt, mb);
+        double msg[4];
+        ok = mailbox_recv(sy + FusedProj::PART + ((iter & 1) * FusedProj::MAXB + (tid < nb ? tid : 0)) * 8, tag, tid < nb, msg);
+        if (!ok) break;
+        s1 = msg[0]; s0 = msg[1]; cnt = (long long)msg[2];
+        if (first) {
+            const double m = (tid < nb) ? msg[3] : -INFINITY;
+            rmax = block_max(m, sm, tid, ph);
+            if (cnt > 0) s1 = fma(s0, m - rmax, s1);         // re-base this workgroup's partial to the grid-wide max
+        }
+        block_sum2_cnt(s1, s0, cnt, sm, tid, ph);
+        if (first) {
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++) r[k] -= rmax;
+            if (cnt == 0) {                                  // hint right of every r_i (or no entries): all-active restart
+                if (tau == -INFINITY) break;
+                tau = -INFINITY;
+                // r[] is shifted now, so the restart is an ordinary later pass
+                first = false;
+                continue;
+            }
+            first = false;
+        } else if (cnt == prev || cnt == 0) {
+            break;
+        }
+        prev = cnt;
+        tau = (s1 - z) / s0;
+    }
+    if (!ok) tau = NAN;
+
+    // ---- C: p, d, the fused first trial point; partials of g.d, max|d|, #positive ----
+    double gd = 0.0, dm = 0.0;
+    long long npos = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const int64_t i = ((int64_t)k * nb + b) * 1024 + tid;
+        if (i < L) {
+            const double pi = sc[k] * fmax(r[k] - tau, 0.0);
+            const double di = pi - x[i];
+            if (p) p[i] = pi;
+            if (d) d[i] = di;
+            if (xnew) { xnew[i] = pi; mtrial[i] = scale[i] * pi; }
+            if (g) gd = fma(g[i], di, gd);
+            dm = fmax(dm, fabs(di));
+            npos += pi > 0.0;
+        }
+    }
+    block_sum_cnt(gd, npos, sm, tid, ph);
+    dm = block_max(dm, sm, tid, ph);
+    const unsigned int ftag = epoch + (unsigned int)FusedProj::EPOCH_STEP - 1u;
+    if (tid < 8) mailbox_send(sy + FusedProj::FIN + b * 8, ftag, gd, dm, (double)npos, 0.0);
+    if (b != 0) return;
+
+    // ---- D: workgroup 0 collects everybody's statistics, remembers the hint and advances the epoch ----
+    double msg[4];
+    const bool got = mailbox_recv(sy + FusedProj::FIN + (tid < nb ? tid : 0) * 8, ftag, tid < nb, msg);
+    gd = msg[0]; dm = msg[1]; npos = (long long)msg[2];
+    block_sum_cnt(gd, npos, sm, tid, ph);
+    dm = block_max(dm, sm, tid, ph);
+    if (tid == 0) {
+        if (!ok || !got) { t[12] = 1.0; tau = NAN; gd = NAN; dm = NAN; }   // sticky: a wait timed out, results are NaN from here on
+        if (stats) { stats[0] = gd; stats[1] = dm; stats[2] = tau; stats[3] = (double)npos; }
+        if (enable) *enable = 1;
+        if (spg_state && spg_mode == 2 && dm <= spg_state[SPG_EPS]) spg_state[SPG_DONE] = 1.0;
+        t[0] = tau; t[1] = rmax;
+        if (ok && got) t[4 + mode] = use_theta ? (1.0 - (tau + rmax)) / lambda : tau + rmax;
+        t[9] += (double)passes;
+        t[10] += 1.0;
+        t[11] = (double)(epoch + (unsigned int)FusedProj::EPOCH_STEP);   // exact in a double; wraps modulo 2^32 with the cast above
     }
 }
 
@@ -2299,6 +2535,7 @@ extern "C" int bluest_plan_combine_grad(bluest_plan_t plan, const double *grad_d
 // ------------------------------------------------------------------------------------------------------
 // Part 3 host side
 // ------------------------------------------------------------------------------------------------------
+#define PROJ_PASSES 5   // enqueued multi-block Newton passes (warm-started searches need 2-3; the finishing kernel covers the rest)
 static int simplex_impl(const double *x_dev, const double *g_dev, double lambda, double z, double floor, int64_t L, double *p_dev,
                         double *d_dev, double *stats_dev, double *spg_state, int spg_mode, void *stream,
                         const double *trial_scale = nullptr, double *trial_xnew = nullptr, double *trial_m = nullptr,
@@ -2311,17 +2548,40 @@ static int simplex_impl(const double *x_dev, const double *g_dev, double lambda,
     hipStream_t st = (hipStream_t)stream;
     if (ws && L > 4096) {   // long vector: streaming parts on many CUs
         const int nb = (int)((L + 1023) / 1024);
+        {   // single launch with grid barriers while (r, s) of the whole vector fit the registers of <= #CU workgroups
+            static int ncu = 0;
+            if (!ncu) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                HIP_TRY(hipGetDevice(&dev));
+                HIP_TRY(hipGetDeviceProperties(&prop, dev));
+                ncu = prop.multiProcessorCount;
+            }
+            static int maxp = getenv("BLUEST_PROJ_MAXP") ? atoi(getenv("BLUEST_PROJ_MAXP")) : (int)FusedProj::MAXP;   // timing experiments
+            static int maxb = getenv("BLUEST_PROJ_MAXB") ? atoi(getenv("BLUEST_PROJ_MAXB")) : 64;   // 64 measured best at L = 245505 (61 -> 42 us)
+            const int nbf = std::max(1, std::min(std::min(nb, ncu), std::min(maxb, (int)FusedProj::MAXB)));
+            const int64_t items = (L + 1024LL * nbf - 1) / (1024LL * nbf);
+            if (items <= 16 && !getenv("BLUEST_PROJ_MULTI_LAUNCH")) {
+#define PF(IT) hipLaunchKernelGGL((k_proj_fused<IT>), dim3(nbf), dim3(1024), 0, st, x_dev, g_dev, lambda, z, floor, L, ws, nb, p_dev, d_dev, \
+                                  stats_dev, spg_state, spg_mode, trial_scale, trial_xnew, trial_m, trial_enable, maxp)
+                if (items <= 1) PF(1); else if (items <= 2) PF(2); else if (items <= 4) PF(4); else if (items <= 8) PF(8); else PF(16);
+#undef PF
+                HIP_TRY(hipGetLastError());
+                return BLUEST_OK;
+            }
+        }
         hipLaunchKernelGGL(k_proj_a, dim3(nb), dim3(1024), 0, st, x_dev, g_dev, lambda, floor, L, ws, nb, spg_state, spg_mode);
-#define PB(IT) hipLaunchKernelGGL((k_proj_b<IT>), dim3(1), dim3(1024), 0, st, z, floor, L, ws, nb, spg_state)
+        const int mode = (spg_mode >= 0 && spg_mode <= 2) ? spg_mode : 0;   // one warm-start slot per kind of projection
+#define PB(IT) hipLaunchKernelGGL((k_proj_b<IT>), dim3(1), dim3(1024), 0, st, z, floor, L, ws, nb, spg_state, mode)
         if (L <= 1024 * 8) PB(8);
         else if (L <= 1024 * 24) PB(24);
         else {   // long vector: multi-block Newton passes, then the (normally idle) finishing search
-            hipLaunchKernelGGL(k_proj_q0, dim3(1), dim3(64), 0, st, z, floor, L, ws, nb, spg_state);
-            for (int pass = 0; pass < 12; pass++) {
+            hipLaunchKernelGGL(k_proj_q0, dim3(1), dim3(64), 0, st, z, floor, L, ws, nb, spg_state, mode);
+            for (int pass = 0; pass < PROJ_PASSES; pass++) {
                 hipLaunchKernelGGL(k_proj_p, dim3(nb), dim3(1024), 0, st, L, ws, nb, spg_state);
-                hipLaunchKernelGGL(k_proj_q, dim3(1), dim3(64), 0, st, z, L, ws, nb, spg_state);
+                hipLaunchKernelGGL(k_proj_q, dim3(1), dim3(64), 0, st, z, L, ws, nb, spg_state, mode);
             }
-            hipLaunchKernelGGL(k_proj_b_finish, dim3(1), dim3(1024), 0, st, z, L, ws, nb, spg_state);
+            hipLaunchKernelGGL(k_proj_b_finish, dim3(1), dim3(1024), 0, st, z, L, ws, nb, spg_state, mode);
         }
 #undef PB
         hipLaunchKernelGGL(k_proj_c, dim3(nb), dim3(1024), 0, st, x_dev, g_dev, L, ws, nb, p_dev, d_dev, trial_scale, trial_xnew, trial_m,

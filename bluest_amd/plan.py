@@ -205,5 +205,5 @@ def projection_workspace(L, device):
     if key not in _WORKSPACES:
         n = ctypes.c_int64(0)
         check(_lib.lib().bluest_simplex_workspace_doubles(int(L), ctypes.byref(n)))
-        _WORKSPACES[key] = torch.empty(n.value, dtype=torch.float64, device=device)
+        _WORKSPACES[key] = torch.zeros(n.value, dtype=torch.float64, device=device)
     return _WORKSPACES[key]

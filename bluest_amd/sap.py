@@ -201,12 +201,15 @@ class SpgAllocator(object):
                 dspg = DeviceSpg(plan, scale, s, pq, floor, lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"],
                                  Hlength=prm["linesearch_history_length"], slots=prm["slots"], check_every=prm["check_every"])
                 f_prev = None
-                maxit_left = int(prm["maxit"]) // len(p_list)          # every continuation stage gets its share of the budget
-                for restart in range(int(prm["restarts"]) + 1):
+                last_stage = stage == len(p_list) - 1
+                # the earlier stages minimise a surrogate (a looser smooth max): one run to a 5x looser stall tolerance is all
+                # the warm start needs; the restarts and the full tolerance are spent on the last stage only
+                maxit_left = int(prm["maxit"]) - tot_it if last_stage else int(prm["maxit"]) // len(p_list)
+                for restart in range((int(prm["restarts"]) if last_stage else 0) + 1):
                     if maxit_left <= 0:
                         break
-                    res = dspg.run(x, eps=prm["eps"], maxit=maxit_left, max_fevals=prm["max_fevals"], rel_tol=prm["rel_tol"],
-                                   stall_window=prm["stall_window"])
+                    res = dspg.run(x, eps=prm["eps"], maxit=maxit_left, max_fevals=prm["max_fevals"],
+                                   rel_tol=prm["rel_tol"] * (1.0 if last_stage else 5.0), stall_window=prm["stall_window"])
                     x = prune_dust(res["x"])
                     res["x"] = x
                     tot_it += res["it"]

@@ -9,6 +9,7 @@ Same algorithm as bluest_amd.spg.spg with SpgAllocator's callbacks (tests/test_g
 iteration by iteration); this is what `solve(..., solver="spg")` runs by default.
 """
 import ctypes
+import gc
 
 import numpy as np
 import torch
@@ -47,6 +48,7 @@ class DeviceSpg(object):
         v = ctypes.c_void_p()
         check(self.lib.bluest_plan_v_workspace(plan._h, ctypes.byref(v), None))
         self.v_ws = v.value
+        self.graph_sets = {}          # hipGraphs per number of in-iteration line-search slots
         self.graphs = None
 
     # ---- launch sequences (captured into hipGraphs) -------------------------------------------------------------
@@ -100,8 +102,16 @@ class DeviceSpg(object):
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            fn()
+        # no cyclic garbage collection while capturing: collecting an older solver's graphs / tensors inside the capture
+        # calls hipGraphExecDestroy / hipFree on this thread and invalidates it (hipErrorStreamCaptureInvalidated)
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                fn()
+        finally:
+            if was_enabled:
+                gc.enable()
         return g
 
     # ---- host-side objective (initialisation only) ---------------------------------------------------------------
@@ -144,17 +154,23 @@ class DeviceSpg(object):
             st.copy_(torch.from_numpy(h))
             check(lib.bluest_plan_set_gate(plan._h, self.enable.data_ptr(), 1))
             try:
-                if use_graph and self.graphs is None:
-                    self.graphs = (self._capture(self._iteration), self._capture(self._slots), self._capture(self._finish),
-                                   self._capture(self._iteration_checked))
-                run_iter = self.graphs[0].replay if use_graph else self._iteration
-                run_slots = self.graphs[1].replay if use_graph else self._slots
-                run_finish = self.graphs[2].replay if use_graph else self._finish
-                run_iter_checked = self.graphs[3].replay if use_graph else self._iteration_checked
-                info, it = 1, 0
+                def bind():
+                    """launchers for the current number of slots self.T (graphs captured on first use)"""
+                    if use_graph and self.T not in self.graph_sets:
+                        self.graph_sets[self.T] = (self._capture(self._iteration), self._capture(self._slots),
+                                                   self._capture(self._finish), self._capture(self._iteration_checked))
+                    if use_graph:
+                        self.graphs = self.graph_sets[self.T]
+                        return tuple(g.replay for g in self.graphs)
+                    return self._iteration, self._slots, self._finish, self._iteration_checked
+
+                run_iter, run_slots, run_finish, run_iter_checked = bind()
+                fail_windows = []                                   # did the host have to continue a line search, per window
+                info, it, count = 1, 0, 1
                 stalled = False
                 hs = h
                 trace = [(0, 1.0)]                                  # (iteration, normalised objective) at the host checks
+                checks = [(0, 1, 1.0)]                              # (iteration, evaluations, normalised objective)
                 while True:
                     if hs[DONE] != 0.0 or gpmax <= eps:
                         info = 0
@@ -174,6 +190,7 @@ class DeviceSpg(object):
                         run_iter()
                     run_iter_checked()                          # last one also measures gpmax (sets DONE when <= eps)
                     hs = st.cpu().numpy()
+                    fail_windows.append(hs[FAIL] != 0.0)
                     while hs[FAIL] != 0.0:                       # rare: more than T trial points needed
                         if hs[ALPHA] < 1e-300 or hs[COUNT] >= max_fevals:
                             info = 2
@@ -187,9 +204,25 @@ class DeviceSpg(object):
                             hs = st.cpu().numpy()
                     if info == 2:
                         break
-                    it = int(hs[IT])
+                    it, count = int(hs[IT]), int(hs[COUNT])
                     gpmax = float(hs[GPSTATS + 1])
                     trace.append((it, float(hs[F])))
+                    checks.append((it, count, float(hs[F])))
+                    # backtracking is frequent on this problem: keep a second trial point inside the iteration graph (costs
+                    # three predicated-off launches when unused, saves the host round trip and the idle rest of the window)
+                    if self.T == 1 and sum(fail_windows[-10:]) >= 3:
+                        self.T = 2
+                        run_iter, run_slots, run_finish, run_iter_checked = bind()
+                    # line search in trouble: >= 8 trial points per iteration over at least 5 iterations (not just the first
+                    # iteration after a restart, whose re-initialised step is expected to backtrack) and nothing gained --
+                    # the iterate is stationary to rounding (typical for a restart from an already converged point)
+                    back = [c for c in checks if c[0] <= it - 5]
+                    if rel_tol > 0.0 and back:
+                        it0, count0, f0 = back[-1]
+                        if count - count0 >= 8 * (it - it0) and f0 - checks[-1][2] <= rel_tol * abs(checks[-1][2]):
+                            info = 0
+                            stalled = True
+                            break
                 hs = st.cpu().numpy()
             finally:
                 check(lib.bluest_plan_set_gate(plan._h, None, 0))

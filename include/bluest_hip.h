@@ -167,8 +167,12 @@ int bluest_plan_combine_grad(bluest_plan_t plan, const double *grad_dev, int64_t
  * stats_dev[0] = g.d, stats_dev[1] = max|d|, stats_dev[2] = tau (threshold on the ratios, after shifting by their
  * max), stats_dev[3] = number of positive entries of p.  g_dev may be NULL (then lambda is ignored: p = P(x)).
  * d_dev or p_dev may be NULL.
- * work_dev: NULL, or bluest_simplex_workspace_doubles(L) doubles of scratch; with it, vectors longer than 4096 are
- * projected by four launches whose streaming parts use many CUs (one workgroup alone moves only ~25-60 GB/s).
+ * work_dev: NULL, or bluest_simplex_workspace_doubles(L) doubles of scratch, ZERO-FILLED once (hipMemset) before its
+ * first use and then left alone between calls: with it, vectors longer than 4096 are projected by ONE launch of up to 64
+ * workgroups (one workgroup alone moves only ~25-60 GB/s) that exchange their partial sums through tagged mailboxes in
+ * the scratch, and the threshold search is warm-started from the previous call on the same scratch (typically 3 passes
+ * instead of 10-15).  The result does not depend on the hint.  Keep one scratch per stream: two projections running
+ * concurrently on the same scratch would read each other's mailboxes.
  */
 int bluest_simplex_workspace_doubles(int64_t L, int64_t *n_doubles);
 int bluest_simplex_project(const double *x_dev, const double *g_dev, double lambda, double z, double floor, int64_t L,

@@ -285,14 +285,21 @@ def test_simplex_projection_vs_oracle(gpu, oracle):
             assert np.abs(d.cpu().numpy() - (p - v)).max() <= 1e-16 * max(1.0, np.abs(v).max())
             st = stats.cpu().numpy()
             assert st[3] == (p > 0).sum() and abs(st[1] - np.abs(p - v).max()) <= 1e-15 * max(1.0, np.abs(v).max())
-    # fused step: p = P(x - lambda g), g.d
+    # fused step: p = P(x - lambda g), g.d -- through the single-launch path and through the multi-launch fallback
+    import os
     L = 21699
     xv, gv = rng.rand(L) / L, rng.randn(L)
-    for lam in (0.0, 1e-3, 1.0, 1e30):
-        want = oracle.simplex_projection(xv - lam * gv)
-        p, d, stats = simplex_project(torch.from_numpy(xv).to(dev), torch.from_numpy(gv).to(dev), lam)
-        assert np.abs(p.cpu().numpy() - want).max() < 1e-13
-        assert abs(float(stats[0]) - gv @ (want - xv)) <= 1e-12 * max(1.0, np.abs(gv).sum())
+    for multi in (False, True):
+        if multi:
+            os.environ["BLUEST_PROJ_MULTI_LAUNCH"] = "1"
+        try:
+            for lam in (0.0, 1e-3, 1.0, 1e30, 1e-3):      # the last one is warm-started from a wildly different threshold
+                want = oracle.simplex_projection(xv - lam * gv)
+                p, d, stats = simplex_project(torch.from_numpy(xv).to(dev), torch.from_numpy(gv).to(dev), lam)
+                assert np.abs(p.cpu().numpy() - want).max() < 1e-13
+                assert abs(float(stats[0]) - gv @ (want - xv)) <= 1e-12 * max(1.0, np.abs(gv).sum())
+        finally:
+            os.environ.pop("BLUEST_PROJ_MULTI_LAUNCH", None)
 
 
 def test_scaled_simplex_projection_vs_oracle(gpu, oracle):

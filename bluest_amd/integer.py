@@ -7,8 +7,7 @@ runs on the GPU (`bluest_intproj_eval`: one wavefront per candidate and output, 
 
 The candidate enumeration and the linear filters (model-0 constraint, budget, ordering) are host numpy on <= 2^20
 small integers per chunk, written to keep the reference's selection rule (including its ordering of candidates).
-`MOSAP.cleanup_solution` (mosap.py:125-210) is not ported, so its two rungs of the ladder are
-skipped.
+`MOSAP.cleanup_solution` (mosap.py:125-210) supplies the second starting point of the multi-output ladder.
 """
 import numpy as np
 import torch
@@ -225,27 +224,54 @@ def integer_projection_sap(sap, samples, budget=None, eps=None, max_model_sample
 
 
 def integer_projection_mosap(mos, samples, budget=None, eps=None, max_model_samples=None):
-    """bluest/mosap.py:212-289 without the cleanup rungs (cleanup_solution is not ported)"""
+    """bluest/mosap.py:212-289: the whole ladder -- closest integer point; the same from the cleaned-up (sparser) allocation;
+    both again with budget / tolerances relaxed by 1e-3 ... 1; finally rounding up or down"""
     if budget is None and eps is None:
         raise ValueError("Need to specify either budget or RMSE tolerance")
     if mos.verbose: print("Integer projection...")
     ss = samples.copy()
     ES, rhs = mos.get_max_sample_constraints(max_model_samples)
     args = (mos.N, mos.costs, mos.e, mos.SAPS, mos.mappings, mos.plan)
-    out, fval = best_closest_integer_solution(ss, *args, budget=budget, eps=eps, max_samples_info=(ES, rhs))
-    if np.isinf(fval):
+
+    def closest(start, b, e):
+        return best_closest_integer_solution(start, *args, budget=b, eps=e, max_samples_info=(ES, rhs))
+
+    out, fval = closest(ss, budget, eps)                                   # STEP 0
+    css = None
+    if np.isinf(fval):                                                     # STEP 1: clean up, try again
+        if mos.verbose: print("Integer projection failed. Trying to recover by cleanup...")
+        css = mos.cleanup_solution(ss)
+        out, fval = closest(css, budget, eps)
+    if np.isinf(fval):                                                     # STEP 2: relax the constraints
         for i in reversed(range(4)):
             if mos.verbose: print("WARNING! An integer solution satisfying the constraints could not be found. Increasing the tolerance/budget.\n")
             nb, ne = _increase_tolerance(budget, eps, 10. ** -i)
-            out, fval = best_closest_integer_solution(ss, *args, budget=nb, eps=ne, max_samples_info=(ES, rhs))
+            out, fval = closest(ss, nb, ne)
+            if np.isinf(fval):
+                out, fval = closest(css, nb, ne)
             if not np.isinf(fval): break
-    if np.isinf(fval):
-        # mosap.py:250-287 restricted to the un-cleaned candidates: round up if allowed, else down, else up
-        up, down = np.ceil(ss), np.floor(ss)
-        if max_model_samples is not None and not all([up @ ees <= rr for ees, rr in zip(ES, rhs)]) and \
-                all([down[mos.mappings[n]] @ mos.e[mos.mappings[n]] >= 1 for n in range(mos.n_outputs)]):
-            out = down
+    if np.isinf(fval):                                                     # STEP 3: round
+        def sampled_once(x):
+            return all([x[mos.mappings[n]] @ mos.e[mos.mappings[n]] >= 1 for n in range(mos.n_outputs)])
+
+        def within_caps(x):
+            return all([x @ ees <= rr for ees, rr in zip(ES, rhs)])
+
+        up, down, cup, cdown = np.ceil(ss), np.floor(ss), np.ceil(css), np.floor(css)
+        if eps is None: prefer_up = up @ mos.costs < cup @ mos.costs
+        else:           prefer_up = max(mos.variances(up)) < max(mos.variances(cup))
+        warn = "WARNING! An integer solution satisfying the constraints could not be found even after increasing the tolerance/budget."
+        if max_model_samples is not None and within_caps(up):
+            out, note = up, " Rounding up.\n"
+        elif max_model_samples is not None and within_caps(cup):
+            out, note = cup, " Rounding up.\n"
+        elif max_model_samples is not None and sampled_once(down):
+            out, note = down, " Rounding down to satisfy max model sample constraints.\n"
+        elif max_model_samples is not None and sampled_once(cdown):
+            out, note = cdown, " Rounding down to satisfy max model sample constraints.\n"
         else:
-            if mos.verbose: print("WARNING! An integer solution satisfying the constraints could not be found even after increasing the tolerance/budget. Rounding up.\n")
-            out = up
+            out = up if prefer_up else cup
+            note = (" Rounding up.\n" if max_model_samples is None else
+                    " and the max model sample constraints could not be satisfied. Rounding up.\n")
+        if mos.verbose: print(warn + note)
     return np.asarray(out).astype(int)

@@ -10,6 +10,7 @@ All outputs share ONE device plan: a call to variances()/variance_GH() is one Ph
 import numpy as np
 import torch
 
+from . import misc
 from .plan import EVAL_INF, EVAL_NO_MODEL0, EVAL_OK, EVAL_SINGULAR, Plan
 from .sap import BLUESTError, SAP, SpgAllocator, indicator_vectors, normalise_groups, status_to_python
 
@@ -236,6 +237,85 @@ class MOSAP(object):
                 m_h = m.cpu().numpy() if isinstance(m, torch.Tensor) else np.asarray(m, dtype=np.float64)
                 hessians.append(self.SAPS[n]._hessian(m_h[self.mappings[n]], delta))
         return variances, gradients, hessians
+
+    def get_cleanup_matrices(self, m, delta=0):
+        """bluest/mosap.py:102-111: the per-output cleanup matrices stacked, (n_outputs*N, L).  Phi of every output comes
+        from ONE launch of the shared plan; the per-group products run through the `cleanupK` kernel."""
+        m_h = np.asarray(m.cpu().numpy() if isinstance(m, torch.Tensor) else m, dtype=np.float64)
+        PHI = self.plan.phi_matrix(m_h, delta=delta)[0].cpu().numpy()
+        Xs = []
+        for n in range(self.n_outputs):
+            sap = self.SAPS[n]
+            if abs(m_h[self.mappings[n]]).max() < 0.05:
+                raise ValueError("No entry greater or equal than 1 found in m.")
+            invPHI = np.linalg.pinv(PHI[n])
+            X = np.zeros((self.N, self.L))
+            X[:, self.mappings[n]] = np.hstack([misc.cleanupK(k, sap.sizes[k], sap.groups[k - 1], sap.invcovs[k - 1], invPHI)
+                                                for k in range(1, sap.K + 1) if sap.sizes[k] > 0])
+            Xs.append(X)
+        return np.vstack(Xs)
+
+    def cleanup_solution(self, m, delta=0, tol=0):
+        """bluest/mosap.py:125-210: look for a sparser allocation with the same (max) variance and no larger cost.  Moves
+        along null vectors of the cleanup matrix restricted to the support, cheapest direction first, as far as
+        non-negativity and "model 0 of every output is still sampled once" allow; a move is kept if the variance does not
+        get worse by more than 1e-4 relative.  Every variance is one evaluation of the shared plan on the GPU; the
+        null-space is scipy's (as in the reference)."""
+        from scipy.linalg import null_space
+        m = np.array(m, dtype=np.float64)
+        N, L, w = self.N, self.L, self.costs
+        E = np.zeros((self.n_outputs, L))
+        for n in range(self.n_outputs):
+            E[n, self.mappings[n]] = self.e[self.mappings[n]]
+
+        def report(it, nnz, nullsize, V):
+            if self.verbose:
+                ns = "n/a" if nullsize < 0 else "%3d" % nullsize
+                print("It %3d: Solution cleanup, L = %d, N = %d, nnz = %d, nullspace size = %s, variance = %e." % (it, L, N, nnz, ns, V))
+
+        support = np.flatnonzero(m > tol)
+        V0 = V = max(self.variances(m, delta=delta))
+        it, nullsize = 0, -1
+        if self.verbose: print("\nSolution cleanup started!")
+        report(it, len(support), nullsize, V)
+        while len(support) > N:
+            support = np.flatnonzero(m > tol)
+            m[m < tol] = 0
+            if it > 0 and L >= 1000: report(it, len(support), nullsize, V)
+            it += 1
+            directions = null_space(self.get_cleanup_matrices(m, delta=delta)[:, support])
+            dcost = w[support] @ directions
+            directions = directions[:, dcost != 0] * -np.sign(dcost[dcost != 0])      # every direction now lowers the cost
+            dcost = -abs(dcost[dcost != 0])
+            nullsize = len(dcost)
+            if nullsize == 0:
+                break
+            Er = E[:, support]
+            sampled0 = Er @ m[support]
+            step = 0.0
+            for j in np.argsort(abs(dcost))[::-1]:
+                t = directions[:, j]
+                Et = Er @ t
+                lim0 = np.min(abs(sampled0[Et < 0] - 1) / abs(Et[Et < 0])) if (Et < 0).any() else np.inf
+                limp = np.min(m[support][t < 0] / abs(t[t < 0])) if (t < 0).any() else np.inf
+                step = max(min(lim0, limp), 0)
+                if step > 5 * tol:
+                    trial = m.copy()
+                    trial[support] += step * t
+                    V = max(self.variances(trial, delta=delta))
+                    if V < V0 or abs(V - V0) / abs(V0) < 1.0e-4:
+                        m = trial
+                        break
+                    step = 0.0
+            if step <= 5 * tol:
+                break
+            V = max(self.variances(m, delta=delta))
+        support = np.flatnonzero(m > tol)
+        m[m < tol] = 0
+        V = max(self.variances(m, delta=delta))
+        report(it, len(support), nullsize, V)
+        if self.verbose: print("Solution cleanup completed.\n")
+        return m
 
     def compute_BLUE_estimators(self, sums, samples):
         """bluest/mosap.py:113-123"""

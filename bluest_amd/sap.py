@@ -341,6 +341,16 @@ class SAP(object):
         self.variance = variance
         self.variance_GH = variance_GH
 
+    def get_cleanup_matrix(self, m, delta=0):
+        """bluest/misc.py:507-516 (`assemble_cleanup_matrix`), bluest/sap.py:137-138: X[:, i] = R_i^T C_i^-1 (pinv(Phi)[0])_g --
+        allocations that differ by a null vector of X have the same estimator variance to first order"""
+        m = np.asarray(m.cpu().numpy() if isinstance(m, torch.Tensor) else m, dtype=np.float64)
+        if abs(m).max() < 0.05:
+            raise ValueError("No entry greater or equal than 1 found in m.")
+        invPHI = np.linalg.pinv(np.asarray(self.get_phi(m, delta=delta)))
+        return np.hstack([misc.cleanupK(k, self.sizes[k], self.groups[k - 1], self.invcovs[k - 1], invPHI)
+                          for k in range(1, self.K + 1) if self.sizes[k] > 0])
+
     def _hessian(self, m, delta):
         """bluest/misc.py:497-503: K x K blocks of hessKQ, then hess += hess.T.  O(L^2) memory by construction."""
         m_h = m.cpu().numpy() if isinstance(m, torch.Tensor) else np.asarray(m, dtype=np.float64)

@@ -190,6 +190,12 @@ def gen_mosap(bluest, fname):
     Vs = mos.variances(m)
     Vgh, grads, _ = mos.variance_GH(m, nohess=True)
     out = {"n": n, "n_out": n_out, "kmax": kmax, "m": m, "Vs": np.array(Vs), "Vgh": np.array(Vgh), "e": mos.e}
+    # sparsification of an allocation without changing variance or cost (mosap.py:102-111, 125-210)
+    out["X_cleanup"] = mos.get_cleanup_matrices(m)
+    mc = mos.cleanup_solution(m.copy())
+    out["m_clean"] = mc
+    out["V_clean"] = np.array(mos.variances(mc))
+    out["costs"] = costs
     for o in range(n_out):
         out["map%d" % o] = mos.mappings[o]
         out["grad%d" % o] = grads[o]

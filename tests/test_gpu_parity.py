@@ -200,6 +200,17 @@ def test_mosap_ragged(gpu, oracle):
         assert rel_err(grads[o], G["grad%d" % o]) < TOL
         # the per-output view evaluates its own local allocation (SAPS[n].variance(m[mappings[n]]))
         assert abs(mos.SAPS[o].variance(G["m"][mos.mappings[o]]) / G["Vs"][o] - 1) < TOL
+    # solution cleanup (mosap.py:102-111, 125-210): the matrices, then the reference's sparser allocation
+    X = mos.get_cleanup_matrices(G["m"])
+    assert X.shape == G["X_cleanup"].shape and np.abs(X - G["X_cleanup"]).max() <= 1e-10 * np.abs(G["X_cleanup"]).max()
+    for o in range(n_out):
+        Xo = mos.SAPS[o].get_cleanup_matrix(G["m"][mos.mappings[o]])
+        assert np.abs(Xo - G["X_cleanup"][o * n:(o + 1) * n][:, mos.mappings[o]]).max() <= 1e-10 * np.abs(G["X_cleanup"]).max()
+    mc = mos.cleanup_solution(G["m"].copy())
+    assert (mc >= 0).all() and (mc > 0).sum() == (G["m_clean"] > 0).sum() == n * n_out
+    assert mc @ G["costs"] <= G["m"] @ G["costs"] and max(mos.variances(mc)) <= max(G["Vs"]) * (1 + 1e-4)
+    assert ((mc > 0) == (G["m_clean"] > 0)).all() and np.abs(mc - G["m_clean"]).max() <= 1e-6 * np.abs(G["m_clean"]).max()
+    assert rel_err(mos.variances(mc), G["V_clean"]) < 1e-6
 
 
 def test_hh_paper_known_answer(gpu):

@@ -8,12 +8,17 @@ workload : BASELINE.json configs[3]: n=20 models, groups up to size 5 (K_tot=216
            synthetic Wishart covariances (bluest_amd/synth.py).  A "step" evaluates one allocation vector m for
            all 8 outputs (what one SPG iteration / one MOSAP.variance_GH call does): 3 kernel launches
            (Phi chunks -> fold+solve -> gradient tiles), inputs resident in HBM, results left in HBM.
-N > 1    : one process per GPU, total work fixed => "scaling": "strong".  Two shardings of the same step:
-           --shard outputs (default when N divides n_out): the outputs are independent sample-allocation problems
-             (bluest/mosap.py:39), rank r assembles outputs r*n_out/N..; NO data-path collective;
-           --shard groups (default otherwise, e.g. single-output problems): the group set is sharded, each step
-             all-reduces the partial Phi records (n_out*(n^2+2n+1) f64) over RCCL, every rank solves redundantly
-             and evaluates the gradient of its shard (bluest_amd/dist.py).
+N > 1    : one process per GPU.  Three ways to use more than one GPU:
+           --shard candidates (default): the unit of work is the evaluation of one allocation vector; independent vectors
+             (line-search trial points, integer-projection candidates, budget / tolerance sweeps) are the partition of the
+             path that has no exchange at all, so rank r evaluates ITS OWN allocation vector for all outputs in every
+             step.  Per-GPU work fixed => "scaling": "weak", value = N * n_out * steps / time; NO data-path collective.
+           --shard outputs: ONE allocation vector, rank r assembles outputs r*n_out/N.. (the outputs are independent
+             sample-allocation problems, bluest/mosap.py:39); no data-path collective; total work fixed ("strong"), and
+             latency-bound at the headline size: one output costs 13 us, eight cost 15 us.
+           --shard groups: ONE allocation vector, the group set is sharded, each step all-reduces the partial Phi records
+             (n_out*(n^2+2n+1) f64) over RCCL, every rank solves redundantly and evaluates the gradient of its shard
+             (bluest_amd/dist.py); "strong"; for K_tot in the 10^5..10^6 range.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -142,7 +147,7 @@ def main():
     ap.add_argument("--no-sap", action="store_true", help="skip the SAP wall-clock leg (covariances -> continuous optimum)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
     ap.add_argument("--graph-steps", type=int, default=40, help="steps captured per hipGraph")
-    ap.add_argument("--shard", choices=["auto", "outputs", "groups"], default="auto")
+    ap.add_argument("--shard", choices=["auto", "candidates", "outputs", "groups"], default="auto")
     ap.add_argument("--n", type=int, default=N_MODELS)
     ap.add_argument("--kmax", type=int, default=KMAX)
     ap.add_argument("--n-out", type=int, default=N_OUT)
@@ -175,9 +180,11 @@ def main():
     L = prob["K_tot"]
     shard = args.shard
     if shard == "auto":
-        shard = "outputs" if (world > 1 and args.n_out % world == 0) else "groups"
+        shard = "candidates"
+    if shard == "outputs" and args.n_out % world:
+        raise SystemExit("--shard outputs needs n_out divisible by the number of GPUs")
     my_outputs = list(range(args.n_out))
-    if world == 1:
+    if world == 1 or shard == "candidates":
         plan = Plan(args.n, L, build_outputs(prob), max_candidates=1, device=dev)
         sharded = None
     elif shard == "outputs":
@@ -192,8 +199,8 @@ def main():
     n_out = plan.n_out
 
     # a small ring of different allocation vectors so that consecutive steps do not repeat the same input
-    rng = np.random.RandomState(2024)
-    ring = [torch.from_numpy(prob["m"][0]).to(dev)] + [torch.from_numpy(10.0 * rng.rand(L)).to(dev) for _ in range(3)]
+    rng = np.random.RandomState(2024 + (rank if shard == "candidates" else 0))   # candidates: every rank its own vectors
+    ring = [torch.from_numpy(prob["m"][0] if rank == 0 or shard != "candidates" else 10.0 * rng.rand(L)).to(dev)] + [torch.from_numpy(10.0 * rng.rand(L)).to(dev) for _ in range(3)]
     var = torch.empty((1, n_out), dtype=torch.float64, device=dev)
     grad = torch.empty((1, plan.grad_len), dtype=torch.float64, device=dev)
     status = torch.empty((1, n_out), dtype=torch.int32, device=dev)
@@ -257,7 +264,8 @@ def main():
         elapsed = float(t[0])
     assert bool((status == 0).all()) or sharded is not None
     assert bool(torch.isfinite(var).all())
-    if world > 1:
+    weak = world > 1 and shard == "candidates"
+    if world > 1 and not weak:
         # self-check outside the timed region: the sharded evaluation equals the unsharded one
         step(0)
         full = Plan(args.n, L, build_outputs(prob), max_candidates=1, device=dev)
@@ -331,14 +339,16 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "Phi-assemblies/s", "value": args.steps * args.n_out / elapsed, "unit": "assemblies/s (one output: Phi(m) over all groups -> V, grad V)",
+            "metric": "Phi-assemblies/s", "value": args.steps * args.n_out * (world if weak else 1) / elapsed, "unit": "assemblies/s (one output: Phi(m) over all groups -> V, grad V)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "collective_backend": None if world == 1 else backend,
             "config": {"workload": "n=%d models, groups up to size %d (K_tot=%d), n_out=%d, Wishart covariances; one step = V and grad V of one allocation for all outputs"
                                    % (args.n, args.kmax, L, args.n_out),
                        "n_models": args.n, "k_max": args.kmax, "K_tot": L, "n_out": args.n_out, "batch": 1,
                        "parallelism": "single GPU" if world == 1 else (
+                           "candidate axis over %d GPUs: every GPU evaluates its own allocation vector for all %d outputs per step, no data-path collective"
+                           % (world, args.n_out) if weak else
                            "outputs sharded over %d GPUs (%d per GPU), no data-path collective" % (world, len(my_outputs)) if sharded is None
                            else "group set sharded over %d GPUs, all-reduce of the Phi records per step" % world),
                        "launch": "hipGraph replay" if graph is not None else "eager"},

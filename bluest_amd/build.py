@@ -55,7 +55,7 @@ def build(force=False, verbose=False):
     if not force and up_to_date():
         build_shim(force=False, verbose=verbose)
         return LIB
-    cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-I" + os.path.join(ROOT, "include"),
            "-o", LIB, SRC] + os.environ.get("BLUEST_EXTRA_HIPCC_FLAGS", "").split()
     if verbose:
         print(" ".join(cmd))

@@ -29,6 +29,9 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <thread>
+#include <atomic>
+#include <chrono>
 
 #include "bluest_hip.h"
 
@@ -62,6 +65,19 @@ extern "C" int bluest_debug_span_read(unsigned long long *out) { return hipMemcp
 #define SPAN_BEGIN(kid)
 #define SPAN_END(kid, bump)
 #endif
+static int g_debug_timing = getenv("BLUEST_DEBUG_TIMING") ? 1 : 0;   // stderr phase times of the set-up entry points
+struct PhaseTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    const char *what;
+    explicit PhaseTimer(const char *w) : what(w) {}
+    void lap(const char *phase)
+    {
+        if (!g_debug_timing) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[bluest timing] %s: %s %.3f ms\n", what, phase, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 static int g_debug_solve = getenv("BLUEST_DEBUG_SOLVE") ? atoi(getenv("BLUEST_DEBUG_SOLVE")) : 0;  // timing experiments only
 
 static int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -2140,8 +2156,10 @@ extern "C" int bluest_plan_add_output_cov(bluest_plan_t plan, const double *C, i
                                           const int64_t *groups, const int64_t *mapping, double *invcovs_out)
 {
     OutputDesc od;
+    PhaseTimer timer("plan_add_output_cov");
     int rc = plan_add_common(plan, K, sizes, groups, mapping, od);
     if (rc) return rc;
+    timer.lap("copy groups / mapping");
     if (!C) return fail(BLUEST_ERR_ARG, "C is NULL");
     const int N = plan->N;
     int64_t ni = 0, ng = 0;
@@ -2165,6 +2183,7 @@ extern "C" int bluest_plan_add_output_cov(bluest_plan_t plan, const double *C, i
         if (rc == BLUEST_OK) e = hipMemcpy(od.invcovs.data(), dic, (size_t)ni * sizeof(double), hipMemcpyDeviceToHost);
     }
     (void)hipFree(dC); (void)hipFree(dic); (void)hipFree(dg);
+    timer.lap("device pinv round trip (malloc, H2D, kernels, D2H, free)");
     if (rc) return rc;
     HIP_TRY(e);
     if (invcovs_out) memcpy(invcovs_out, od.invcovs.data(), (size_t)ni * sizeof(double));
@@ -2182,6 +2201,20 @@ static int upload(T **dst, const std::vector<T> &src)
     return BLUEST_OK;
 }
 
+// host-side layout construction: the outputs are independent, one worker thread each (up to 16)
+template <class F>
+static void for_each_output(int n_out, F fn)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = std::max(1, std::min(n_out, (int)std::min<unsigned>(hw ? hw : 1u, 16u)));
+    if (nt <= 1) { for (int o = 0; o < n_out; o++) fn(o); return; }
+    std::atomic<int> next{0};
+    std::vector<std::thread> workers;
+    for (int t = 0; t < nt; t++)
+        workers.emplace_back([&]() { for (;;) { const int o = next++; if (o >= n_out) break; fn(o); } });
+    for (auto &w : workers) w.join();
+}
+
 extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
 {
     if (!plan) return fail(BLUEST_ERR_ARG, "plan is NULL");
@@ -2191,12 +2224,13 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     const int N = plan->N, n_out = (int)plan->outs.size();
     const int nsym = N * (N + 1) / 2;
     auto tri = [N](int a, int b) { return a * N - a * (a - 1) / 2 + (b - a); };
+    PhaseTimer timer("plan_finalize");
 
     // ---- Phi pass: destination-major symmetric CSR ------------------------------------------------
     // count entries per (output,row); pick the chunk size so that no row needs more than 64 chunks
     std::vector<std::vector<int64_t>> counts(n_out, std::vector<int64_t>(nsym, 0));
     int64_t max_row = 0;
-    for (int o = 0; o < n_out; o++) {
+    for_each_output(n_out, [&](int o) {
         const OutputDesc &od = plan->outs[o];
         int64_t go = 0;
         for (int k = 1; k <= od.K; k++) {
@@ -2207,8 +2241,10 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
             }
             go += od.sizes[k - 1] * k;
         }
+    });
+    for (int o = 0; o < n_out; o++)
         for (int r = 0; r < nsym; r++) max_row = std::max(max_row, counts[o][r]);
-    }
+    timer.lap("count");
     int iters = 1;
     while ((max_row + 256LL * iters - 1) / (256LL * iters) > 64 && iters < 1024) iters *= 2;
     const int64_t CH = 256LL * iters;
@@ -2241,7 +2277,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     std::vector<int32_t> cols((size_t)(n_chunks * CH), 0);
     {
         std::vector<int64_t> fill((size_t)n_out * nsym, 0);
-        for (int o = 0; o < n_out; o++) {
+        for_each_output(n_out, [&](int o) {
             const OutputDesc &od = plan->outs[o];
             int64_t go = 0, io = 0, li = 0;
             for (int k = 1; k <= od.K; k++) {
@@ -2258,64 +2294,58 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
                 }
                 go += od.sizes[k - 1] * k; io += od.sizes[k - 1] * k * k;
             }
-        }
-        // padding: value 0, column = the row's first column (keeps max|m| per row exact, adds nothing)
-        for (size_t r = 0; r < rows.size(); r++) {
-            const int64_t beg = (int64_t)rows[r].first_chunk * CH, end = beg + (int64_t)rows[r].n_chunks * CH;
-            for (int64_t pos = beg + fill[r]; pos < end; pos++) cols[pos] = cols[beg];
-        }
+            // padding: value 0, column = the row's first column (keeps max|m| per row exact, adds nothing)
+            for (size_t r = (size_t)o * nsym; r < (size_t)(o + 1) * nsym; r++) {
+                const int64_t beg = (int64_t)rows[r].first_chunk * CH, end = beg + (int64_t)rows[r].n_chunks * CH;
+                for (int64_t pos = beg + fill[r]; pos < end; pos++) cols[pos] = cols[beg];
+            }
+        });
     }
 
+    timer.lap("CSR alloc + fill");
     // ---- gradient pass: group-major tiles ------------------------------------------------------------
     {
         int kmax_all = 0;
         for (const auto &od : plan->outs) kmax_all = std::max(kmax_all, od.K);
         plan->fused_tpb = fused_tpb(pick_nt(N), pick_ku(kmax_all));
     }
+    // phase 1 (serial, cheap): descriptors and offsets; phase 2 (one thread per output): fill values and indices
     std::vector<TileDesc> tiles;
-    std::vector<double> tvals;
-    std::vector<uint8_t> tidx;
+    std::vector<size_t> tile_begin(n_out + 1, 0);
+    size_t n_tvals = 0, n_tidx = 0;
     plan->grad_off.assign(n_out, 0);
     int64_t grad_len = 0;
     for (int o = 0; o < n_out; o++) {
         const OutputDesc &od = plan->outs[o];
         plan->grad_off[o] = grad_len;
         const size_t first_tile_of_output = tiles.size();
-        int64_t go = 0, io = 0, li = 0;
+        tile_begin[o] = first_tile_of_output;
+        int64_t li = 0;
         for (int k = 1; k <= od.K; k++) {
             const int64_t Lk = od.sizes[k - 1];
             const int ne = k * (k + 1) / 2;
             for (int64_t t0 = 0; t0 < Lk; t0 += 64) {
                 TileDesc td;
-                td.val_off = (int64_t)tvals.size();
-                while (tidx.size() % 16) tidx.push_back(0);
-                td.idx_off = (int64_t)tidx.size();
+                td.val_off = (int64_t)n_tvals;
+                n_tidx = (n_tidx + 15) / 16 * 16;
+                td.idx_off = (int64_t)n_tidx;
                 td.grad_off = grad_len + li + t0;
                 td.n_valid = (int32_t)std::min<int64_t>(64, Lk - t0);
                 td.k = (int16_t)k; td.out = (int16_t)o;
-                tvals.resize(tvals.size() + (size_t)ne * 64, 0.0);
-                tidx.resize(tidx.size() + (size_t)k * 64, 0);
-                for (int lane = 0; lane < td.n_valid; lane++) {
-                    const int64_t i = t0 + lane;
-                    const int64_t *g = od.groups.data() + go + i * k;
-                    const double *ic = od.invcovs.data() + io + i * k * k;
-                    int e = 0;
-                    for (int j = 0; j < k; j++) {
-                        tidx[td.idx_off + j * 64 + lane] = (uint8_t)g[j];
-                        for (int l = j; l < k; l++, e++)
-                            tvals[td.val_off + e * 64 + lane] = (j == l) ? ic[j * k + j] : 0.5 * (ic[j * k + l] + ic[l * k + j]);
-                    }
-                }
+                n_tvals += (size_t)ne * 64;
+                n_tidx += (size_t)k * 64;
                 tiles.push_back(td);
             }
-            go += Lk * k; io += Lk * k * k; li += Lk;
+            li += Lk;
         }
         // first tile of the output is flagged; the list is padded to a multiple of FUSED_TPB tiles per output with empty
         // tiles so that a workgroup of the fused solve+gradient kernel never straddles two outputs
-        tiles[first_tile_of_output].n_valid |= (1 << 30);
-        while ((tiles.size() - first_tile_of_output) % plan->fused_tpb) {
+        if (tiles.size() > first_tile_of_output) tiles[first_tile_of_output].n_valid |= (1 << 30);
+        tile_begin[o + 1] = tiles.size();       // real tiles of this output end here (padding follows)
+        while ((tiles.size() - first_tile_of_output) % plan->fused_tpb || tiles.size() == first_tile_of_output) {
             TileDesc td;
-            td.val_off = 0; td.idx_off = 0; td.grad_off = 0; td.n_valid = 0; td.k = 1; td.out = (int16_t)o;
+            td.val_off = 0; td.idx_off = 0; td.grad_off = 0; td.n_valid = (tiles.size() == first_tile_of_output) ? (1 << 30) : 0;
+            td.k = 1; td.out = (int16_t)o;
             tiles.push_back(td);
         }
         const int bpo = (int)((tiles.size() - first_tile_of_output) / plan->fused_tpb);
@@ -2323,6 +2353,35 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
         else if (plan->fused_bpo != bpo) plan->fused_bpo = 0;
         grad_len += od.L_o;
     }
+    std::vector<size_t> real_end(tile_begin.begin() + 1, tile_begin.end());
+    std::vector<double> tvals(n_tvals, 0.0);
+    std::vector<uint8_t> tidx(n_tidx, 0);
+    for_each_output(n_out, [&](int o) {
+        const OutputDesc &od = plan->outs[o];
+        std::vector<int64_t> go(od.K + 1, 0), io(od.K + 1, 0);     // start of size bucket k in groups / invcovs
+        for (int k = 1; k < od.K; k++) { go[k + 1] = go[k] + od.sizes[k - 1] * k; io[k + 1] = io[k] + od.sizes[k - 1] * k * k; }
+        int64_t seen = 0;
+        int kcur = 0;
+        for (size_t t = tile_begin[o]; t < real_end[o]; t++) {
+            const TileDesc &td = tiles[t];
+            const int k = td.k;
+            if (k != kcur) { kcur = k; seen = 0; }
+            const int64_t t0 = seen;
+            const int nv = td.n_valid & 0xffff;
+            for (int lane = 0; lane < nv; lane++) {
+                const int64_t i = t0 + lane;
+                const int64_t *g = od.groups.data() + go[k] + i * k;
+                const double *ic = od.invcovs.data() + io[k] + i * k * k;
+                int e = 0;
+                for (int j = 0; j < k; j++) {
+                    tidx[td.idx_off + j * 64 + lane] = (uint8_t)g[j];
+                    for (int l = j; l < k; l++, e++)
+                        tvals[td.val_off + e * 64 + lane] = (j == l) ? ic[j * k + j] : 0.5 * (ic[j * k + l] + ic[l * k + j]);
+                }
+            }
+            seen += 64;
+        }
+    });
     plan->grad_len = grad_len;
 
     // ---- inverse maps for combine_grad ------------------------------------------------------------
@@ -2337,6 +2396,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     plan->phi_bytes = n_chunks * CH * 8 + (plan->shared ? n_chunks / n_out : n_chunks) * CH * 4 + n_chunks * 16;
     plan->grad_bytes = (int64_t)tvals.size() * 8 + (int64_t)tidx.size() + grad_len * 8;
 
+    timer.lap("tiles + inverse maps");
     int rc;
     if ((rc = upload(&plan->d_vals, vals))) return rc;
     if ((rc = upload(&plan->d_cols, cols))) return rc;
@@ -2351,6 +2411,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     HIP_TRY(hipMalloc((void **)&plan->d_v, (size_t)max_candidates * n_out * N * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&plan->d_status, (size_t)max_candidates * n_out * sizeof(int32_t)));
     plan->finalized = true;
+    timer.lap("uploads + device allocations");
     // host copies of the reference-layout inputs are no longer needed
     for (auto &od : plan->outs) { std::vector<double>().swap(od.invcovs); std::vector<int64_t>().swap(od.groups); }
     return BLUEST_OK;

@@ -537,6 +537,32 @@ def test_edge_shapes_vs_oracle(gpu, oracle):
     V, g, PHI = _oracle_eval(oracle, C64, 16, groups_big, m_big)
     Vg, gg, _ = sap_big.variance_GH(m_big, nohess=True)
     assert abs(Vg / V - 1) < 1e-9 and rel_err(gg, g) < 1e-9 and rel_err(sap_big.get_phi(m_big), PHI) < 1e-12
+    # (f) two outputs with very different group sets (28 vs 7 gradient tiles: different numbers of workgroups of the fused
+    #     solve+gradient kernel per output, so it takes the output index from the tile descriptors, not from arithmetic)
+    from bluest_amd.mosap import MOSAP
+    n = 12
+    Cs = [synth.wishart_covariance(n, o)[0] for o in range(2)]
+    g_all = synth.all_groups(n, 5)
+    mg = [[g.copy() for g in g_all], [g.copy() for g in g_all[:3]] + [np.zeros((0, 4), dtype=np.int64), np.zeros((0, 5), dtype=np.int64)]]
+    costs = np.ones(sum(len(g) for g in g_all))
+    mos = MOSAP(Cs, 5, [5, 5], [g.copy() for g in g_all], [[g.copy() for g in q] for q in mg], costs, [costs[:len(costs)], costs[:298]],
+                verbose=False)
+    m_f = 0.5 + 9 * rng.rand(len(costs))
+    Vs, grads, _ = mos.variance_GH(m_f, nohess=True)
+    for o in range(2):
+        V, g, _ = _oracle_eval(oracle, Cs[o], 5, mg[o], m_f[mos.mappings[o]])
+        assert abs(Vs[o] / V - 1) < TOL and rel_err(grads[o], g) < TOL
+    # (g) a badly conditioned information matrix (one model sampled 1e8 times more than the rest): Gauss-Jordan without
+    #     pivoting on an SPD matrix stays at cond * eps
+    C9, _ = synth.wishart_covariance(9)
+    g9 = synth.all_groups(9, 3)
+    m9 = 1e-3 + 1e-2 * rng.rand(sum(len(g) for g in g9))
+    m9[0] = 1.0e6
+    sap9 = SAP(C9, 3, [g.copy() for g in g9], np.ones(len(m9)), verbose=False)
+    V, g, PHI = _oracle_eval(oracle, C9, 3, g9, m9)
+    Vg, gg, _ = sap9.variance_GH(m9, nohess=True)
+    cond = np.linalg.cond(PHI)
+    assert cond > 1e6 and abs(Vg / V - 1) < 10 * cond * 2.2e-16 and rel_err(gg, g) < 100 * cond * 2.2e-16
     # (e) out-of-range arguments are refused by the C-ABI, not executed
     from bluest_amd import _lib
     with pytest.raises(_lib.BluestHipError):

@@ -2201,17 +2201,21 @@ static int upload(T **dst, const std::vector<T> &src)
     return BLUEST_OK;
 }
 
-// host-side layout construction: the outputs are independent, one worker thread each (up to 16)
-template <class F>
-static void for_each_output(int n_out, F fn)
+// host-side layout construction on up to 16 worker threads
+static int host_threads()
 {
     const unsigned hw = std::thread::hardware_concurrency();
-    const int nt = std::max(1, std::min(n_out, (int)std::min<unsigned>(hw ? hw : 1u, 16u)));
-    if (nt <= 1) { for (int o = 0; o < n_out; o++) fn(o); return; }
+    return (int)std::max(1u, std::min<unsigned>(hw ? hw : 1u, 16u));
+}
+template <class F>
+static void parallel_items(int n_items, F fn)
+{
+    const int nt = std::min(n_items, host_threads());
+    if (nt <= 1) { for (int i = 0; i < n_items; i++) fn(i); return; }
     std::atomic<int> next{0};
     std::vector<std::thread> workers;
     for (int t = 0; t < nt; t++)
-        workers.emplace_back([&]() { for (;;) { const int o = next++; if (o >= n_out) break; fn(o); } });
+        workers.emplace_back([&]() { for (;;) { const int i = next++; if (i >= n_items) break; fn(i); } });
     for (auto &w : workers) w.join();
 }
 
@@ -2230,18 +2234,35 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     // count entries per (output,row); pick the chunk size so that no row needs more than 64 chunks
     std::vector<std::vector<int64_t>> counts(n_out, std::vector<int64_t>(nsym, 0));
     int64_t max_row = 0;
-    for_each_output(n_out, [&](int o) {
+    // parallel counting sort: slice s of S owns a contiguous range of the output's groups; it counts its entries per row,
+    // the per-slice counts are prefix-summed into start offsets, then every slice writes its own entries -- rows keep their
+    // entries in group order whatever S is, so the layout (and every summation order on the GPU) is independent of threading
+    const int S = std::max(1, host_threads() / n_out);      // slices per output
+    std::vector<std::vector<int64_t>> slice_cnt((size_t)n_out * S, std::vector<int64_t>(nsym, 0));
+    auto for_groups_of_slice = [&](int o, int slice, auto &&body) {
         const OutputDesc &od = plan->outs[o];
-        int64_t go = 0;
+        const int64_t lo = od.L_o * slice / S, hi = od.L_o * (slice + 1) / S;
+        int64_t go = 0, io = 0, l0 = 0;
         for (int k = 1; k <= od.K; k++) {
-            for (int64_t i = 0; i < od.sizes[k - 1]; i++) {
-                const int64_t *g = od.groups.data() + go + i * k;
-                for (int j = 0; j < k; j++)
-                    for (int l = j; l < k; l++) counts[o][tri((int)std::min(g[j], g[l]), (int)std::max(g[j], g[l]))]++;
-            }
-            go += od.sizes[k - 1] * k;
+            const int64_t Lk = od.sizes[k - 1];
+            for (int64_t i = std::max<int64_t>(lo - l0, 0); i < std::min<int64_t>(hi - l0, Lk); i++)
+                body(k, od.groups.data() + go + i * k, od.invcovs.data() + io + i * k * k, l0 + i);
+            go += Lk * k; io += Lk * k * k; l0 += Lk;
         }
+    };
+    parallel_items(n_out * S, [&](int item) {
+        std::vector<int64_t> &cnt = slice_cnt[item];
+        for_groups_of_slice(item / S, item % S, [&](int k, const int64_t *g, const double *, int64_t) {
+            for (int j = 0; j < k; j++)
+                for (int l = j; l < k; l++) cnt[tri((int)std::min(g[j], g[l]), (int)std::max(g[j], g[l]))]++;
+        });
     });
+    for (int o = 0; o < n_out; o++)
+        for (int r = 0; r < nsym; r++) {
+            int64_t run = 0;
+            for (int sl = 0; sl < S; sl++) { const int64_t c = slice_cnt[(size_t)o * S + sl][r]; slice_cnt[(size_t)o * S + sl][r] = run; run += c; }
+            counts[o][r] = run;      // slice_cnt now holds each slice's start offset inside the row
+        }
     for (int o = 0; o < n_out; o++)
         for (int r = 0; r < nsym; r++) max_row = std::max(max_row, counts[o][r]);
     timer.lap("count");
@@ -2276,32 +2297,29 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     std::vector<double> vals((size_t)(n_chunks * CH), 0.0);
     std::vector<int32_t> cols((size_t)(n_chunks * CH), 0);
     {
-        std::vector<int64_t> fill((size_t)n_out * nsym, 0);
-        for_each_output(n_out, [&](int o) {
+        parallel_items(n_out * S, [&](int item) {
+            const int o = item / S;
+            std::vector<int64_t> &next = slice_cnt[item];     // start offsets, advanced as the slice writes
             const OutputDesc &od = plan->outs[o];
-            int64_t go = 0, io = 0, li = 0;
-            for (int k = 1; k <= od.K; k++) {
-                for (int64_t i = 0; i < od.sizes[k - 1]; i++, li++) {
-                    const int64_t *g = od.groups.data() + go + i * k;
-                    const double *ic = od.invcovs.data() + io + i * k * k;
-                    for (int j = 0; j < k; j++)
-                        for (int l = j; l < k; l++) {
-                            const size_t r = (size_t)o * nsym + tri((int)std::min(g[j], g[l]), (int)std::max(g[j], g[l]));
-                            const int64_t pos = (int64_t)rows[r].first_chunk * CH + fill[r]++;
-                            vals[pos] = (j == l) ? ic[j * k + j] : 0.5 * (ic[j * k + l] + ic[l * k + j]);
-                            cols[pos] = (int32_t)od.mapping[li];
-                        }
-                }
-                go += od.sizes[k - 1] * k; io += od.sizes[k - 1] * k * k;
-            }
-            // padding: value 0, column = the row's first column (keeps max|m| per row exact, adds nothing)
-            for (size_t r = (size_t)o * nsym; r < (size_t)(o + 1) * nsym; r++) {
+            for_groups_of_slice(o, item % S, [&](int k, const int64_t *g, const double *ic, int64_t li) {
+                for (int j = 0; j < k; j++)
+                    for (int l = j; l < k; l++) {
+                        const int rr = tri((int)std::min(g[j], g[l]), (int)std::max(g[j], g[l]));
+                        const int64_t pos = (int64_t)rows[(size_t)o * nsym + rr].first_chunk * CH + next[rr]++;
+                        vals[pos] = (j == l) ? ic[j * k + j] : 0.5 * (ic[j * k + l] + ic[l * k + j]);
+                        cols[pos] = (int32_t)od.mapping[li];
+                    }
+            });
+        });
+        // padding: value 0, column = the row's first column (keeps max|m| per row exact, adds nothing)
+        parallel_items(n_out, [&](int o) {
+            for (int rr = 0; rr < nsym; rr++) {
+                const size_t r = (size_t)o * nsym + rr;
                 const int64_t beg = (int64_t)rows[r].first_chunk * CH, end = beg + (int64_t)rows[r].n_chunks * CH;
-                for (int64_t pos = beg + fill[r]; pos < end; pos++) cols[pos] = cols[beg];
+                for (int64_t pos = beg + counts[o][rr]; pos < end; pos++) cols[pos] = cols[beg];
             }
         });
     }
-
     timer.lap("CSR alloc + fill");
     // ---- gradient pass: group-major tiles ------------------------------------------------------------
     {
@@ -2311,6 +2329,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     }
     // phase 1 (serial, cheap): descriptors and offsets; phase 2 (one thread per output): fill values and indices
     std::vector<TileDesc> tiles;
+    std::vector<int64_t> tile_t0;            // index of the tile's first group inside its size bucket
     std::vector<size_t> tile_begin(n_out + 1, 0);
     size_t n_tvals = 0, n_tidx = 0;
     plan->grad_off.assign(n_out, 0);
@@ -2335,6 +2354,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
                 n_tvals += (size_t)ne * 64;
                 n_tidx += (size_t)k * 64;
                 tiles.push_back(td);
+                tile_t0.push_back(t0);
             }
             li += Lk;
         }
@@ -2347,41 +2367,45 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
             td.val_off = 0; td.idx_off = 0; td.grad_off = 0; td.n_valid = (tiles.size() == first_tile_of_output) ? (1 << 30) : 0;
             td.k = 1; td.out = (int16_t)o;
             tiles.push_back(td);
+            tile_t0.push_back(0);
         }
         const int bpo = (int)((tiles.size() - first_tile_of_output) / plan->fused_tpb);
         if (o == 0) plan->fused_bpo = bpo;
         else if (plan->fused_bpo != bpo) plan->fused_bpo = 0;
         grad_len += od.L_o;
     }
-    std::vector<size_t> real_end(tile_begin.begin() + 1, tile_begin.end());
     std::vector<double> tvals(n_tvals, 0.0);
     std::vector<uint8_t> tidx(n_tidx, 0);
-    for_each_output(n_out, [&](int o) {
-        const OutputDesc &od = plan->outs[o];
-        std::vector<int64_t> go(od.K + 1, 0), io(od.K + 1, 0);     // start of size bucket k in groups / invcovs
-        for (int k = 1; k < od.K; k++) { go[k + 1] = go[k] + od.sizes[k - 1] * k; io[k + 1] = io[k] + od.sizes[k - 1] * k * k; }
-        int64_t seen = 0;
-        int kcur = 0;
-        for (size_t t = tile_begin[o]; t < real_end[o]; t++) {
-            const TileDesc &td = tiles[t];
-            const int k = td.k;
-            if (k != kcur) { kcur = k; seen = 0; }
-            const int64_t t0 = seen;
-            const int nv = td.n_valid & 0xffff;
-            for (int lane = 0; lane < nv; lane++) {
-                const int64_t i = t0 + lane;
-                const int64_t *g = od.groups.data() + go[k] + i * k;
-                const double *ic = od.invcovs.data() + io[k] + i * k * k;
-                int e = 0;
-                for (int j = 0; j < k; j++) {
-                    tidx[td.idx_off + j * 64 + lane] = (uint8_t)g[j];
-                    for (int l = j; l < k; l++, e++)
-                        tvals[td.val_off + e * 64 + lane] = (j == l) ? ic[j * k + j] : 0.5 * (ic[j * k + l] + ic[l * k + j]);
+    {
+        std::vector<std::vector<int64_t>> gofs(n_out), iofs(n_out);   // start of size bucket k in groups / invcovs
+        for (int o = 0; o < n_out; o++) {
+            const OutputDesc &od = plan->outs[o];
+            gofs[o].assign(od.K + 2, 0); iofs[o].assign(od.K + 2, 0);
+            for (int k = 1; k <= od.K; k++) { gofs[o][k + 1] = gofs[o][k] + od.sizes[k - 1] * k; iofs[o][k + 1] = iofs[o][k] + od.sizes[k - 1] * k * k; }
+        }
+        const int n_slices = host_threads() * 4;
+        const size_t nt_all = tiles.size();
+        parallel_items(n_slices, [&](int slice) {
+            for (size_t t = (size_t)slice * nt_all / n_slices; t < (size_t)(slice + 1) * nt_all / n_slices; t++) {
+                const TileDesc &td = tiles[t];
+                const int nv = td.n_valid & 0xffff;
+                if (nv == 0) continue;
+                const OutputDesc &od = plan->outs[td.out];
+                const int k = td.k;
+                for (int lane = 0; lane < nv; lane++) {
+                    const int64_t i = tile_t0[t] + lane;
+                    const int64_t *g = od.groups.data() + gofs[td.out][k] + i * k;
+                    const double *ic = od.invcovs.data() + iofs[td.out][k] + i * k * k;
+                    int e = 0;
+                    for (int j = 0; j < k; j++) {
+                        tidx[td.idx_off + j * 64 + lane] = (uint8_t)g[j];
+                        for (int l = j; l < k; l++, e++)
+                            tvals[td.val_off + e * 64 + lane] = (j == l) ? ic[j * k + j] : 0.5 * (ic[j * k + l] + ic[l * k + j]);
+                    }
                 }
             }
-            seen += 64;
-        }
-    });
+        });
+    }
     plan->grad_len = grad_len;
 
     // ---- inverse maps for combine_grad ------------------------------------------------------------

@@ -201,9 +201,12 @@ class SpgAllocator(object):
                 ok = bool((sp == EVAL_OK).all()) and float((vp[0] / v0[0]).max()) <= 1.0 + 1.0e-6
                 return xp if ok else xc
 
+            # ONE solver object for all stages: the smoothing exponent lives in the device state, so the captured hipGraphs
+            # are shared by the stages (capturing them is a visible part of a 0.1 s solve)
+            dspg = DeviceSpg(plan, scale, s, p_list[0], floor, lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"],
+                             Hlength=prm["linesearch_history_length"], slots=prm["slots"], check_every=prm["check_every"])
             for stage, pq in enumerate(p_list):
-                dspg = DeviceSpg(plan, scale, s, pq, floor, lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"],
-                                 Hlength=prm["linesearch_history_length"], slots=prm["slots"], check_every=prm["check_every"])
+                dspg.p = float(pq)
                 f_prev = None
                 last_stage = stage == len(p_list) - 1
                 # the earlier stages minimise a surrogate (a looser smooth max): one run to a 5x looser stall tolerance is all

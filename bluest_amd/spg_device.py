@@ -155,14 +155,21 @@ class DeviceSpg(object):
             check(lib.bluest_plan_set_gate(plan._h, self.enable.data_ptr(), 1))
             try:
                 def bind():
-                    """launchers for the current number of slots self.T (graphs captured on first use)"""
-                    if use_graph and self.T not in self.graph_sets:
-                        self.graph_sets[self.T] = (self._capture(self._iteration), self._capture(self._slots),
-                                                   self._capture(self._finish), self._capture(self._iteration_checked))
-                    if use_graph:
-                        self.graphs = self.graph_sets[self.T]
-                        return tuple(g.replay for g in self.graphs)
-                    return self._iteration, self._slots, self._finish, self._iteration_checked
+                    """launchers for the current number of slots self.T; every hipGraph is captured when it is first needed
+                    (the continuation graphs `slots` / `finish` only if a line search ever overflows its slots)"""
+                    if not use_graph:
+                        return self._iteration, self._slots, self._finish, self._iteration_checked
+                    gs = self.graph_sets.setdefault(self.T, {})
+
+                    def lazy(name, fn):
+                        def replay():
+                            if name not in gs:
+                                gs[name] = self._capture(fn)
+                            gs[name].replay()
+                        return replay
+                    self.graphs = gs
+                    return (lazy("iteration", self._iteration), lazy("slots", self._slots), lazy("finish", self._finish),
+                            lazy("iteration_checked", self._iteration_checked))
 
                 run_iter, run_slots, run_finish, run_iter_checked = bind()
                 fail_windows = []                                   # did the host have to continue a line search, per window

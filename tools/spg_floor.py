@@ -40,9 +40,9 @@ def timed(fn, reps):
 
 saved = d.st.clone()
 d.st[spg_device.DONE] = 1.0
-print("iteration graph, all kernels predicated off: %.1f us per replay" % timed(d.graphs[0].replay, 2000))
+print("iteration graph, all kernels predicated off: %.1f us per replay" % timed(d.graphs["iteration"].replay, 2000))
 d.st.copy_(saved)
-print("iteration graph, live:                       %.1f us per replay" % timed(d.graphs[0].replay, 2000))
+print("iteration graph, live:                       %.1f us per replay" % timed(d.graphs["iteration"].replay, 2000))
 saved = d.st.clone()
 g20 = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g20, capture_error_mode="thread_local"):

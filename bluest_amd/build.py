@@ -10,7 +10,10 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = os.path.join(HERE, "csrc", "bluest_hip.hip")
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = ["runtime.hip", "mirrors.hip", "plan.hip", "spg.hip", "intproj.hip"]     # translation units of libbluest_hip.so
+HEADERS = ["common.hpp", "solve.hpp", "plan.hpp"]
+OBJDIR = os.path.join(CSRC, "_build")
 HDR = os.path.join(ROOT, "include", "bluest_hip.h")
 LIB = os.path.join(HERE, "libbluest_hip.so")
 ARCH = "gfx950"
@@ -23,8 +26,12 @@ def hipcc():
     raise RuntimeError("hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin/hipcc)")
 
 
+def _inputs():
+    return [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [HDR]
+
+
 def up_to_date():
-    return os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(SRC), os.path.getmtime(HDR))
+    return os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(f) for f in _inputs())
 
 
 SHIM_SRC = os.path.join(HERE, "csrc", "cmisc_shim.cpp")
@@ -55,8 +62,22 @@ def build(force=False, verbose=False):
     if not force and up_to_date():
         build_shim(force=False, verbose=verbose)
         return LIB
-    cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-I" + os.path.join(ROOT, "include"),
-           "-o", LIB, SRC] + os.environ.get("BLUEST_EXTRA_HIPCC_FLAGS", "").split()
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJDIR, exist_ok=True)
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-pthread", "-I" + os.path.join(ROOT, "include"),
+             "-I" + CSRC] + os.environ.get("BLUEST_EXTRA_HIPCC_FLAGS", "").split()
+
+    def compile_one(name):
+        obj = os.path.join(OBJDIR, os.path.splitext(name)[0] + ".o")
+        cmd = [hipcc()] + flags + ["-c", os.path.join(CSRC, name), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:   # the units compile in parallel
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

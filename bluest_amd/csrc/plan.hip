@@ -1,0 +1,982 @@
+// plan.hip -- Part 2 of include/bluest_hip.h: the evaluation plan of one (multi-output) sample-allocation problem on MI355X
+// (gfx950 / CDNA4).
+//
+// What is computed (reference files bluest/*.py, bluest/cmisc.cpp; cited per function in include/bluest_hip.h):
+//   Phi_o(m) = sum_i m_i R_i^T C_i^-1 R_i      (misc.py:459-461, cmisc.cpp:25-40)
+//   V_o      = (Phi_o[idx,idx]^-1)_00          (misc.py:463-477, :490)
+//   grad_o,i = -v[g_i]^T C_i^-1 v[g_i]         (misc.py:493, cmisc.cpp:58-72), v = row 0 of pinv(Phi_o)
+// for every output o of a multi-output problem and a batch of candidate allocations m, all float64.
+//
+// Design: HBM/L2-streaming integer + f64 work with ~0.2 flop/byte, so there is no MFMA; the levers are
+// coalescing, bytes per entry, dependent round trips and launch count.
+//   * Phi pass : destination-major symmetric CSR of psi, cut into wave-sized chunks; one wavefront streams one chunk with
+//                16-byte loads and gathers m from L2; fixed-order butterfly sum => bit-reproducible (no float atomics).
+//   * solve    : per (candidate, output): quads of lanes fold the chunk partials per row -> Phi in LDS; one wavefront holds
+//                the restricted, permuted matrix in registers and eliminates by Gauss-Jordan (solve.hpp).
+//   * grad pass: group-major tiles of 64 groups, lane = group, packed-symmetric inverse stored entry-major so every
+//                wave-instruction reads 512 contiguous bytes; fused with the solve for the single-candidate evaluation
+//                (k_solve_grad: one solver wavefront, 15 tile wavefronts streaming while it factorises).
+// No CPU fallback exists in this library.
+
+#include "common.hpp"
+
+#ifdef BLUEST_PHASE_TIMING   // experiment builds only (tools/phase_timing.py): 100 MHz timestamps of one workgroup's phases
+__device__ long long g_phase[3][12];
+#define PHASE(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1)) \
+        g_phase[blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 2 : 1)][i] = wall_clock64(); } while (0)
+extern "C" int bluest_debug_phase_times(long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(long long) * 36) == hipSuccess ? 0 : 1; }
+// kernel spans in a chain of evaluations: [step % 16][kernel][begin, end] (min / max over a sample of workgroups)
+__device__ unsigned long long g_span[16][2][2];
+__device__ int g_step;
+#define SPAN_SAMPLED() (threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x < 8 || blockIdx.x + 8 >= gridDim.x || (blockIdx.x & 31) == 0))
+#define SPAN_BEGIN(kid) const int span_step_ = g_step & 15; \
+    do { if (SPAN_SAMPLED()) atomicMin(&g_span[span_step_][kid][0], (unsigned long long)wall_clock64()); } while (0)
+#define SPAN_END(kid, bump) do { if (SPAN_SAMPLED()) atomicMax(&g_span[span_step_][kid][1], (unsigned long long)wall_clock64()); \
+        if (bump && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_step = g_step + 1; } while (0)
+extern "C" int bluest_debug_span_reset(void)
+{
+    unsigned long long h[16][2][2];
+    for (int i = 0; i < 16; i++) for (int k = 0; k < 2; k++) { h[i][k][0] = ~0ull; h[i][k][1] = 0ull; }
+    int z = 0;
+    return (hipMemcpyToSymbol(HIP_SYMBOL(g_span), h, sizeof(h)) == hipSuccess && hipMemcpyToSymbol(HIP_SYMBOL(g_step), &z, sizeof(z)) == hipSuccess) ? 0 : 1;
+}
+extern "C" int bluest_debug_span_read(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : 1; }
+#else
+#define PHASE(i)
+#define SPAN_BEGIN(kid)
+#define SPAN_END(kid, bump)
+#endif
+static int g_debug_timing = getenv("BLUEST_DEBUG_TIMING") ? 1 : 0;   // stderr phase times of the set-up entry points
+struct PhaseTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    const char *what;
+    explicit PhaseTimer(const char *w) : what(w) {}
+    void lap(const char *phase)
+    {
+        if (!g_debug_timing) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[bluest timing] %s: %s %.3f ms\n", what, phase, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+static int g_debug_solve = getenv("BLUEST_DEBUG_SOLVE") ? atoi(getenv("BLUEST_DEBUG_SOLVE")) : 0;  // timing experiments only
+
+
+#include "plan.hpp"
+
+// ------------------------------------------------------------------------------------------------------
+// Part 2 -- plan kernels
+// ------------------------------------------------------------------------------------------------------
+// Phi pass: one wavefront per chunk of CH = 256*iters entries; lane l owns entries [4l, 4l+4) of each 256-block.
+__global__ __launch_bounds__(256) void k_phi_chunks(const double *__restrict__ vals, const int32_t *__restrict__ cols,
+                                                    int iters, int64_t n_chunks, const double *__restrict__ m,
+                                                    int64_t m_stride, int n_cand, double2 *__restrict__ partial,
+                                                    const int32_t *__restrict__ gate)
+{
+    if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
+    const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (chunk >= n_chunks) return;
+    const int64_t base = chunk * (int64_t)iters * 256 + lane * 4;
+    for (int c = 0; c < n_cand; c++) {
+        const double *mc = m + (int64_t)c * m_stride;
+        double s = 0.0, amax = 0.0;
+        for (int it = 0; it < iters; it++) {
+            const double2 v01 = *reinterpret_cast<const double2 *>(vals + base + it * 256);
+            const double2 v23 = *reinterpret_cast<const double2 *>(vals + base + it * 256 + 2);
+            const int4 cc = *reinterpret_cast<const int4 *>(cols + base + it * 256);
+            const double m0 = mc[cc.x], m1 = mc[cc.y], m2 = mc[cc.z], m3 = mc[cc.w];
+            s = fma(v01.x, m0, s);
+            s = fma(v01.y, m1, s);
+            s = fma(v23.x, m2, s);
+            s = fma(v23.y, m3, s);
+            amax = fmax(fmax(amax, fmax(fabs(m0), fabs(m1))), fmax(fabs(m2), fabs(m3)));
+        }
+        s = wave_sum(s);
+        amax = wave_max(amax);
+        if (lane == 0) partial[(int64_t)c * n_chunks + chunk] = make_double2(s, amax);
+    }
+}
+
+// Phi pass, shared structure: when every output has the same groups and mapping (the usual multi-output case) the
+// column indices and the gathered m are common; one wavefront streams the chunk of OB outputs and reads them once.
+// vals / partial keep the output-major chunk numbering of the general layout (chunk id = o*ncpo + c).
+template <int OB>
+__global__ __launch_bounds__(256) void k_phi_chunks_shared(const double *__restrict__ vals, const int32_t *__restrict__ cols,
+                                                           int iters, int64_t ncpo, int n_out, const double *__restrict__ m,
+                                                           int64_t m_stride, int n_cand, int64_t n_chunks,
+                                                           double2 *__restrict__ partial, const int32_t *__restrict__ gate)
+{
+    if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
+    const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int o0 = blockIdx.y * OB;
+    if (chunk >= ncpo) return;
+    SPAN_BEGIN(0);
+    const int64_t CH = (int64_t)iters * 256;
+    const int64_t base = chunk * CH + lane * 4;
+    for (int c = 0; c < n_cand; c++) {
+        const double *mc = m + (int64_t)c * m_stride;
+        double s[OB];
+#pragma unroll
+        for (int oo = 0; oo < OB; oo++) s[oo] = 0.0;
+        double amax = 0.0;
+        for (int it = 0; it < iters; it++) {
+            const int4 cc = *reinterpret_cast<const int4 *>(cols + base + it * 256);
+            double2 v01[OB], v23[OB];
+#pragma unroll
+            for (int oo = 0; oo < OB; oo++) {
+                const int o = (o0 + oo < n_out) ? o0 + oo : n_out - 1;
+                const double *vp = vals + (int64_t)o * ncpo * CH + base + it * 256;
+                v01[oo] = *reinterpret_cast<const double2 *>(vp);
+                v23[oo] = *reinterpret_cast<const double2 *>(vp + 2);
+            }
+            const double m0 = mc[cc.x], m1 = mc[cc.y], m2 = mc[cc.z], m3 = mc[cc.w];
+            amax = fmax(fmax(amax, fmax(fabs(m0), fabs(m1))), fmax(fabs(m2), fabs(m3)));
+#pragma unroll
+            for (int oo = 0; oo < OB; oo++) {
+                s[oo] = fma(v01[oo].x, m0, s[oo]);
+                s[oo] = fma(v01[oo].y, m1, s[oo]);
+                s[oo] = fma(v23[oo].x, m2, s[oo]);
+                s[oo] = fma(v23[oo].y, m3, s[oo]);
+            }
+        }
+        amax = wave_max(amax);
+#pragma unroll
+        for (int oo = 0; oo < OB; oo++) {
+            const double t = wave_sum(s[oo]);
+            if (lane == 0 && o0 + oo < n_out) partial[(int64_t)c * n_chunks + (int64_t)(o0 + oo) * ncpo + chunk] = make_double2(t, amax);
+        }
+    }
+    SPAN_END(0, false);
+}
+
+// fused: fold chunk partials + solve.  grid = (n_out, n_cand), block = fold_threads (fold) -> wavefront 0 (solve).
+// want_v: bit0 = also produce v (gradient wanted); bit1 / bit2 = timing diagnostics (fold only / solve twice).
+template <int NT>
+__global__ __launch_bounds__(fold_threads(NT)) void k_solve_from_chunks(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
+                                                           const double2 *__restrict__ partial, int64_t n_chunks,
+                                                           double delta, int want_v, double *__restrict__ var,
+                                                           double *__restrict__ v, int32_t *__restrict__ status,
+                                                           const int32_t *__restrict__ gate)
+{
+    __shared__ SolveLds<NT> lds;
+    if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
+    const int o = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+    if (tid < N) lds.amax[tid] = 0.0;
+    for (int t = tid; t < N * N; t += fold_threads(NT)) lds.phi[t] = 0.0;
+    __syncthreads();
+    fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, fold_threads(NT));
+    __syncthreads();
+    if (tid >= WAVE) return;   // single wavefront from here on
+    const int lane = tid;
+    const int64_t e = (int64_t)c * n_out + o;
+    if (want_v & 2) {   // diagnostics: fold only (timing experiments)
+        if (lane == 0) { var[e] = lds.phi[0]; status[e] = 0; }
+        return;
+    }
+    const double am = (lane < N) ? lds.amax[lane] : 0.0;
+    const bool big = __ballot(am >= 0.05) != 0ull;   // max |m| >= 0.05 (misc.py:464)
+    const int reps = (want_v & 4) ? 2 : 1;   // diagnostics: run the solve twice
+    for (int rep = 0; rep < reps; rep++)
+        solve_wave<NT>(lds, N, delta, am > 1.0e-6, am > 0.0, big, (want_v & 1) != 0, var + e, v + e * N, status + e, lane);
+}
+
+// multi-GPU path, phase A tail: fold chunk partials into an all-reduce-able record.
+template <int NT>
+__global__ __launch_bounds__(fold_threads(NT)) void k_fold_to_record(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
+                                                        const double2 *__restrict__ partial, int64_t n_chunks,
+                                                        double *__restrict__ rec)
+{
+    __shared__ SolveLds<NT> lds;
+    const int o = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+    if (tid < N) lds.amax[tid] = 0.0;
+    for (int t = tid; t < N * N; t += fold_threads(NT)) lds.phi[t] = 0.0;
+    __syncthreads();
+    fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, fold_threads(NT));
+    __syncthreads();
+    const int reclen = N * N + 2 * N + 1;
+    double *r = rec + ((int64_t)c * n_out + o) * reclen;
+    for (int t = tid; t < N * N; t += fold_threads(NT)) r[t] = lds.phi[t];
+    if (tid >= WAVE) return;
+    const double am = (tid < N) ? lds.amax[tid] : 0.0;
+    if (tid < N) { r[N * N + tid] = (am > 1.0e-6) ? 1.0 : 0.0; r[N * N + N + tid] = (am > 0.0) ? 1.0 : 0.0; }
+    const double big = wave_max(am);
+    if (tid == 0) r[N * N + 2 * N] = (big >= 0.05) ? 1.0 : 0.0;
+}
+
+// multi-GPU path, phase B: solve from an (all-reduced) record.  block = 64.
+template <int NT>
+__global__ __launch_bounds__(64) void k_solve_from_record(int N, int n_out, const double *__restrict__ rec,
+                                                          double delta, int want_v, double *__restrict__ var,
+                                                          double *__restrict__ v, int32_t *__restrict__ status)
+{
+    __shared__ SolveLds<NT> lds;
+    const int o = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
+    const int reclen = N * N + 2 * N + 1;
+    const double *r = rec + ((int64_t)c * n_out + o) * reclen;
+    for (int t = lane; t < N * N; t += WAVE) lds.phi[t] = r[t];
+    __syncthreads();
+    const bool s1 = lane < N && r[N * N + lane] > 0.0;
+    const bool s2 = lane < N && r[N * N + N + lane] > 0.0;
+    const bool big = r[N * N + 2 * N] > 0.0;
+    const int64_t e = (int64_t)c * n_out + o;
+    solve_wave<NT>(lds, N, delta, s1, s2, big, (want_v & 1) != 0, var + e, v + e * N, status + e, lane);
+}
+
+// gradient pass: one wavefront per tile, lane = group.  q = sum_j v_j (s_jj v_j + 2 sum_{l>j} s_jl v_l).
+template <int K>
+__device__ __forceinline__ void grad_tile(const TileDesc &td, const double *__restrict__ tvals,
+                                          const uint8_t *__restrict__ tidx, const double *__restrict__ v,
+                                          const int32_t *__restrict__ status, int N, int n_out, int n_cand,
+                                          double *__restrict__ grad, int64_t grad_stride, int lane)
+{
+    const double *vals = tvals + td.val_off + lane;
+    const uint8_t *idx = tidx + td.idx_off + lane;
+    int gi[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) gi[j] = idx[j * 64];
+    double s[K * (K + 1) / 2];
+#pragma unroll
+    for (int e = 0; e < K * (K + 1) / 2; e++) s[e] = vals[e * 64];
+    for (int c = 0; c < n_cand; c++) {
+        const int64_t eo = (int64_t)c * n_out + td.out;
+        const double *vc = v + eo * N;
+        double vj[K];
+#pragma unroll
+        for (int j = 0; j < K; j++) vj[j] = vc[gi[j]];
+        double q = 0.0;
+        int e = 0;
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            double t = 0.0;
+#pragma unroll
+            for (int l = j + 1; l < K; l++) t = fma(s[e + (l - j)], vj[l], t);
+            t = fma(s[e], vj[j], 2.0 * t);
+            q = fma(vj[j], t, q);
+            e += K - j;
+        }
+        if (lane < (td.n_valid & 0xffff))
+            grad[(int64_t)c * grad_stride + td.grad_off + lane] = (status[eo] == BLUEST_EVAL_INF) ? INFINITY : -q;
+    }
+}
+
+// the quadratic form of one group from a tile already in registers: q = v_g^T S v_g (packed symmetric S, K static)
+template <int K, int NE, int KU>
+__device__ __forceinline__ double tile_form(const double (&s)[NE], const int (&gi)[KU], const double *__restrict__ vc)
+{
+    double vj[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) vj[j] = vc[gi[j]];
+    double q = 0.0;
+    int e = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        double t = 0.0;
+#pragma unroll
+        for (int l = j + 1; l < K; l++) t = fma(s[e + (l - j)], vj[l], t);
+        t = fma(s[e], vj[j], 2.0 * t);
+        q = fma(vj[j], t, q);
+        e += K - j;
+    }
+    return q;
+}
+
+// generic k (13..16): entries re-read per candidate, no big register arrays
+__device__ __forceinline__ void grad_tile_generic(const TileDesc &td, const double *__restrict__ tvals,
+                                                  const uint8_t *__restrict__ tidx, const double *__restrict__ v,
+                                                  const int32_t *__restrict__ status, int N, int n_out, int n_cand,
+                                                  double *__restrict__ grad, int64_t grad_stride, int lane)
+{
+    const int K = td.k;
+    const double *vals = tvals + td.val_off + lane;
+    const uint8_t *idx = tidx + td.idx_off + lane;
+    for (int c = 0; c < n_cand; c++) {
+        const int64_t eo = (int64_t)c * n_out + td.out;
+        const double *vc = v + eo * N;
+        double q = 0.0;
+        int e = 0;
+        for (int j = 0; j < K; j++) {
+            const double vjj = vc[idx[j * 64]];
+            double t = 0.0;
+            for (int l = j + 1; l < K; l++) t = fma(vals[(e + (l - j)) * 64], vc[idx[l * 64]], t);
+            t = fma(vals[e * 64], vjj, 2.0 * t);
+            q = fma(vjj, t, q);
+            e += K - j;
+        }
+        if (lane < (td.n_valid & 0xffff))
+            grad[(int64_t)c * grad_stride + td.grad_off + lane] = (status[eo] == BLUEST_EVAL_INF) ? INFINITY : -q;
+    }
+}
+
+// KU = largest group size with a fully unrolled register path in this instantiation (the host picks the smallest
+// KU covering the plan, so the common small-k plans keep a small register footprint)
+template <int KU>
+__global__ __launch_bounds__(256) void k_grad_tiles(const TileDesc *__restrict__ tiles, int64_t n_tiles,
+                                                    const double *__restrict__ tvals,
+                                                    const uint8_t *__restrict__ tidx, const double *__restrict__ v,
+                                                    const int32_t *__restrict__ status, int N, int n_out, int n_cand,
+                                                    double *__restrict__ grad, int64_t grad_stride,
+                                                    const int32_t *__restrict__ gate)
+{
+    if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= n_tiles) return;
+    const TileDesc td = tiles[t];
+#define GT(KK) case KK: if (KK <= KU) { grad_tile<(KK <= KU ? KK : 1)>(td, tvals, tidx, v, status, N, n_out, n_cand, grad, grad_stride, lane); break; }
+    switch (td.k) {
+        GT(1) GT(2) GT(3) GT(4) GT(5) GT(6) GT(7) GT(8) GT(9) GT(10) GT(11) GT(12)
+        default: grad_tile_generic(td, tvals, tidx, v, status, N, n_out, n_cand, grad, grad_stride, lane);
+    }
+#undef GT
+}
+
+// Fused solve + gradient pass (single candidate): every workgroup owns 4 tiles of ONE output, folds that output's chunk
+// partials and factorises Phi itself (redundantly with the other workgroups of the output -- ~2.5 us of one wavefront,
+// no inter-workgroup hand-off, so nothing to synchronise), then its 4 wavefronts evaluate their tiles with v read from
+// LDS.  Saves one dependent launch per evaluation.  The tile list is padded so that no workgroup straddles two outputs.
+// tiles per workgroup of the fused kernel: wavefront 0 solves, wavefronts 1..TPB own one tile each.  15 (1024 threads,
+// 128 VGPRs) while the register-resident matrix (2 NT VGPRs) and tile (KU (KU+1) + KU VGPRs) fit, else 7 (512 threads, 256 VGPRs)
+__host__ __device__ constexpr int fused_tpb(int NT, int KU) { return (NT <= 26 && KU <= 8) ? 15 : 7; }
+static int pick_ku(int kmax) { return kmax <= 5 ? 5 : kmax <= 6 ? 6 : kmax <= 8 ? 8 : 12; }
+template <int NT, int KU>
+__global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
+                                                    const double2 *__restrict__ partial, double delta,
+                                                    const TileDesc *__restrict__ tiles, int64_t n_tiles, int bpo,
+                                                    const double *__restrict__ tvals, const uint8_t *__restrict__ tidx,
+                                                    double *__restrict__ var, double *__restrict__ v_ws,
+                                                    int32_t *__restrict__ status, double *__restrict__ grad,
+                                                    const int32_t *__restrict__ gate)
+{
+    constexpr int FUSED_TPB = fused_tpb(NT, KU);
+    constexpr int NTHREADS = 64 * (FUSED_TPB + 1);
+    constexpr int NE = KU * (KU + 1) / 2;
+    __shared__ SolveLds<NT> lds;
+    if (gate && *gate == 0) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    SPAN_BEGIN(1);
+    PHASE(0);
+    const int64_t t0 = (int64_t)blockIdx.x * FUSED_TPB;
+    // which output, and am I its first workgroup: arithmetic when every output has the same number of workgroups (bpo > 0,
+    // the usual case), else from the first tile's descriptor (one more dependent load in front of the fold)
+    int o, first;
+    if (bpo > 0) { o = blockIdx.x / bpo; first = (blockIdx.x % bpo) == 0; }
+    else { const TileDesc td0 = tiles[t0]; o = td0.out; first = (td0.n_valid >> 30) & 1; }
+    if (tid < N) lds.amax[tid] = 0.0;
+    for (int t = tid; t < N * N; t += NTHREADS) lds.phi[t] = 0.0;
+    __syncthreads();
+    PHASE(1);
+    fold_rows<NT>(lds, N, rows, o * nsym, nsym, partial, tid, NTHREADS);
+    __syncthreads();
+    PHASE(2);
+    // the list is padded to a multiple of FUSED_TPB tiles per output, so every tile of this workgroup belongs to output o
+    const TileDesc td = tiles[t0 + (wave > 0 ? wave - 1 : 0)];
+    const int k = td.k;
+    double s[NE];
+    int gi[KU];
+    if (wave == 0) {
+        const double am = (lane < N) ? lds.amax[lane] : 0.0;
+        const bool big = __ballot(am >= 0.05) != 0ull;   // max |m| >= 0.05 (misc.py:464)
+        double V = 0.0;
+        int32_t st = 0;
+        PHASE(8);
+        solve_wave<NT>(lds, N, delta, am > 1.0e-6, am > 0.0, big, true, &V, lds.vout, &st, lane);
+        if (lane == 0) lds.status = st;
+        if (first) {   // first workgroup of this output publishes V, status, v
+            if (lane == 0) { var[o] = V; status[o] = st; }
+            if (lane < N) v_ws[(int64_t)o * N + lane] = lds.vout[lane];
+        }
+        PHASE(3);
+    } else if (k <= KU) {
+        // stream the tile into registers while wavefront 0 factorises (after the fold, so these loads do not queue in front of it)
+        const double *vals = tvals + td.val_off + lane;
+        const uint8_t *idx = tidx + td.idx_off + lane;
+        const int ne = k * (k + 1) / 2;
+#pragma unroll
+        for (int j = 0; j < KU; j++) if (j < k) gi[j] = idx[j * 64];
+#pragma unroll
+        for (int e = 0; e < NE; e++) if (e < ne) s[e] = vals[e * 64];
+    }
+    __syncthreads();
+    if (wave == 0) { SPAN_END(1, true); return; }
+    const bool valid = lane < (td.n_valid & 0xffff);
+    const bool inf = lds.status == BLUEST_EVAL_INF;
+    double *gout = grad + td.grad_off + lane;
+#define GT(KK) case KK: if (KK <= KU) { const double q = tile_form<(KK <= KU ? KK : 1)>(s, gi, lds.vout); if (valid) *gout = inf ? INFINITY : -q; break; }
+    switch (k) {
+        GT(1) GT(2) GT(3) GT(4) GT(5) GT(6) GT(7) GT(8) GT(9) GT(10) GT(11) GT(12)
+        default: {
+            // grad_tile reads v as v[(c*n_out + td.out)*N + model] and status[c*n_out + td.out]: point both at LDS
+            const double *vl = lds.vout - (int64_t)td.out * N;
+            const int32_t *sl = &lds.status - td.out;
+            grad_tile_generic(td, tvals, tidx, vl, sl, N, n_out, 1, grad, 0, lane);
+        }
+    }
+#undef GT
+    PHASE(4);
+    SPAN_END(1, false);
+}
+
+// out[c][j] = scale[j] * sum_o coef[c][o] * grad_o[c][invmap_o[j]]
+__global__ void k_combine_grad(const double *__restrict__ grad, int64_t grad_stride, const int64_t *__restrict__ goff,
+                               const int32_t *__restrict__ invmap, int64_t L, int n_out,
+                               const double *__restrict__ coef, const double *__restrict__ scale, int n_cand,
+                               double *__restrict__ out, int64_t out_stride, const int32_t *__restrict__ gate)
+{
+    if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (j >= L || c >= n_cand) return;
+    double s = 0.0;
+    for (int o = 0; o < n_out; o++) {
+        const int32_t li = invmap[(int64_t)o * L + j];
+        if (li >= 0) s = fma(coef[(int64_t)c * n_out + o], grad[(int64_t)c * grad_stride + goff[o] + li], s);
+    }
+    out[(int64_t)c * out_stride + j] = scale ? scale[j] * s : s;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Part 2 host side: the plan
+// ------------------------------------------------------------------------------------------------------
+static void plan_free_device(bluest_plan_s *p)
+{
+    void *ptrs[] = {p->d_vals, p->d_cols, p->d_rows, p->d_out_row_begin, p->d_tiles, p->d_tvals, p->d_tidx,
+                    p->d_invmap, p->d_goff, p->d_partial, p->d_v, p->d_status};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+}
+
+extern "C" int bluest_plan_create(bluest_plan_t *plan, int n_models, int64_t L_global)
+{
+    if (!plan) return fail(BLUEST_ERR_ARG, "plan is NULL");
+    if (n_models <= 0 || n_models > BLUEST_MAX_MODELS)
+        return fail(BLUEST_ERR_ARG, "n_models=%d out of range (1..%d)", n_models, BLUEST_MAX_MODELS);
+    if (L_global <= 0 || L_global > 0x7fffffffLL) return fail(BLUEST_ERR_ARG, "L_global=%lld out of range", (long long)L_global);
+    int rc = require_gpu(); if (rc) return rc;
+    bluest_plan_s *p = new bluest_plan_s();
+    p->N = n_models;
+    p->L = L_global;
+    *plan = p;
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_destroy(bluest_plan_t plan)
+{
+    if (!plan) return BLUEST_OK;
+    plan_free_device(plan);
+    delete plan;
+    return BLUEST_OK;
+}
+
+static int plan_add_common(bluest_plan_t plan, int K, const int64_t *sizes, const int64_t *groups, const int64_t *mapping,
+                           OutputDesc &od)
+{
+    if (!plan) return fail(BLUEST_ERR_ARG, "plan is NULL");
+    if (plan->finalized) return fail(BLUEST_ERR_STATE, "plan already finalized");
+    if (K <= 0 || K > BLUEST_MAX_GROUP) return fail(BLUEST_ERR_ARG, "K=%d out of range (1..%d)", K, BLUEST_MAX_GROUP);
+    if (!sizes || !groups) return fail(BLUEST_ERR_ARG, "null pointer");
+    if ((int)plan->outs.size() >= 32767) return fail(BLUEST_ERR_ARG, "too many outputs");
+    od.K = K;
+    od.sizes.assign(sizes, sizes + K);
+    int64_t L_o = 0, ng = 0;
+    for (int k = 1; k <= K; k++) {
+        if (sizes[k - 1] < 0) return fail(BLUEST_ERR_ARG, "negative size");
+        L_o += sizes[k - 1];
+        ng += sizes[k - 1] * k;
+    }
+    if (L_o <= 0) return fail(BLUEST_ERR_ARG, "output has no groups");
+    od.L_o = L_o;
+    od.groups.assign(groups, groups + ng);
+    for (int64_t t = 0; t < ng; t++)
+        if (groups[t] < 0 || groups[t] >= plan->N) return fail(BLUEST_ERR_ARG, "model index %lld out of range", (long long)groups[t]);
+    if (mapping) {
+        od.mapping.assign(mapping, mapping + L_o);
+        for (int64_t t = 0; t < L_o; t++)
+            if (mapping[t] < 0 || mapping[t] >= plan->L) return fail(BLUEST_ERR_ARG, "mapping index %lld out of range", (long long)mapping[t]);
+    } else {
+        if (L_o != plan->L) return fail(BLUEST_ERR_ARG, "identity mapping needs L_o == L_global (%lld vs %lld)", (long long)L_o, (long long)plan->L);
+        od.mapping.resize(L_o);
+        for (int64_t t = 0; t < L_o; t++) od.mapping[t] = t;
+    }
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_add_output(bluest_plan_t plan, int K, const int64_t *sizes, const int64_t *groups,
+                                      const double *invcovs, const int64_t *mapping)
+{
+    OutputDesc od;
+    int rc = plan_add_common(plan, K, sizes, groups, mapping, od);
+    if (rc) return rc;
+    if (!invcovs) return fail(BLUEST_ERR_ARG, "invcovs is NULL");
+    int64_t ni = 0;
+    for (int k = 1; k <= K; k++) ni += sizes[k - 1] * k * k;
+    od.invcovs.assign(invcovs, invcovs + ni);
+    plan->outs.push_back(std::move(od));
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_add_output_cov(bluest_plan_t plan, const double *C, int K, const int64_t *sizes,
+                                          const int64_t *groups, const int64_t *mapping, double *invcovs_out)
+{
+    OutputDesc od;
+    PhaseTimer timer("plan_add_output_cov");
+    int rc = plan_add_common(plan, K, sizes, groups, mapping, od);
+    if (rc) return rc;
+    timer.lap("copy groups / mapping");
+    if (!C) return fail(BLUEST_ERR_ARG, "C is NULL");
+    const int N = plan->N;
+    int64_t ni = 0, ng = 0;
+    for (int k = 1; k <= K; k++) { ni += sizes[k - 1] * k * k; ng += sizes[k - 1] * k; }
+    od.invcovs.resize(ni);
+    double *dC = nullptr, *dic = nullptr;
+    int64_t *dg = nullptr;
+    HIP_TRY(hipMalloc((void **)&dC, (size_t)N * N * sizeof(double)));
+    hipError_t e = hipMalloc((void **)&dic, (size_t)ni * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&dg, (size_t)ng * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMemcpy(dC, C, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dg, groups, (size_t)ng * sizeof(int64_t), hipMemcpyHostToDevice);
+    rc = BLUEST_OK;
+    if (e == hipSuccess) {
+        int64_t go = 0, io = 0;
+        for (int k = 1; k <= K && rc == BLUEST_OK; k++) {
+            const int64_t Lk = sizes[k - 1];
+            if (Lk > 0) rc = launch_group_pinv(dC, N, k, Lk, dg + go, dic + io, 0);
+            go += Lk * k; io += Lk * k * k;
+        }
+        if (rc == BLUEST_OK) e = hipMemcpy(od.invcovs.data(), dic, (size_t)ni * sizeof(double), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(dC); (void)hipFree(dic); (void)hipFree(dg);
+    timer.lap("device pinv round trip (malloc, H2D, kernels, D2H, free)");
+    if (rc) return rc;
+    HIP_TRY(e);
+    if (invcovs_out) memcpy(invcovs_out, od.invcovs.data(), (size_t)ni * sizeof(double));
+    plan->outs.push_back(std::move(od));
+    return BLUEST_OK;
+}
+
+template <typename T>
+static int upload(T **dst, const std::vector<T> &src)
+{
+    *dst = nullptr;
+    const size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc((void **)dst, bytes));
+    if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return BLUEST_OK;
+}
+
+// host-side layout construction on up to 16 worker threads
+static int host_threads()
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min<unsigned>(hw ? hw : 1u, 16u));
+}
+template <class F>
+static void parallel_items(int n_items, F fn)
+{
+    const int nt = std::min(n_items, host_threads());
+    if (nt <= 1) { for (int i = 0; i < n_items; i++) fn(i); return; }
+    std::atomic<int> next{0};
+    std::vector<std::thread> workers;
+    for (int t = 0; t < nt; t++)
+        workers.emplace_back([&]() { for (;;) { const int i = next++; if (i >= n_items) break; fn(i); } });
+    for (auto &w : workers) w.join();
+}
+
+extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
+{
+    if (!plan) return fail(BLUEST_ERR_ARG, "plan is NULL");
+    if (plan->finalized) return fail(BLUEST_ERR_STATE, "plan already finalized");
+    if (plan->outs.empty()) return fail(BLUEST_ERR_STATE, "plan has no outputs");
+    if (max_candidates <= 0 || max_candidates > 65535) return fail(BLUEST_ERR_ARG, "max_candidates=%d out of range", max_candidates);
+    const int N = plan->N, n_out = (int)plan->outs.size();
+    const int nsym = N * (N + 1) / 2;
+    auto tri = [N](int a, int b) { return a * N - a * (a - 1) / 2 + (b - a); };
+    PhaseTimer timer("plan_finalize");
+
+    // ---- Phi pass: destination-major symmetric CSR ------------------------------------------------
+    // count entries per (output,row); pick the chunk size so that no row needs more than 64 chunks
+    std::vector<std::vector<int64_t>> counts(n_out, std::vector<int64_t>(nsym, 0));
+    int64_t max_row = 0;
+    // parallel counting sort: slice s of S owns a contiguous range of the output's groups; it counts its entries per row,
+    // the per-slice counts are prefix-summed into start offsets, then every slice writes its own entries -- rows keep their
+    // entries in group order whatever S is, so the layout (and every summation order on the GPU) is independent of threading
+    const int S = std::max(1, host_threads() / n_out);      // slices per output
+    std::vector<std::vector<int64_t>> slice_cnt((size_t)n_out * S, std::vector<int64_t>(nsym, 0));
+    auto for_groups_of_slice = [&](int o, int slice, auto &&body) {
+        const OutputDesc &od = plan->outs[o];
+        const int64_t lo = od.L_o * slice / S, hi = od.L_o * (slice + 1) / S;
+        int64_t go = 0, io = 0, l0 = 0;
+        for (int k = 1; k <= od.K; k++) {
+            const int64_t Lk = od.sizes[k - 1];
+            for (int64_t i = std::max<int64_t>(lo - l0, 0); i < std::min<int64_t>(hi - l0, Lk); i++)
+                body(k, od.groups.data() + go + i * k, od.invcovs.data() + io + i * k * k, l0 + i);
+            go += Lk * k; io += Lk * k * k; l0 += Lk;
+        }
+    };
+    parallel_items(n_out * S, [&](int item) {
+        std::vector<int64_t> &cnt = slice_cnt[item];
+        for_groups_of_slice(item / S, item % S, [&](int k, const int64_t *g, const double *, int64_t) {
+            for (int j = 0; j < k; j++)
+                for (int l = j; l < k; l++) cnt[tri((int)std::min(g[j], g[l]), (int)std::max(g[j], g[l]))]++;
+        });
+    });
+    for (int o = 0; o < n_out; o++)
+        for (int r = 0; r < nsym; r++) {
+            int64_t run = 0;
+            for (int sl = 0; sl < S; sl++) { const int64_t c = slice_cnt[(size_t)o * S + sl][r]; slice_cnt[(size_t)o * S + sl][r] = run; run += c; }
+            counts[o][r] = run;      // slice_cnt now holds each slice's start offset inside the row
+        }
+    for (int o = 0; o < n_out; o++)
+        for (int r = 0; r < nsym; r++) max_row = std::max(max_row, counts[o][r]);
+    timer.lap("count");
+    int iters = 1;
+    while ((max_row + 256LL * iters - 1) / (256LL * iters) > 64 && iters < 1024) iters *= 2;
+    const int64_t CH = 256LL * iters;
+    plan->iters = iters;
+    plan->nsym = nsym;
+    plan->shared = true;
+    for (int o = 1; o < n_out; o++) {
+        const OutputDesc &x = plan->outs[0], &y = plan->outs[o];
+        if (x.K != y.K || x.sizes != y.sizes || x.groups != y.groups || x.mapping != y.mapping) { plan->shared = false; break; }
+    }
+
+    std::vector<RowDesc> rows((size_t)n_out * nsym);
+    std::vector<int32_t> out_row_begin(n_out + 1);
+    int64_t n_chunks = 0;
+    for (int o = 0; o < n_out; o++) {
+        out_row_begin[o] = o * nsym;
+        for (int a = 0; a < N; a++)
+            for (int b = a; b < N; b++) {
+                RowDesc &rd = rows[(size_t)o * nsym + tri(a, b)];
+                const int64_t nc = (counts[o][tri(a, b)] + CH - 1) / CH;
+                rd.first_chunk = (int32_t)n_chunks;
+                rd.n_chunks = (int32_t)nc;
+                rd.out = (int16_t)o; rd.a = (int16_t)a; rd.b = (int16_t)b; rd.pad = 0;
+                n_chunks += nc;
+            }
+    }
+    out_row_begin[n_out] = n_out * nsym;
+    if (n_chunks <= 0 || n_chunks * CH > 0x7fffffff0LL) return fail(BLUEST_ERR_ARG, "problem too large for one plan (%lld chunks)", (long long)n_chunks);
+    std::vector<double> vals((size_t)(n_chunks * CH), 0.0);
+    std::vector<int32_t> cols((size_t)(n_chunks * CH), 0);
+    {
+        parallel_items(n_out * S, [&](int item) {
+            const int o = item / S;
+            std::vector<int64_t> &next = slice_cnt[item];     // start offsets, advanced as the slice writes
+            const OutputDesc &od = plan->outs[o];
+            for_groups_of_slice(o, item % S, [&](int k, const int64_t *g, const double *ic, int64_t li) {
+                for (int j = 0; j < k; j++)
+                    for (int l = j; l < k; l++) {
+                        const int rr = tri((int)std::min(g[j], g[l]), (int)std::max(g[j], g[l]));
+                        const int64_t pos = (int64_t)rows[(size_t)o * nsym + rr].first_chunk * CH + next[rr]++;
+                        vals[pos] = (j == l) ? ic[j * k + j] : 0.5 * (ic[j * k + l] + ic[l * k + j]);
+                        cols[pos] = (int32_t)od.mapping[li];
+                    }
+            });
+        });
+        // padding: value 0, column = the row's first column (keeps max|m| per row exact, adds nothing)
+        parallel_items(n_out, [&](int o) {
+            for (int rr = 0; rr < nsym; rr++) {
+                const size_t r = (size_t)o * nsym + rr;
+                const int64_t beg = (int64_t)rows[r].first_chunk * CH, end = beg + (int64_t)rows[r].n_chunks * CH;
+                for (int64_t pos = beg + counts[o][rr]; pos < end; pos++) cols[pos] = cols[beg];
+            }
+        });
+    }
+    timer.lap("CSR alloc + fill");
+    // ---- gradient pass: group-major tiles ------------------------------------------------------------
+    {
+        int kmax_all = 0;
+        for (const auto &od : plan->outs) kmax_all = std::max(kmax_all, od.K);
+        plan->fused_tpb = fused_tpb(pick_nt(N), pick_ku(kmax_all));
+    }
+    // phase 1 (serial, cheap): descriptors and offsets; phase 2 (one thread per output): fill values and indices
+    std::vector<TileDesc> tiles;
+    std::vector<int64_t> tile_t0;            // index of the tile's first group inside its size bucket
+    std::vector<size_t> tile_begin(n_out + 1, 0);
+    size_t n_tvals = 0, n_tidx = 0;
+    plan->grad_off.assign(n_out, 0);
+    int64_t grad_len = 0;
+    for (int o = 0; o < n_out; o++) {
+        const OutputDesc &od = plan->outs[o];
+        plan->grad_off[o] = grad_len;
+        const size_t first_tile_of_output = tiles.size();
+        tile_begin[o] = first_tile_of_output;
+        int64_t li = 0;
+        for (int k = 1; k <= od.K; k++) {
+            const int64_t Lk = od.sizes[k - 1];
+            const int ne = k * (k + 1) / 2;
+            for (int64_t t0 = 0; t0 < Lk; t0 += 64) {
+                TileDesc td;
+                td.val_off = (int64_t)n_tvals;
+                n_tidx = (n_tidx + 15) / 16 * 16;
+                td.idx_off = (int64_t)n_tidx;
+                td.grad_off = grad_len + li + t0;
+                td.n_valid = (int32_t)std::min<int64_t>(64, Lk - t0);
+                td.k = (int16_t)k; td.out = (int16_t)o;
+                n_tvals += (size_t)ne * 64;
+                n_tidx += (size_t)k * 64;
+                tiles.push_back(td);
+                tile_t0.push_back(t0);
+            }
+            li += Lk;
+        }
+        // first tile of the output is flagged; the list is padded to a multiple of FUSED_TPB tiles per output with empty
+        // tiles so that a workgroup of the fused solve+gradient kernel never straddles two outputs
+        if (tiles.size() > first_tile_of_output) tiles[first_tile_of_output].n_valid |= (1 << 30);
+        tile_begin[o + 1] = tiles.size();       // real tiles of this output end here (padding follows)
+        while ((tiles.size() - first_tile_of_output) % plan->fused_tpb || tiles.size() == first_tile_of_output) {
+            TileDesc td;
+            td.val_off = 0; td.idx_off = 0; td.grad_off = 0; td.n_valid = (tiles.size() == first_tile_of_output) ? (1 << 30) : 0;
+            td.k = 1; td.out = (int16_t)o;
+            tiles.push_back(td);
+            tile_t0.push_back(0);
+        }
+        const int bpo = (int)((tiles.size() - first_tile_of_output) / plan->fused_tpb);
+        if (o == 0) plan->fused_bpo = bpo;
+        else if (plan->fused_bpo != bpo) plan->fused_bpo = 0;
+        grad_len += od.L_o;
+    }
+    std::vector<double> tvals(n_tvals, 0.0);
+    std::vector<uint8_t> tidx(n_tidx, 0);
+    {
+        std::vector<std::vector<int64_t>> gofs(n_out), iofs(n_out);   // start of size bucket k in groups / invcovs
+        for (int o = 0; o < n_out; o++) {
+            const OutputDesc &od = plan->outs[o];
+            gofs[o].assign(od.K + 2, 0); iofs[o].assign(od.K + 2, 0);
+            for (int k = 1; k <= od.K; k++) { gofs[o][k + 1] = gofs[o][k] + od.sizes[k - 1] * k; iofs[o][k + 1] = iofs[o][k] + od.sizes[k - 1] * k * k; }
+        }
+        const int n_slices = host_threads() * 4;
+        const size_t nt_all = tiles.size();
+        parallel_items(n_slices, [&](int slice) {
+            for (size_t t = (size_t)slice * nt_all / n_slices; t < (size_t)(slice + 1) * nt_all / n_slices; t++) {
+                const TileDesc &td = tiles[t];
+                const int nv = td.n_valid & 0xffff;
+                if (nv == 0) continue;
+                const OutputDesc &od = plan->outs[td.out];
+                const int k = td.k;
+                for (int lane = 0; lane < nv; lane++) {
+                    const int64_t i = tile_t0[t] + lane;
+                    const int64_t *g = od.groups.data() + gofs[td.out][k] + i * k;
+                    const double *ic = od.invcovs.data() + iofs[td.out][k] + i * k * k;
+                    int e = 0;
+                    for (int j = 0; j < k; j++) {
+                        tidx[td.idx_off + j * 64 + lane] = (uint8_t)g[j];
+                        for (int l = j; l < k; l++, e++)
+                            tvals[td.val_off + e * 64 + lane] = (j == l) ? ic[j * k + j] : 0.5 * (ic[j * k + l] + ic[l * k + j]);
+                    }
+                }
+            }
+        });
+    }
+    plan->grad_len = grad_len;
+
+    // ---- inverse maps for combine_grad ------------------------------------------------------------
+    std::vector<int32_t> invmap((size_t)n_out * plan->L, -1);
+    for (int o = 0; o < n_out; o++)
+        for (int64_t li = 0; li < plan->outs[o].L_o; li++) invmap[(size_t)o * plan->L + plan->outs[o].mapping[li]] = (int32_t)li;
+
+    plan->n_chunks = n_chunks;
+    plan->n_rows = (int64_t)rows.size();
+    plan->n_tiles = (int64_t)tiles.size();
+    plan->max_cand = max_candidates;
+    plan->phi_bytes = n_chunks * CH * 8 + (plan->shared ? n_chunks / n_out : n_chunks) * CH * 4 + n_chunks * 16;
+    plan->grad_bytes = (int64_t)tvals.size() * 8 + (int64_t)tidx.size() + grad_len * 8;
+
+    timer.lap("tiles + inverse maps");
+    int rc;
+    if ((rc = upload(&plan->d_vals, vals))) return rc;
+    if ((rc = upload(&plan->d_cols, cols))) return rc;
+    if ((rc = upload(&plan->d_rows, rows))) return rc;
+    if ((rc = upload(&plan->d_out_row_begin, out_row_begin))) return rc;
+    if ((rc = upload(&plan->d_tiles, tiles))) return rc;
+    if ((rc = upload(&plan->d_tvals, tvals))) return rc;
+    if ((rc = upload(&plan->d_tidx, tidx))) return rc;
+    if ((rc = upload(&plan->d_invmap, invmap))) return rc;
+    if ((rc = upload(&plan->d_goff, plan->grad_off))) return rc;
+    HIP_TRY(hipMalloc((void **)&plan->d_partial, (size_t)max_candidates * n_chunks * sizeof(double2)));
+    HIP_TRY(hipMalloc((void **)&plan->d_v, (size_t)max_candidates * n_out * N * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&plan->d_status, (size_t)max_candidates * n_out * sizeof(int32_t)));
+    plan->finalized = true;
+    timer.lap("uploads + device allocations");
+    // host copies of the reference-layout inputs are no longer needed
+    for (auto &od : plan->outs) { std::vector<double>().swap(od.invcovs); std::vector<int64_t>().swap(od.groups); }
+    return BLUEST_OK;
+}
+
+int plan_ready(bluest_plan_t plan, int n_cand)
+{
+    if (!plan) return fail(BLUEST_ERR_ARG, "plan is NULL");
+    if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
+    if (n_cand <= 0 || n_cand > plan->max_cand) return fail(BLUEST_ERR_ARG, "n_cand=%d outside 1..%d", n_cand, plan->max_cand);
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_n_outputs(bluest_plan_t plan, int *n)
+{
+    if (!plan || !n) return fail(BLUEST_ERR_ARG, "null pointer");
+    *n = (int)plan->outs.size();
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_grad_layout(bluest_plan_t plan, int64_t *grad_len, int64_t *offsets)
+{
+    if (!plan) return fail(BLUEST_ERR_ARG, "plan is NULL");
+    if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
+    if (grad_len) *grad_len = plan->grad_len;
+    if (offsets) for (size_t o = 0; o < plan->outs.size(); o++) offsets[o] = plan->grad_off[o];
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_traffic(bluest_plan_t plan, int64_t *phi_bytes, int64_t *grad_bytes)
+{
+    if (!plan) return fail(BLUEST_ERR_ARG, "plan is NULL");
+    if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
+    if (phi_bytes) *phi_bytes = plan->phi_bytes;
+    if (grad_bytes) *grad_bytes = plan->grad_bytes;
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_phi_len(bluest_plan_t plan, int64_t *len)
+{
+    if (!plan || !len) return fail(BLUEST_ERR_ARG, "null pointer");
+    *len = (int64_t)plan->outs.size() * (plan->N * plan->N + 2 * plan->N + 1);
+    return BLUEST_OK;
+}
+
+static void launch_grad(bluest_plan_t plan, const double *v_dev, const int32_t *status_dev, int n_cand, double *grad_dev,
+                        int64_t grad_stride, hipStream_t st)
+{
+    const int n_out = (int)plan->outs.size();
+    int kmax = 0;
+    for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
+#define LG(KU) hipLaunchKernelGGL((k_grad_tiles<KU>), dim3((unsigned)((plan->n_tiles + 3) / 4)), dim3(256), 0, st, plan->d_tiles, plan->n_tiles, \
+                                  plan->d_tvals, plan->d_tidx, v_dev, status_dev, plan->N, n_out, n_cand, grad_dev, grad_stride, plan->gate)
+    if (kmax <= 5) LG(5);
+    else if (kmax <= 8) LG(8);
+    else LG(12);
+#undef LG
+}
+
+static void launch_chunks(bluest_plan_t p, const double *m, int n_cand, int64_t m_stride, hipStream_t st)
+{
+    const int n_out = (int)p->outs.size();
+    if (p->shared && n_out >= 2) {
+        const int64_t ncpo = p->n_chunks / n_out;
+        const unsigned gx = (unsigned)((ncpo + 3) / 4);
+#define LCS(OB) hipLaunchKernelGGL((k_phi_chunks_shared<OB>), dim3(gx, (n_out + OB - 1) / OB), dim3(256), 0, st, p->d_vals, p->d_cols, \
+                                   p->iters, ncpo, n_out, m, m_stride, n_cand, p->n_chunks, p->d_partial, p->gate)
+        // outputs per wavefront: sharing the column stream saves bytes, but the pass is latency-bound, so keep at least
+        // ~4096 wavefronts in flight (measured at n=20, n_out=8: OB=8 6.9 us, OB=4 5.5 us, OB=2 5.1 us, OB=1 6.1 us)
+        int ob = 8;
+        while (ob > 2 && (ncpo * ((n_out + ob - 1) / ob) < 4096 || ob > n_out)) ob /= 2;
+        if (ob == 8) LCS(8);
+        else if (ob == 4) LCS(4);
+        else LCS(2);
+#undef LCS
+        return;
+    }
+    hipLaunchKernelGGL(k_phi_chunks, dim3((unsigned)((p->n_chunks + 3) / 4)), dim3(256), 0, st, p->d_vals, p->d_cols,
+                       p->iters, p->n_chunks, m, m_stride, n_cand, p->d_partial, p->gate);
+}
+
+extern "C" int bluest_plan_phi_chunks(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, void *stream)
+{
+    int rc = plan_ready(plan, n_cand); if (rc) return rc;
+    if (!m_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (n_cand > 1 && m_stride < plan->L) return fail(BLUEST_ERR_ARG, "m_stride < L_global");
+    launch_chunks(plan, m_dev, n_cand, m_stride, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_phi(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, double *phi_dev, void *stream)
+{
+    int rc = plan_ready(plan, n_cand); if (rc) return rc;
+    if (!m_dev || !phi_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (n_cand > 1 && m_stride < plan->L) return fail(BLUEST_ERR_ARG, "m_stride < L_global");
+    hipStream_t st = (hipStream_t)stream;
+    const int n_out = (int)plan->outs.size();
+    launch_chunks(plan, m_dev, n_cand, m_stride, st);
+#define LFR(NT) hipLaunchKernelGGL((k_fold_to_record<NT>), dim3(n_out, n_cand), dim3(fold_threads(NT)), 0, st, plan->N, n_out, plan->d_rows, \
+                                   plan->nsym, plan->d_partial, plan->n_chunks, phi_dev)
+    NT_DISPATCH(plan->N, LFR);
+#undef LFR
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_solve(bluest_plan_t plan, const double *phi_dev, int n_cand, double delta, double *var_dev,
+                                 double *v_dev, int32_t *status_dev, void *stream)
+{
+    int rc = plan_ready(plan, n_cand); if (rc) return rc;
+    if (!phi_dev || !var_dev || !v_dev || !status_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    const int n_out = (int)plan->outs.size();
+#define LSR(NT) hipLaunchKernelGGL((k_solve_from_record<NT>), dim3(n_out, n_cand), dim3(64), 0, (hipStream_t)stream, plan->N, n_out, \
+                                   phi_dev, delta, 1, var_dev, v_dev, status_dev)
+    NT_DISPATCH(plan->N, LSR);
+#undef LSR
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_grad(bluest_plan_t plan, const double *v_dev, const int32_t *status_dev, int n_cand,
+                                double *grad_dev, int64_t grad_stride, void *stream)
+{
+    int rc = plan_ready(plan, n_cand); if (rc) return rc;
+    if (!v_dev || !status_dev || !grad_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (n_cand > 1 && grad_stride < plan->grad_len) return fail(BLUEST_ERR_ARG, "grad_stride < grad_len");
+    const int n_out = (int)plan->outs.size();
+    launch_grad(plan, v_dev, status_dev, n_cand, grad_dev, grad_stride, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, double delta,
+                                double *var_dev, double *grad_dev, int64_t grad_stride, int32_t *status_dev, void *stream)
+{
+    int rc = plan_ready(plan, n_cand); if (rc) return rc;
+    if (!m_dev || !var_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (n_cand > 1 && m_stride < plan->L) return fail(BLUEST_ERR_ARG, "m_stride < L_global");
+    if (grad_dev && n_cand > 1 && grad_stride < plan->grad_len) return fail(BLUEST_ERR_ARG, "grad_stride < grad_len");
+    hipStream_t st = (hipStream_t)stream;
+    const int n_out = (int)plan->outs.size();
+    int32_t *status = status_dev ? status_dev : plan->d_status;
+    launch_chunks(plan, m_dev, n_cand, m_stride, st);
+    int kmax = 0;
+    for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
+    // fused solve + gradient pass (2 launches per evaluation); groups larger than 12 take the generic tile code inside it
+    if (grad_dev && n_cand == 1 && !g_debug_solve) {
+        const dim3 grid((unsigned)(plan->n_tiles / plan->fused_tpb));
+#define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, \
+                                        delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->d_tvals, plan->d_tidx, var_dev, plan->d_v, status, grad_dev, plan->gate)
+#define LSG(NT) do { if (kmax <= 5) LSG2(NT, 5); else if (kmax <= 6) LSG2(NT, 6); else if (kmax <= 8) LSG2(NT, 8); else LSG2(NT, 12); } while (0)
+        NT_DISPATCH(plan->N, LSG);
+#undef LSG
+#undef LSG2
+        HIP_TRY(hipGetLastError());
+        return BLUEST_OK;
+    }
+    const int want = ((grad_dev || plan->always_v) ? 1 : 0) | g_debug_solve;
+#define LSC(NT) hipLaunchKernelGGL((k_solve_from_chunks<NT>), dim3(n_out, n_cand), dim3(fold_threads(NT)), 0, st, plan->N, n_out, plan->d_rows, \
+                                   plan->nsym, plan->d_partial, plan->n_chunks, delta, want, var_dev, plan->d_v, status, plan->gate)
+    NT_DISPATCH(plan->N, LSC);
+#undef LSC
+    if (grad_dev)
+        launch_grad(plan, plan->d_v, status, n_cand, grad_dev, grad_stride, st);
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_combine_grad(bluest_plan_t plan, const double *grad_dev, int64_t grad_stride, const double *coef_dev,
+                                        const double *scale_dev, int n_cand, double *out_dev, int64_t out_stride, void *stream)
+{
+    int rc = plan_ready(plan, n_cand); if (rc) return rc;
+    if (!grad_dev || !coef_dev || !out_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    const int n_out = (int)plan->outs.size();
+    hipLaunchKernelGGL(k_combine_grad, dim3((unsigned)((plan->L + 255) / 256), n_cand), dim3(256), 0, (hipStream_t)stream, grad_dev,
+                       grad_stride, plan->d_goff, plan->d_invmap, plan->L, n_out, coef_dev, scale_dev, n_cand, out_dev, out_stride, plan->gate);
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+

@@ -2,7 +2,7 @@
 Device-resident evaluation plan: Python face of Part 2 of include/bluest_hip.h.
 
 torch is used only as plumbing: it owns device buffers and the current HIP stream; every number is produced by
-the hand-written kernels in csrc/bluest_hip.hip.
+the hand-written kernels in csrc/plan.hip (and csrc/spg.hip for the projection).
 """
 import ctypes
 

@@ -18,7 +18,7 @@ from . import _lib
 from ._lib import check
 from .plan import EVAL_OK, _stream, projection_workspace, simplex_project
 
-# state layout (csrc/bluest_hip.hip SPG_*)
+# state layout (csrc/spg.hip SPG_*)
 F, FNEW, LAMBDA, ALPHA, GD, DMAX, TAU, NPOS, ACCEPT, FAIL, DONE, IT, COUNT, NORM, P, LMIN, LMAX, HLEN, SDOTS, SDOTY, FTRIAL = range(21)
 EPS, GPSTATS = 21, 24
 HIST, COEF, S, STATE_DOUBLES = 32, 64, 128, 256

@@ -179,7 +179,7 @@ int bluest_simplex_project(const double *x_dev, const double *g_dev, double lamb
                            double *p_dev, double *d_dev, double *stats_dev, double *work_dev, void *stream);
 
 /* Device-resident SPG iteration (bluest/spg.py:68-106 with the control flow on the GPU).  The solver state is an
- * array of BLUEST_SPG_STATE_DOUBLES doubles in HBM (layout: csrc/bluest_hip.hip SPG_*, bluest_amd/spg_device.py);
+ * array of BLUEST_SPG_STATE_DOUBLES doubles in HBM (layout: csrc/spg.hip SPG_*, bluest_amd/spg_device.py);
  * every kernel below reads its scalars (lambda, alpha, f, history ...) from it and is a no-op once state[DONE] or
  * state[FAIL] is set, so a whole iteration -- direction, T predicated line-search slots, gradient, Barzilai-Borwein
  * update -- is a fixed launch sequence that can be captured in one hipGraph and replayed without host round trips.

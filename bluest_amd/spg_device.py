@@ -217,6 +217,7 @@ class DeviceSpg(object):
                     checks.append((it, count, float(hs[F])))
                     # backtracking is frequent on this problem: keep a second trial point inside the iteration graph (costs
                     # three predicated-off launches when unused, saves the host round trip and the idle rest of the window)
+                    # (3 of 10 measured better than 6 of 10: 92 vs 125 us per iteration at the headline size)
                     if self.T == 1 and sum(fail_windows[-10:]) >= 3:
                         self.T = 2
                         run_iter, run_slots, run_finish, run_iter_checked = bind()

@@ -181,10 +181,128 @@ def best_closest_integer_solution(sol, N, w, e, saps, mappings, plan, budget=Non
         r_sol[idx_full[rest]] = r_bnds[comb, np.arange(len(rest))]
         best_val, best_fval = _search(r_sol, N, w, e, saps, mappings, plan, budget, eps, max_samples_info,
                                       lb_full[brute], ub_full[brute], idx_full[brute], multi)
+    # extension (no reference counterpart): with this many free entries the random search rarely hits the feasible corner,
+    # so a greedy rounding competes with it; the better feasible point wins (lower variance / lower cost)
+    g_val, g_fval = greedy_integer(sol, N, w, e, saps, mappings, plan, budget, eps, max_samples_info)
+    if g_val is not None:
+        if best_val is None:
+            better = True
+        elif budget is not None:
+            better = g_fval < best_fval
+        else:
+            better = w @ g_val < w @ best_val
+        if better:
+            best_val, best_fval = g_val, g_fval
     if best_val is None:
         print("Unable to find feasible integer solution.")
         return None, np.inf
     return best_val, best_fval
+
+
+def greedy_integer(sol, N, w, e, saps, mappings, plan, budget=None, eps=None, max_samples_info=([], []), max_support=256):
+    """Greedy rounding of a continuous allocation on its support, every step one GPU batch of single-sample moves
+    (`bluest_intproj_eval`).  budget mode: start from floor(sol), keep buying the sample with the largest drop of max_o V_o
+    per unit cost that still fits 1.0001*budget (misc.py:284).  eps mode: start from ceil(sol), keep removing the most
+    expensive sample that leaves every V_o <= 1.0001*eps_o^2 (misc.py:301).  Returns (integer allocation, max_o V_o) or
+    (None, inf).  Not in the reference: used next to its randomised search when there are too many free entries."""
+    ES, rhs = max_samples_info
+    No = len(saps)
+    sup = np.flatnonzero(sol > 1.0e-8)
+    if len(sup) == 0:
+        return None, np.inf
+    if len(sup) > max_support:
+        sup = sup[np.argsort(sol[sup])[-max_support:]]
+    LL = len(sup)
+    cols = np.zeros((No, LL, N * N))
+    for n in range(No):
+        pos = {int(g): li for li, g in enumerate(mappings[n])}
+        for j, gidx in enumerate(sup):
+            li = pos.get(int(gidx))
+            if li is not None:
+                cols[n, j] = psi_column(saps[n], li)
+    wsup = w[sup]
+
+    def sampled_once(mv):
+        return all(e[mappings[n]] @ mv[mappings[n]] >= 1 for n in range(No))
+
+    def within_caps(mv):
+        return all(ees @ mv <= rr for ees, rr in zip(ES, rhs))
+
+    def moves(mv, sign):
+        """V[j, o] of mv + sign * (one sample of support entry j); the candidate kernel takes <= 32 free entries per call"""
+        base = plan.phi_matrix(mv.astype(np.float64))[0].reshape(No, N * N)
+        out = []
+        for c0 in range(0, LL, 32):
+            c1 = min(c0 + 32, LL)
+            out.append(candidate_variances(N, base, cols[:, c0:c1], sign * np.eye(c1 - c0), plan.device).cpu().numpy())
+        V = np.vstack(out)
+        return np.where(np.isfinite(V), V, np.inf)
+
+    def variances(mv):
+        base = plan.phi_matrix(mv.astype(np.float64))[0].reshape(No, N * N)
+        V = candidate_variances(N, base, cols[:, :1], np.zeros((1, 1)), plan.device).cpu().numpy()[0]
+        return np.where(np.isfinite(V), V, np.inf)
+
+    m = np.zeros(len(sol), dtype=np.int64)
+    if budget is not None:
+        m[sup] = np.floor(sol[sup]).astype(np.int64)
+        while not sampled_once(m):                         # model 0 of some output is not sampled yet: cheapest group that has it
+            lacking = [n for n in range(No) if e[mappings[n]] @ m[mappings[n]] < 1]
+            cand = [j for j in range(LL) if any(e[sup[j]] > 0 and sup[j] in set(mappings[n].tolist()) for n in lacking)]
+            if not cand:
+                return None, np.inf
+            m[sup[min(cand, key=lambda j: wsup[j])]] += 1
+        if w @ m > 1.0001 * budget or not within_caps(m):
+            return None, np.inf
+        Vcur = variances(m).max()
+        for _ in range(3 * LL + 16):
+            left = 1.0001 * budget - w @ m
+            V = moves(m, +1).max(axis=1)
+            gain = (Vcur - V) / wsup
+            gain[wsup > left] = -np.inf
+            for j in np.argsort(-gain):
+                if not gain[j] > 0.0:
+                    j = -1
+                    break
+                trial = m.copy()
+                trial[sup[j]] += 1
+                if within_caps(trial):
+                    break
+            else:
+                j = -1
+            if j < 0:
+                break
+            m[sup[j]] += 1
+            Vcur = V[j]
+        return (m, float(Vcur)) if np.isfinite(Vcur) else (None, np.inf)
+    lim = 1.0001 * np.asarray(eps, dtype=np.float64) ** 2
+    m[sup] = np.ceil(sol[sup]).astype(np.int64)
+    Vcur = variances(m)
+    for _ in range(3 * LL + 16):                          # the continuous point was infeasible after pruning: buy samples first
+        if (Vcur <= lim).all():
+            break
+        V = moves(m, +1)
+        j = int(np.argmin((V / lim[None, :]).max(axis=1) + 1e-12 * wsup))
+        m[sup[j]] += 1
+        Vcur = V[j]
+    if not (Vcur <= lim).all() or not sampled_once(m) or not within_caps(m):
+        return None, np.inf
+    for _ in range(3 * LL + 16):
+        V = moves(m, -1)
+        ok = (V <= lim[None, :]).all(axis=1) & (m[sup] >= 1)
+        best = -1
+        for j in np.argsort(-wsup):
+            if ok[j]:
+                trial = m.copy()
+                trial[sup[j]] -= 1
+                if sampled_once(trial):
+                    best = j
+                    break
+        if best < 0:
+            break
+        m[sup[best]] -= 1
+        Vcur = V[best]
+    return m, float(Vcur.max())
 
 
 def _increase_tolerance(budget, eps, fac):

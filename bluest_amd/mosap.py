@@ -238,20 +238,38 @@ class MOSAP(object):
                 hessians.append(self.SAPS[n]._hessian(m_h[self.mappings[n]], delta))
         return variances, gradients, hessians
 
-    def get_cleanup_matrices(self, m, delta=0):
+    def get_cleanup_matrices(self, m, delta=0, columns=None):
         """bluest/mosap.py:102-111: the per-output cleanup matrices stacked, (n_outputs*N, L).  Phi of every output comes
-        from ONE launch of the shared plan; the per-group products run through the `cleanupK` kernel."""
+        from ONE launch of the shared plan; the per-group products run through the `cleanupK` kernel.
+        columns (extension): global group indices -- only those columns are computed and returned, (n_outputs*N, len(columns));
+        `cleanup_solution` only ever looks at the support of m."""
         m_h = np.asarray(m.cpu().numpy() if isinstance(m, torch.Tensor) else m, dtype=np.float64)
         PHI = self.plan.phi_matrix(m_h, delta=delta)[0].cpu().numpy()
+        cols = None if columns is None else np.asarray(columns, dtype=np.int64)
         Xs = []
         for n in range(self.n_outputs):
             sap = self.SAPS[n]
             if abs(m_h[self.mappings[n]]).max() < 0.05:
                 raise ValueError("No entry greater or equal than 1 found in m.")
             invPHI = np.linalg.pinv(PHI[n])
-            X = np.zeros((self.N, self.L))
-            X[:, self.mappings[n]] = np.hstack([misc.cleanupK(k, sap.sizes[k], sap.groups[k - 1], sap.invcovs[k - 1], invPHI)
-                                                for k in range(1, sap.K + 1) if sap.sizes[k] > 0])
+            if cols is None:
+                X = np.zeros((self.N, self.L))
+                X[:, self.mappings[n]] = np.hstack([misc.cleanupK(k, sap.sizes[k], sap.groups[k - 1], sap.invcovs[k - 1], invPHI)
+                                                    for k in range(1, sap.K + 1) if sap.sizes[k] > 0])
+            else:
+                X = np.zeros((self.N, len(cols)))
+                local = np.full(self.L, -1, dtype=np.int64)
+                local[self.mappings[n]] = np.arange(len(self.mappings[n]))
+                loc = local[cols]                                   # position of each requested group inside output n (-1: absent)
+                for k in range(1, sap.K + 1):
+                    lo, hi = sap.cumsizes[k - 1], sap.cumsizes[k]
+                    pick = np.flatnonzero((loc >= lo) & (loc < hi))
+                    if len(pick) == 0:
+                        continue
+                    sel = loc[pick] - lo
+                    gk = np.asarray(sap.groups[k - 1])[sel]
+                    ick = np.asarray(sap.invcovs[k - 1]).reshape(-1, k * k)[sel].ravel()
+                    X[:, pick] = misc.cleanupK(k, len(sel), gk, ick, invPHI)
             Xs.append(X)
         return np.vstack(Xs)
 
@@ -283,7 +301,7 @@ class MOSAP(object):
             m[m < tol] = 0
             if it > 0 and L >= 1000: report(it, len(support), nullsize, V)
             it += 1
-            directions = null_space(self.get_cleanup_matrices(m, delta=delta)[:, support])
+            directions = null_space(self.get_cleanup_matrices(m, delta=delta, columns=support))
             dcost = w[support] @ directions
             directions = directions[:, dcost != 0] * -np.sign(dcost[dcost != 0])      # every direction now lowers the cost
             dcost = -abs(dcost[dcost != 0])

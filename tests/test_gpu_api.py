@@ -189,3 +189,31 @@ def test_hodgkin_huxley_end_to_end_matches_the_paper_allocation():
     assert mi.dtype.kind == "i" and (errs_i <= np.sqrt(1.0001) + 1e-9).all()
     assert abs(mi @ costs / paper_cost - 1) < 2e-4 and (mi > 0).sum() <= 14
     assert np.allclose(errs_i, G["errors_over_eps"], atol=0.01)          # same active constraint, same profile of errors
+
+
+def test_greedy_integer_rounding_is_feasible_and_close():
+    """extension next to the reference's randomised search (too many free entries to brute-force): the greedy rounding returns
+    a feasible integer allocation -- within 1.0001*budget resp. 1.0001*eps^2 as the reference's filters (misc.py:284, 301) --
+    whose objective is close to the continuous optimum's"""
+    from bluest_amd.integer import greedy_integer
+    from bluest_amd.mosap import MOSAP
+    n, kmax, n_out = 12, 4, 3
+    prob = synth.problem(n, kmax, n_out)
+    groups = prob["groups"]
+    mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in groups] for _ in range(n_out)],
+                prob["costs"], [prob["costs"]] * n_out, verbose=False)
+    B = prob["budget"]
+    mc = mos.solve(budget=B, solver="spg", continuous_relaxation=True)
+    Vc = max(mos.variances(mc))
+    args = (mos.N, mos.costs, mos.e, mos.SAPS, mos.mappings, mos.plan)
+    mi, Vi = greedy_integer(mc, *args, budget=B)
+    assert mi is not None and mi.dtype.kind == "i" and (mi >= 0).all()
+    assert mi @ mos.costs <= 1.0001 * B and abs(max(mos.variances(mi)) / Vi - 1) < 1e-9
+    assert Vc * (1 - 1e-3) <= Vi <= Vc * 1.02                        # integrality costs at most a couple of per cent here
+    eps = np.sqrt(np.array(mos.variances(mc)) * 1.5)
+    me = mos.solve(eps=eps, solver="spg", continuous_relaxation=True)
+    mj, Vj = greedy_integer(me, *args, eps=eps)
+    assert mj is not None and (np.array(mos.variances(mj)) <= 1.0001 * eps ** 2).all()
+    assert me @ mos.costs * (1 - 1e-3) <= mj @ mos.costs <= me @ mos.costs * 1.02
+    for n_ in range(n_out):
+        assert mj[mos.mappings[n_]] @ mos.e[mos.mappings[n_]] >= 1 and mi[mos.mappings[n_]] @ mos.e[mos.mappings[n_]] >= 1

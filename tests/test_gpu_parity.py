@@ -206,6 +206,8 @@ def test_mosap_ragged(gpu, oracle):
     for o in range(n_out):
         Xo = mos.SAPS[o].get_cleanup_matrix(G["m"][mos.mappings[o]])
         assert np.abs(Xo - G["X_cleanup"][o * n:(o + 1) * n][:, mos.mappings[o]]).max() <= 1e-10 * np.abs(G["X_cleanup"]).max()
+    some = np.array([0, 3, 7, len(G["m"]) - 1])
+    assert np.abs(mos.get_cleanup_matrices(G["m"], columns=some) - X[:, some]).max() <= 1e-13 * np.abs(X).max()
     mc = mos.cleanup_solution(G["m"].copy())
     assert (mc >= 0).all() and (mc > 0).sum() == (G["m_clean"] > 0).sum() == n * n_out
     assert mc @ G["costs"] <= G["m"] @ G["costs"] and max(mos.variances(mc)) <= max(G["Vs"]) * (1 + 1e-4)

@@ -238,6 +238,26 @@ class MOSAP(object):
                 hessians.append(self.SAPS[n]._hessian(m_h[self.mappings[n]], delta))
         return variances, gradients, hessians
 
+    def _restricted_plan(self, keep):
+        """shared plan of this problem restricted to the global groups `keep` (sorted indices); stored pseudo-inverses reused"""
+        keep = np.asarray(keep, dtype=np.int64)
+        outs = []
+        for n in range(self.n_outputs):
+            sap, mp = self.SAPS[n], np.asarray(self.mappings[n])
+            local = np.flatnonzero(np.isin(mp, keep))                        # positions inside output n, ascending
+            groups, invcovs, sizes = [], [], []
+            for k in range(1, sap.K + 1):
+                lo, hi = sap.cumsizes[k - 1], sap.cumsizes[k]
+                sel = local[(local >= lo) & (local < hi)] - lo
+                groups.append(np.asarray(sap.groups[k - 1]).reshape(-1, k)[sel])
+                invcovs.append(np.asarray(sap.invcovs[k - 1]).reshape(-1, k * k)[sel].ravel())
+                sizes.append(len(sel))
+            if not any(len(g) and (g == 0).any() for g in groups):
+                raise BLUESTError("restricted plan: output %d would not sample model 0" % n)
+            outs.append({"K": sap.K, "sizes": sizes, "groups": groups, "invcovs": invcovs,
+                         "mapping": np.searchsorted(keep, mp[local])})
+        return Plan(self.N, len(keep), outs, max_candidates=1, device=self.plan.device)
+
     def get_cleanup_matrices(self, m, delta=0, columns=None):
         """bluest/mosap.py:102-111: the per-output cleanup matrices stacked, (n_outputs*N, L).  Phi of every output comes
         from ONE launch of the shared plan; the per-group products run through the `cleanupK` kernel.
@@ -382,7 +402,7 @@ class MOSAP(object):
             ee = np.zeros((self.L,))
             ee[self.mappings[n]] = self.e[self.mappings[n]]
             es.append(ee)
-        alloc = SpgAllocator(self.plan, self.costs, es, verbose=False)
+        alloc = SpgAllocator(self.plan, self.costs, es, verbose=False, subplan=self._restricted_plan)
         try:
             samples = alloc.solve(budget=budget, eps=eps, x0=x0, params=solver_params)
         except BLUESTError as err:

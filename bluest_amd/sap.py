@@ -32,6 +32,11 @@ spg_sap_default_params = {
     "slots": 1,               # line-search trial points launched per iteration by the device loop (more on demand)
     "check_every": 20,        # iterations between host looks at the device state
     "scaling_floor": 1.0e-8,  # > 0: scaled SPG, steps and projections in the metric diag(1/max(x, floor)); 0: plain SPG
+    "polish": True,           # working set: run the last continuation stage on the plan restricted to the largest entries,
+    "polish_support": 8,      #   polish_support * N of them, price the excluded groups with the full gradient and let those
+    "polish_rounds": 2,       #   below the support's multiplier by price_tol (relative) join, at most polish_rounds times
+    "price_tol": 1.0e-3,
+    "polish_full_loose": 25.0, # stall tolerance of the full-problem stages in working-set mode, in units of rel_tol
     "sparsify_tol": 1.0e-5,   # final support selection: keep the fewest largest entries whose objective is within this (relative)
                               # of the full iterate's (0 = off)
     "prune_tol": 1.0e-7,      # (when that is off) drop the smallest entries holding less than this share of the budget
@@ -87,7 +92,8 @@ class SpgAllocator(object):
     (min cost s.t. V_o <= eps_o^2) is the B = 1 problem with s_o = eps_o^2 followed by a rescale.
     """
 
-    def __init__(self, plan, costs, e_list, verbose=False):
+    def __init__(self, plan, costs, e_list, verbose=False, subplan=None):
+        self.subplan = subplan     # callable(sorted global group indices) -> Plan restricted to those groups, or None
         self.plan = plan
         self.dev = plan.device
         self.costs = np.asarray(costs, dtype=np.float64)
@@ -192,44 +198,108 @@ class SpgAllocator(object):
             # pays: a restart typically gains another 1e-4 in the objective on these flat optima
             tot_it = tot_count = 0
 
-            def prune_dust(xc):
-                rel = float(prm["prune_rel"])
-                if rel <= 0.0:
-                    return xc
-                xp = torch.where(xc < rel * xc.max(), torch.zeros_like(xc), xc)
-                xp = xp / xp.sum()
-                vp, _, sp = plan.eval(scale * xp, want_grad=False)
-                v0, _, _ = plan.eval(scale * xc, want_grad=False)
-                ok = bool((sp == EVAL_OK).all()) and float((vp[0] / v0[0]).max()) <= 1.0 + 1.0e-6
-                return xp if ok else xc
+            def run_stages(pl, sc, xc, stages, polish_last, loose=5.0):
+                """the continuation stages on plan `pl` (variables scaled by `sc`) from xc; polish_last: the last stage gets the
+                restarts and the full stall tolerance"""
+                nonlocal tot_it, tot_count
 
-            # ONE solver object for all stages: the smoothing exponent lives in the device state, so the captured hipGraphs
-            # are shared by the stages (capturing them is a visible part of a 0.1 s solve)
-            dspg = DeviceSpg(plan, scale, s, p_list[0], floor, lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"],
-                             Hlength=prm["linesearch_history_length"], slots=prm["slots"], check_every=prm["check_every"])
-            for stage, pq in enumerate(p_list):
-                dspg.p = float(pq)
-                f_prev = None
-                last_stage = stage == len(p_list) - 1
-                # the earlier stages minimise a surrogate (a looser smooth max): one run to a 5x looser stall tolerance is all
-                # the warm start needs; the restarts and the full tolerance are spent on the last stage only
-                maxit_left = int(prm["maxit"]) - tot_it if last_stage else int(prm["maxit"]) // len(p_list)
-                for restart in range((int(prm["restarts"]) if last_stage else 0) + 1):
-                    if maxit_left <= 0:
+                def prune_dust(xq):
+                    rel = float(prm["prune_rel"])
+                    if rel <= 0.0:
+                        return xq
+                    xp = torch.where(xq < rel * xq.max(), torch.zeros_like(xq), xq)
+                    xp = xp / xp.sum()
+                    vp, _, sp = pl.eval(sc * xp, want_grad=False)
+                    v0, _, _ = pl.eval(sc * xq, want_grad=False)
+                    ok = bool((sp == EVAL_OK).all()) and float((vp[0] / v0[0]).max()) <= 1.0 + 1.0e-6
+                    return xp if ok else xq
+
+                # ONE solver object for all stages: the smoothing exponent lives in the device state, so the captured hipGraphs
+                # are shared by the stages (capturing them is a visible part of a 0.1 s solve)
+                dspg = DeviceSpg(pl, sc, s, stages[0], floor, lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"],
+                                 Hlength=prm["linesearch_history_length"], slots=prm["slots"], check_every=prm["check_every"])
+                out = None
+                for stage, pq in enumerate(stages):
+                    dspg.p = float(pq)
+                    f_prev = None
+                    last_stage = polish_last and stage == len(stages) - 1
+                    # the earlier stages minimise a surrogate (a looser smooth max): one run to a 5x looser stall tolerance is all
+                    # the warm start needs; the restarts and the full tolerance are spent on the last stage only
+                    maxit_left = int(prm["maxit"]) - tot_it if last_stage else int(prm["maxit"]) // len(p_list)
+                    for restart in range((int(prm["restarts"]) if last_stage else 0) + 1):
+                        if maxit_left <= 0:
+                            break
+                        out = dspg.run(xc, eps=prm["eps"], maxit=maxit_left, max_fevals=prm["max_fevals"],
+                                       rel_tol=prm["rel_tol"] * (1.0 if last_stage else loose), stall_window=prm["stall_window"])
+                        xc = prune_dust(out["x"])
+                        out["x"] = xc
+                        tot_it += out["it"]
+                        tot_count += out["count"]
+                        maxit_left -= out["it"]
+                        f_abs = out["f"]
+                        if out["solver_info"] == 0 and not out["stalled"]:
+                            break                                          # converged in the projected-gradient sense
+                        if f_prev is not None and f_prev - f_abs <= float(prm["restart_tol"]) * abs(f_abs):
+                            break
+                        f_prev = f_abs
+                return out
+
+            # (only for long vectors: below a few thousand groups the full problem is cheap and converges as well)
+            working_set = (bool(prm["polish"]) and self.subplan is not None
+                           and L > max(4096, 4 * int(prm["polish_support"]) * plan.N))
+            if not working_set:
+                res = run_stages(plan, scale, x, p_list, True)
+            else:
+                # WORKING SET: the smooth stages locate the support on the full problem; the last stage (the true max, where a
+                # first-order method crawls when it drags thousands of near-zero entries along) runs on the plan RESTRICTED to
+                # the largest entries; the full operator then prices the excluded groups at that point (entries whose scaled
+                # gradient lies below the support's multiplier would lower the objective) and they join the set for another
+                # round.  Restricted and full operator agree exactly on allocations supported on the set.
+                res = run_stages(plan, scale, x, p_list[:-1] if len(p_list) > 1 else p_list, False, loose=float(prm["polish_full_loose"]))
+                x = res["x"]
+                S = min(L, int(prm["polish_support"]) * plan.N)
+                keep = torch.sort(torch.argsort(x, descending=True)[:S]).values
+                s_dev = torch.from_numpy(s).to(self.dev)
+                # on the restricted plan an iteration is cheap, so the sharp smooth max goes first again (the plain max alone
+                # stalls in its line search at the kinks); the best point by the TRUE objective over all rounds is returned
+                sub_stages = ([p for p in p_list if np.isfinite(p)][-1:] + [p_list[-1]]) if np.isinf(p_list[-1]) and len(p_list) > 1 else p_list[-1:]
+                best_x, best_f, best_res = None, np.inf, None
+                for rnd in range(int(prm["polish_rounds"])):
+                    try:
+                        sub = self.subplan(keep.cpu().numpy())
+                    except BLUESTError:
+                        sub = None
+                    if sub is None:
+                        res = run_stages(plan, scale, x, p_list[-1:], True)      # cannot restrict (an output would lose model 0)
+                        x = res["x"]
                         break
-                    res = dspg.run(x, eps=prm["eps"], maxit=maxit_left, max_fevals=prm["max_fevals"],
-                                   rel_tol=prm["rel_tol"] * (1.0 if last_stage else 5.0), stall_window=prm["stall_window"])
-                    x = prune_dust(res["x"])
-                    res["x"] = x
-                    tot_it += res["it"]
-                    tot_count += res["count"]
-                    maxit_left -= res["it"]
-                    f_abs = res["f"]
-                    if res["solver_info"] == 0 and not res["stalled"]:
-                        break                                          # converged in the projected-gradient sense
-                    if f_prev is not None and f_prev - f_abs <= float(prm["restart_tol"]) * abs(f_abs):
+                    xs_sub = x[keep] / x[keep].sum()
+                    res = run_stages(sub, scale[keep], xs_sub, sub_stages, True)
+                    x = torch.zeros_like(x)
+                    x[keep] = res["x"]
+                    # pricing with the gradient of a sharp smooth max at the polished point
+                    var, grad, status = plan.eval(scale * x)
+                    r = var[0] / s_dev
+                    if float(r.max()) < best_f:
+                        best_x, best_f, best_res = x.clone(), float(r.max()), res
+                    q = (r / r.max()) ** 2047.0
+                    coef = (q / (q * (r / r.max())).sum() ** (1.0 - 1.0 / 2048.0)) / s_dev
+                    g = plan.combine_grad(grad, coef.reshape(1, -1), scale=scale)[0]
+                    theta = float((g[keep] * x[keep]).sum())                      # multiplier of sum x = 1 on the support
+                    viol = g - theta
+                    viol[keep] = 0.0
+                    enter = torch.nonzero(viol < -float(prm["price_tol"]) * abs(theta)).flatten()
+                    if len(enter) == 0:
                         break
-                    f_prev = f_abs
+                    if len(enter) > S // 2:
+                        enter = enter[torch.argsort(viol[enter])[:S // 2]]
+                    keep = torch.sort(torch.cat([keep[x[keep] > 0], enter])).values
+                    x[enter] = 1.0e-6 / max(len(enter), 1)                        # seed: the scaled metric moves zeros slowly
+                    x = x / x.sum()
+                if best_x is not None:
+                    x, res = best_x, best_res
+                res = dict(res)
+                res["x"] = x
             st["norm"] = res["norm"]
             res["f"] = res["f"] / res["norm"]
             res["it"], res["count"] = tot_it, tot_count
@@ -371,6 +441,21 @@ class SAP(object):
         self.variance = variance
         self.variance_GH = variance_GH
 
+    def _restricted_plan(self, keep):
+        """plan of this problem restricted to the groups `keep` (sorted global indices); the stored pseudo-inverses are reused"""
+        keep = np.asarray(keep, dtype=np.int64)
+        groups, invcovs, sizes = [], [], []
+        for k in range(1, self.K + 1):
+            lo, hi = self.cumsizes[k - 1], self.cumsizes[k]
+            sel = keep[(keep >= lo) & (keep < hi)] - lo
+            groups.append(np.asarray(self.groups[k - 1]).reshape(-1, k)[sel])
+            invcovs.append(np.asarray(self.invcovs[k - 1]).reshape(-1, k * k)[sel].ravel())
+            sizes.append(len(sel))
+        if not any(len(g) and (g == 0).any() for g in groups):
+            raise BLUESTError("restricted plan would not sample model 0")
+        return Plan(self.N, len(keep), [{"K": self.K, "sizes": sizes, "groups": groups, "invcovs": invcovs, "mapping": None}],
+                    max_candidates=1, device=self.plan.device)
+
     def get_cleanup_matrix(self, m, delta=0):
         """bluest/misc.py:507-516 (`assemble_cleanup_matrix`), bluest/sap.py:137-138: X[:, i] = R_i^T C_i^-1 (pinv(Phi)[0])_g --
         allocations that differ by a null vector of X have the same estimator variance to first order"""
@@ -455,7 +540,7 @@ class SAP(object):
             if eps is None: print("Minimizing statistical error for fixed cost...\n")
             else:           print("Minimizing cost given statistical error tolerance...\n")
 
-        alloc = SpgAllocator(self.plan, self.costs, [self.e], verbose=False)
+        alloc = SpgAllocator(self.plan, self.costs, [self.e], verbose=False, subplan=self._restricted_plan)
         try:
             samples = alloc.solve(budget=budget, eps=None if eps is None else [eps], x0=x0, params=solver_params)
         except BLUESTError as err:

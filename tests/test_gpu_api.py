@@ -217,3 +217,45 @@ def test_greedy_integer_rounding_is_feasible_and_close():
     assert me @ mos.costs * (1 - 1e-3) <= mj @ mos.costs <= me @ mos.costs * 1.02
     for n_ in range(n_out):
         assert mj[mos.mappings[n_]] @ mos.e[mos.mappings[n_]] >= 1 and mi[mos.mappings[n_]] @ mos.e[mos.mappings[n_]] >= 1
+
+
+def test_working_set_polish():
+    """(a) the plan restricted to a subset of the groups is the same operator on allocations supported there (identity and
+    ragged mappings); (b) the working-set last stage ends at an objective no worse than the plain run, on far fewer groups"""
+    from bluest_amd.mosap import MOSAP
+    from conftest import golden
+    rng = np.random.RandomState(3)
+    # (a) ragged mappings: the golden multi-output problem
+    G = golden("mosap_n6_o3_ragged.npz")
+    n, n_out, kmax = int(G["n"]), int(G["n_out"]), int(G["kmax"])
+    prob = synth.problem(n, kmax, n_out)
+    groups = [G["g_k%d" % k].tolist() for k in range(1, kmax + 1)]
+    multi_groups = [[G["mg%d_k%d" % (o, k)].tolist() for k in range(1, kmax + 1)] for o in range(n_out)]
+    costs = synth.group_costs([np.array(g) for g in groups], prob["w"])
+    multi_costs = [synth.group_costs([np.array(g) for g in mg], prob["w"]) for mg in multi_groups]
+    mos = MOSAP(prob["C"], kmax, [kmax] * n_out, groups, multi_groups, costs, multi_costs, verbose=False)
+    keep = np.sort(np.concatenate([np.flatnonzero(mos.e > 0), rng.choice(mos.L, 12, replace=False)]))
+    keep = np.unique(keep)
+    sub = mos._restricted_plan(keep)
+    m_sub = 0.5 + 5 * rng.rand(len(keep))
+    m_full = np.zeros(mos.L)
+    m_full[keep] = m_sub
+    import torch
+    v_sub, g_sub, st_sub = sub.eval(torch.from_numpy(m_sub).to(sub.device))
+    assert np.abs(v_sub[0].cpu().numpy() / np.array(mos.variances(m_full)) - 1).max() < 1e-12
+    _, grads, _ = mos.variance_GH(m_full, nohess=True)
+    gs = g_sub[0].cpu().numpy()
+    for o in range(n_out):
+        inside = np.isin(mos.mappings[o], keep)
+        assert np.abs(gs[sub.grad_off[o]:sub.grad_off[o] + inside.sum()] - grads[o][inside]).max() <= 1e-12 * np.abs(grads[o]).max()
+    # (b) a problem long enough for the working set to switch on (K_tot = 6884 > 4096)
+    n, kmax, n_out = 16, 5, 2
+    prob = synth.problem(n, kmax, n_out)
+    g16 = prob["groups"]
+    mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in g16], [[g.copy() for g in g16] for _ in range(n_out)],
+                prob["costs"], [prob["costs"]] * n_out, verbose=False)
+    m_p = mos.solve(budget=prob["budget"], solver="spg", continuous_relaxation=True)
+    m_n = mos.solve(budget=prob["budget"], solver="spg", continuous_relaxation=True, solver_params={"polish": False})
+    Vp, Vn = max(mos.variances(m_p)), max(mos.variances(m_n))
+    assert abs(m_p @ prob["costs"] / prob["budget"] - 1) < 1e-9 and (m_p >= 0).all()
+    assert Vp <= Vn * (1 + 2e-5) and (m_p > 0).sum() <= 8 * n

@@ -6,8 +6,8 @@ metric   : Phi-assemblies/s.  One assembly = for ONE output, build Phi(m) over a
            V = e0^T Phi^-1 e0 and evaluate grad V for every group.
 workload : BASELINE.json configs[3]: n=20 models, groups up to size 5 (K_tot=21699), n_out=8 outputs,
            synthetic Wishart covariances (bluest_amd/synth.py).  A "step" evaluates one allocation vector m for
-           all 8 outputs (what one SPG iteration / one MOSAP.variance_GH call does): 3 kernel launches
-           (Phi chunks -> fold+solve -> gradient tiles), inputs resident in HBM, results left in HBM.
+           all 8 outputs (what one SPG iteration / one MOSAP.variance_GH call does): 2 kernel launches
+           (Phi chunks -> fused fold + solve + gradient tiles), inputs resident in HBM, results left in HBM.
 N > 1    : one process per GPU.  Three ways to use more than one GPU:
            --shard candidates (default): the unit of work is the evaluation of one allocation vector; independent vectors
              (line-search trial points, integer-projection candidates, budget / tolerance sweeps) are the partition of the

@@ -3,7 +3,7 @@ Integer projection of a continuous allocation: same
 bluest/misc.py:141-167 (bounds), :228-311 (multi-output brute force), :313-382 (single output), with the fallback
 ladders of bluest/sap.py:145-187 and bluest/mosap.py:212-289 -- but the heavy step, forming
 phis = basephi + psi[:, idx] @ ms for up to 2^LL candidates and taking pinv(phis)[:,0,0] (misc.py:293-294, 368-369),
-runs on the GPU (`bluest_intproj_eval`: one wavefront per candidate and output, register-resident Cholesky).
+runs on the GPU (`bluest_intproj_eval`: one wavefront per candidate and output, register-resident Gauss-Jordan solve).
 
 The candidate enumeration and the linear filters (model-0 constraint, budget, ordering) are host numpy on <= 2^20
 small integers per chunk, written to keep the reference's selection rule (including its ordering of candidates).

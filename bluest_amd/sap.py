@@ -36,6 +36,9 @@ spg_sap_default_params = {
     "polish_support": 8,      #   polish_support * N of them, price the excluded groups with the full gradient and let those
     "polish_rounds": 2,       #   below the support's multiplier by price_tol (relative) join, at most polish_rounds times
     "price_tol": 1.0e-3,
+    "polish_stages": (2048.0, 65536.0),  # smoothing exponents on the working set (multi-output): 65536 is the max for all
+                              # practical purposes but keeps near-ties smooth -- the plain max there cost 40 % more time on the
+                              # hard cases (line-search stalls at the kinks) for objectives equal to 1e-5
     "polish_full_loose": 25.0, # stall tolerance of the full-problem stages in working-set mode, in units of rel_tol
     "sparsify_tol": 1.0e-5,   # final support selection: keep the fewest largest entries whose objective is within this (relative)
                               # of the full iterate's (0 = off)
@@ -263,6 +266,8 @@ class SpgAllocator(object):
                 # on the restricted plan an iteration is cheap, so the sharp smooth max goes first again (the plain max alone
                 # stalls in its line search at the kinks); the best point by the TRUE objective over all rounds is returned
                 sub_stages = ([p for p in p_list if np.isfinite(p)][-1:] + [p_list[-1]]) if np.isinf(p_list[-1]) and len(p_list) > 1 else p_list[-1:]
+                if prm.get("polish_stages"):
+                    sub_stages = [float(q) for q in prm["polish_stages"]] if n_out > 1 else [np.inf]
                 best_x, best_f, best_res = None, np.inf, None
                 for rnd in range(int(prm["polish_rounds"])):
                     try:
@@ -270,11 +275,16 @@ class SpgAllocator(object):
                     except BLUESTError:
                         sub = None
                     if sub is None:
-                        res = run_stages(plan, scale, x, p_list[-1:], True)      # cannot restrict (an output would lose model 0)
-                        x = res["x"]
+                        res_full = run_stages(plan, scale, x, p_list[-1:], True)  # cannot restrict (an output would lose model 0)
+                        if res_full is not None:
+                            res = res_full
+                            x = res["x"]
                         break
                     xs_sub = x[keep] / x[keep].sum()
-                    res = run_stages(sub, scale[keep], xs_sub, sub_stages, True)
+                    res_sub = run_stages(sub, scale[keep], xs_sub, sub_stages, True)
+                    if res_sub is None:                                           # iteration budget (maxit) exhausted
+                        break
+                    res = res_sub
                     x = torch.zeros_like(x)
                     x[keep] = res["x"]
                     # pricing with the gradient of a sharp smooth max at the polished point

@@ -91,6 +91,13 @@ class DeviceSpg(object):
         self._iteration()
         self._converged()
 
+    def _window(self):
+        """check_every iterations, the last one with the convergence projection: ONE graph replay per host look
+        (a replay per iteration costs ~8 us more per iteration in launch overhead, tools/spg_floor.py)"""
+        for _ in range(self.check_every - 1):
+            self._iteration()
+        self._iteration_checked()
+
     def _capture(self, fn):
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
@@ -158,6 +165,7 @@ class DeviceSpg(object):
                     """launchers for the current number of slots self.T; every hipGraph is captured when it is first needed
                     (the continuation graphs `slots` / `finish` only if a line search ever overflows its slots)"""
                     if not use_graph:
+                        self.run_window = self._window
                         return self._iteration, self._slots, self._finish, self._iteration_checked
                     gs = self.graph_sets.setdefault(self.T, {})
 
@@ -168,6 +176,7 @@ class DeviceSpg(object):
                             gs[name].replay()
                         return replay
                     self.graphs = gs
+                    self.run_window = lazy("window", self._window)
                     return (lazy("iteration", self._iteration), lazy("slots", self._slots), lazy("finish", self._finish),
                             lazy("iteration_checked", self._iteration_checked))
 
@@ -193,9 +202,12 @@ class DeviceSpg(object):
                         info = 1
                         break
                     nrun = min(self.check_every, maxit - it)
-                    for _ in range(nrun - 1):
-                        run_iter()
-                    run_iter_checked()                          # last one also measures gpmax (sets DONE when <= eps)
+                    if nrun == self.check_every:
+                        self.run_window()                       # the whole window is one graph
+                    else:
+                        for _ in range(nrun - 1):
+                            run_iter()
+                        run_iter_checked()                      # last one also measures gpmax (sets DONE when <= eps)
                     hs = st.cpu().numpy()
                     fail_windows.append(hs[FAIL] != 0.0)
                     while hs[FAIL] != 0.0:                       # rare: more than T trial points needed

@@ -36,6 +36,7 @@ spg_sap_default_params = {
     "polish_support": 8,      #   polish_support * N of them, price the excluded groups with the full gradient and let those
     "polish_rounds": 2,       #   below the support's multiplier by price_tol (relative) join, at most polish_rounds times
     "price_tol": 1.0e-3,
+    "polish_stall_window": 100,   # stall window (iterations) of the runs on the working set
     "polish_stages": (2048.0, 65536.0),  # smoothing exponents on the working set (multi-output): 65536 is the max for all
                               # practical purposes but keeps near-ties smooth -- the plain max there cost 40 % more time on the
                               # hard cases (line-search stalls at the kinks) for objectives equal to 1e-5
@@ -201,7 +202,7 @@ class SpgAllocator(object):
             # pays: a restart typically gains another 1e-4 in the objective on these flat optima
             tot_it = tot_count = 0
 
-            def run_stages(pl, sc, xc, stages, polish_last, loose=5.0):
+            def run_stages(pl, sc, xc, stages, polish_last, loose=5.0, window=None):
                 """the continuation stages on plan `pl` (variables scaled by `sc`) from xc; polish_last: the last stage gets the
                 restarts and the full stall tolerance"""
                 nonlocal tot_it, tot_count
@@ -233,7 +234,8 @@ class SpgAllocator(object):
                         if maxit_left <= 0:
                             break
                         out = dspg.run(xc, eps=prm["eps"], maxit=maxit_left, max_fevals=prm["max_fevals"],
-                                       rel_tol=prm["rel_tol"] * (1.0 if last_stage else loose), stall_window=prm["stall_window"])
+                                       rel_tol=prm["rel_tol"] * (1.0 if last_stage else loose),
+                                       stall_window=prm["stall_window"] if window is None else window)
                         xc = prune_dust(out["x"])
                         out["x"] = xc
                         tot_it += out["it"]
@@ -281,7 +283,7 @@ class SpgAllocator(object):
                             x = res["x"]
                         break
                     xs_sub = x[keep] / x[keep].sum()
-                    res_sub = run_stages(sub, scale[keep], xs_sub, sub_stages, True)
+                    res_sub = run_stages(sub, scale[keep], xs_sub, sub_stages, True, window=int(prm["polish_stall_window"]))
                     if res_sub is None:                                           # iteration budget (maxit) exhausted
                         break
                     res = res_sub

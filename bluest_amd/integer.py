@@ -15,7 +15,6 @@ import torch
 from . import _lib
 from ._lib import check
 from .plan import _stream
-from .sap import BLUESTError
 
 CHUNK_BITS = 18   # candidates generated / evaluated per chunk: 2^18
 

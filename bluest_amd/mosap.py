@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import misc
-from .plan import EVAL_INF, EVAL_NO_MODEL0, EVAL_OK, EVAL_SINGULAR, Plan
+from .plan import EVAL_INF, EVAL_SINGULAR, Plan
 from .sap import BLUESTError, SAP, SpgAllocator, indicator_vectors, normalise_groups, status_to_python
 
 

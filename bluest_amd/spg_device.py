@@ -14,7 +14,6 @@ import gc
 import numpy as np
 import torch
 
-from . import _lib
 from ._lib import check
 from .plan import EVAL_OK, _stream, projection_workspace, simplex_project
 

@@ -441,9 +441,9 @@ __global__ void k_combine_grad(const double *__restrict__ grad, int64_t grad_str
 // ------------------------------------------------------------------------------------------------------
 static void plan_free_device(bluest_plan_s *p)
 {
-    void *ptrs[] = {p->d_vals, p->d_cols, p->d_rows, p->d_out_row_begin, p->d_tiles, p->d_tvals, p->d_tidx,
-                    p->d_invmap, p->d_goff, p->d_partial, p->d_v, p->d_status};
-    for (void *q : ptrs) if (q) (void)hipFree(q);
+    if (p->d_arena) (void)hipFree(p->d_arena);
+    if (p->d_scratch) (void)hipFree(p->d_scratch);
+    p->d_arena = p->d_scratch = nullptr;
 }
 
 extern "C" int bluest_plan_create(bluest_plan_t *plan, int n_models, int64_t L_global)
@@ -528,12 +528,19 @@ extern "C" int bluest_plan_add_output_cov(bluest_plan_t plan, const double *C, i
     int64_t ni = 0, ng = 0;
     for (int k = 1; k <= K; k++) { ni += sizes[k - 1] * k * k; ng += sizes[k - 1] * k; }
     od.invcovs.resize(ni);
-    double *dC = nullptr, *dic = nullptr;
-    int64_t *dg = nullptr;
-    HIP_TRY(hipMalloc((void **)&dC, (size_t)N * N * sizeof(double)));
-    hipError_t e = hipMalloc((void **)&dic, (size_t)ni * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&dg, (size_t)ng * sizeof(int64_t));
-    if (e == hipSuccess) e = hipMemcpy(dC, C, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice);
+    // scratch = [C | inverses | groups], kept for the next output (freed by finalize)
+    const size_t offC = 0, offI = ((size_t)N * N * sizeof(double) + 255) / 256 * 256;
+    const size_t offG = offI + ((size_t)ni * sizeof(double) + 255) / 256 * 256;
+    const size_t need = offG + (size_t)ng * sizeof(int64_t);
+    if (need > plan->scratch_bytes) {
+        if (plan->d_scratch) (void)hipFree(plan->d_scratch);
+        plan->d_scratch = nullptr; plan->scratch_bytes = 0;
+        HIP_TRY(hipMalloc(&plan->d_scratch, need));
+        plan->scratch_bytes = need;
+    }
+    double *dC = reinterpret_cast<double *>((char *)plan->d_scratch + offC), *dic = reinterpret_cast<double *>((char *)plan->d_scratch + offI);
+    int64_t *dg = reinterpret_cast<int64_t *>((char *)plan->d_scratch + offG);
+    hipError_t e = hipMemcpy(dC, C, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dg, groups, (size_t)ng * sizeof(int64_t), hipMemcpyHostToDevice);
     rc = BLUEST_OK;
     if (e == hipSuccess) {
@@ -545,8 +552,7 @@ extern "C" int bluest_plan_add_output_cov(bluest_plan_t plan, const double *C, i
         }
         if (rc == BLUEST_OK) e = hipMemcpy(od.invcovs.data(), dic, (size_t)ni * sizeof(double), hipMemcpyDeviceToHost);
     }
-    (void)hipFree(dC); (void)hipFree(dic); (void)hipFree(dg);
-    timer.lap("device pinv round trip (malloc, H2D, kernels, D2H, free)");
+    timer.lap("device pinv round trip (H2D, kernels, D2H)");
     if (rc) return rc;
     HIP_TRY(e);
     if (invcovs_out) memcpy(invcovs_out, od.invcovs.data(), (size_t)ni * sizeof(double));
@@ -554,12 +560,16 @@ extern "C" int bluest_plan_add_output_cov(bluest_plan_t plan, const double *C, i
     return BLUEST_OK;
 }
 
+// the plan's device arrays live in one arena: reserve() collects sizes, then every array is copied to its slot
+struct Arena {
+    size_t bytes = 0;
+    char *base = nullptr;
+    size_t reserve(size_t n) { const size_t off = bytes; bytes += (std::max<size_t>(n, 1) + 255) / 256 * 256; return off; }
+};
 template <typename T>
-static int upload(T **dst, const std::vector<T> &src)
+static int upload(Arena &arena, size_t off, T **dst, const std::vector<T> &src)
 {
-    *dst = nullptr;
-    const size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
-    HIP_TRY(hipMalloc((void **)dst, bytes));
+    *dst = reinterpret_cast<T *>(arena.base + off);
     if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
     return BLUEST_OK;
 }
@@ -785,18 +795,30 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
 
     timer.lap("tiles + inverse maps");
     int rc;
-    if ((rc = upload(&plan->d_vals, vals))) return rc;
-    if ((rc = upload(&plan->d_cols, cols))) return rc;
-    if ((rc = upload(&plan->d_rows, rows))) return rc;
-    if ((rc = upload(&plan->d_out_row_begin, out_row_begin))) return rc;
-    if ((rc = upload(&plan->d_tiles, tiles))) return rc;
-    if ((rc = upload(&plan->d_tvals, tvals))) return rc;
-    if ((rc = upload(&plan->d_tidx, tidx))) return rc;
-    if ((rc = upload(&plan->d_invmap, invmap))) return rc;
-    if ((rc = upload(&plan->d_goff, plan->grad_off))) return rc;
-    HIP_TRY(hipMalloc((void **)&plan->d_partial, (size_t)max_candidates * n_chunks * sizeof(double2)));
-    HIP_TRY(hipMalloc((void **)&plan->d_v, (size_t)max_candidates * n_out * N * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&plan->d_status, (size_t)max_candidates * n_out * sizeof(int32_t)));
+    if (plan->d_scratch) { (void)hipFree(plan->d_scratch); plan->d_scratch = nullptr; plan->scratch_bytes = 0; }
+    Arena arena;
+    const size_t o_vals = arena.reserve(vals.size() * sizeof(double)), o_cols = arena.reserve(cols.size() * sizeof(int32_t));
+    const size_t o_rows = arena.reserve(rows.size() * sizeof(RowDesc)), o_orb = arena.reserve(out_row_begin.size() * sizeof(int32_t));
+    const size_t o_tiles = arena.reserve(tiles.size() * sizeof(TileDesc)), o_tvals = arena.reserve(tvals.size() * sizeof(double));
+    const size_t o_tidx = arena.reserve(tidx.size()), o_invmap = arena.reserve(invmap.size() * sizeof(int32_t));
+    const size_t o_goff = arena.reserve(plan->grad_off.size() * sizeof(int64_t));
+    const size_t o_partial = arena.reserve((size_t)max_candidates * n_chunks * sizeof(double2));
+    const size_t o_v = arena.reserve((size_t)max_candidates * n_out * N * sizeof(double));
+    const size_t o_status = arena.reserve((size_t)max_candidates * n_out * sizeof(int32_t));
+    HIP_TRY(hipMalloc(&plan->d_arena, arena.bytes));
+    arena.base = (char *)plan->d_arena;
+    if ((rc = upload(arena, o_vals, &plan->d_vals, vals))) return rc;
+    if ((rc = upload(arena, o_cols, &plan->d_cols, cols))) return rc;
+    if ((rc = upload(arena, o_rows, &plan->d_rows, rows))) return rc;
+    if ((rc = upload(arena, o_orb, &plan->d_out_row_begin, out_row_begin))) return rc;
+    if ((rc = upload(arena, o_tiles, &plan->d_tiles, tiles))) return rc;
+    if ((rc = upload(arena, o_tvals, &plan->d_tvals, tvals))) return rc;
+    if ((rc = upload(arena, o_tidx, &plan->d_tidx, tidx))) return rc;
+    if ((rc = upload(arena, o_invmap, &plan->d_invmap, invmap))) return rc;
+    if ((rc = upload(arena, o_goff, &plan->d_goff, plan->grad_off))) return rc;
+    plan->d_partial = reinterpret_cast<double2 *>(arena.base + o_partial);
+    plan->d_v = reinterpret_cast<double *>(arena.base + o_v);
+    plan->d_status = reinterpret_cast<int32_t *>(arena.base + o_status);
     plan->finalized = true;
     timer.lap("uploads + device allocations");
     // host copies of the reference-layout inputs are no longer needed

@@ -48,6 +48,9 @@ struct bluest_plan_s {
     int64_t *d_goff = nullptr;
     double2 *d_partial = nullptr;
     double *d_v = nullptr;       // workspace for eval
+    void *d_arena = nullptr;     // ONE device allocation behind all the d_* arrays (hipMalloc is 1-3 ms a piece on a busy process)
+    void *d_scratch = nullptr;   // set-up scratch of bluest_plan_add_output_cov (C, groups, inverses), reused across outputs
+    size_t scratch_bytes = 0;
     int32_t *d_status = nullptr; // workspace for eval when caller passes NULL
 };
 

@@ -2,6 +2,7 @@
 """SAP wall-clock (second half of BASELINE.json's metric): covariance -> continuous optimum m*, setup included.
     python tools/sap_wallclock.py [n kmax n_out]
 Also prints the PCIe-inclusive rate of the operator when handed numpy arrays."""
+import gc
 import json
 import sys
 import time
@@ -22,6 +23,8 @@ out = {"n": n, "kmax": kmax, "n_out": n_out, "K_tot": prob["K_tot"]}
 mos = None
 for rep in range(2):        # second repetition = warm (library loaded, allocator warm)
     mos = None              # release the previous plan (hipFree of ~45 MB) outside the timed region
+    gc.collect()            # as timeit does: no cyclic-GC pause (30-70 ms with torch loaded) inside a 0.25 s measurement
+    gc.disable()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in groups] for _ in range(n_out)],
@@ -31,6 +34,7 @@ for rep in range(2):        # second repetition = warm (library loaded, allocato
     m = mos.solve(budget=prob["budget"], solver="spg", continuous_relaxation=True)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
+    gc.enable()
     out["rep%d" % rep] = {"setup_s": t1 - t0, "solve_s": t2 - t1, "total_s": t2 - t0, "max_V": max(mos.variances(m)),
                           "nnz": int((m > 1e-9 * m.max()).sum()), "info": {k: (float(v) if not isinstance(v, int) else v) for k, v in mos.solver_info.items()}}
 # PCIe-inclusive operator rate with numpy in / numpy out

@@ -38,6 +38,19 @@ def logged(self, x0, **kw):
 
 
 spg_device.DeviceSpg.run = logged
+orig_capture = spg_device.DeviceSpg._capture
+
+
+def timed_capture(self, fn):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g = orig_capture(self, fn)
+    torch.cuda.synchronize()
+    print("    capture %-20s L=%d T=%d: %.1f ms" % (fn.__name__, self.L, self.T, 1e3 * (time.perf_counter() - t0)))
+    return g
+
+
+spg_device.DeviceSpg._capture = timed_capture
 for rep in range(2):
     t0 = time.perf_counter()
     m = mos.solve(budget=prob["budget"], solver="spg", continuous_relaxation=True, solver_params=params or None)

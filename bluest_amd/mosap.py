@@ -12,7 +12,7 @@ import torch
 
 from . import misc
 from .plan import EVAL_INF, EVAL_SINGULAR, Plan
-from .sap import BLUESTError, SAP, SpgAllocator, indicator_vectors, normalise_groups, status_to_python
+from .sap import BLUESTError, LazyIndicators, SAP, SpgAllocator, normalise_groups, status_to_python
 
 
 def _group_keys(gk, N):
@@ -123,7 +123,7 @@ class _SapView(SAP):
             invcovs.append(flat[off:off + cnt] if cnt > 0 else np.array([]))
             off += cnt
         self.invcovs = invcovs
-        self.ES = indicator_vectors(groups, self.N)
+        self.ES = LazyIndicators(groups, self.N)
         self.e = self.ES[0]
         self._psi = None
         self._plan = None
@@ -167,7 +167,7 @@ class MOSAP(object):
         self.sizes = [0] + [len(groupsk) for groupsk in groups]
         self.cumsizes = np.cumsum(self.sizes)
         self.L = int(self.cumsizes[-1])
-        self.ES = [es.astype(np.int64) for es in indicator_vectors(groups, self.N)]
+        self.ES = LazyIndicators(groups, self.N)
         self.e = self.ES[0]
         self.mappings = build_mappings(groups, multi_groups, self.cumsizes, self.N)  # m[mappings[n]] = m_n
 

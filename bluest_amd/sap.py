@@ -67,6 +67,36 @@ def normalise_groups(groups, K, flatten=True):
     return flattened
 
 
+class LazyIndicators(object):
+    """the list ES of the reference (sap.py:89-95): ES[i][j] = 1 if model i is in group j.  Only ES[0] (= `e`, the model-0
+    constraint) is needed on the path; the N x L table (49 MB at K_tot = 245505) is built when somebody asks for another row."""
+
+    def __init__(self, groups, N, dtype=np.int64):
+        self._groups, self._N, self._dtype, self._all = groups, N, dtype, None
+        L = sum(len(g) for g in groups)
+        e = np.zeros(L, dtype=dtype)
+        off = 0
+        for gk in groups:
+            gk = np.asarray(gk)
+            if len(gk):
+                e[off:off + len(gk)] = (gk == 0).any(axis=1)
+            off += len(gk)
+        self.e = e
+
+    def _table(self):
+        if self._all is None:
+            self._all = [row.astype(self._dtype) for row in indicator_vectors(self._groups, self._N)]
+        return self._all
+
+    def __getitem__(self, i):
+        if isinstance(i, (int, np.integer)) and i == 0:
+            return self.e
+        return self._table()[i]
+
+    def __len__(self): return self._N
+    def __iter__(self): return iter(self._table())
+
+
 def indicator_vectors(groups, N):
     """ES[i][j] = 1 if model i is in group j (sap.py:89-95), vectorised"""
     L = sum(len(g) for g in groups)
@@ -402,7 +432,7 @@ class SAP(object):
             off += n
         self.invcovs = invcovs
 
-        self.ES = indicator_vectors(groups, self.N)
+        self.ES = LazyIndicators(groups, self.N)
         self.e = self.ES[0]
         self._psi = None
         self.get_variance_functions()

@@ -22,6 +22,10 @@ def test_indicator_vectors_and_mappings():
     assert all(isinstance(g, np.ndarray) and g.dtype == np.int64 for g in groups)
     ES = indicator_vectors(groups, 3)
     assert (ES[0] == [1, 0, 0, 1, 1, 0, 1]).all() and (ES[2] == [0, 0, 1, 0, 1, 1, 1]).all()
+    from bluest_amd.sap import LazyIndicators
+    lazy = LazyIndicators(groups, 3)
+    assert lazy._all is None and (lazy[0] == ES[0]).all() and lazy._all is None      # row 0 without building the table
+    assert (lazy[2] == ES[2]).all() and len(lazy) == 3 and all((a == b).all() for a, b in zip(lazy, ES))
     cum = np.cumsum([0, 3, 3, 1])
     mg = [[np.array([[0], [2]]), np.array([[1, 2]]), np.zeros((0, 3), dtype=np.int64)],
           [np.array([[1]]), np.array([[0, 1], [0, 2]]), np.array([[0, 1, 2]])]]

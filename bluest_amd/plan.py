@@ -205,5 +205,5 @@ def projection_workspace(L, device):
     if key not in _WORKSPACES:
         n = ctypes.c_int64(0)
         check(_lib.lib().bluest_simplex_workspace_doubles(int(L), ctypes.byref(n)))
-        _WORKSPACES[key] = torch.zeros(n.value, dtype=torch.float64, device=device)
+        _WORKSPACES[key] = torch.from_numpy(np.zeros(n.value)).to(device)     # zero-filled once (tag 0 = empty mailbox)
     return _WORKSPACES[key]

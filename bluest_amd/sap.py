@@ -135,10 +135,192 @@ class SpgAllocator(object):
         self.e_list = e_list  # per output: indicator (global numbering) of groups containing model 0
         self.verbose = verbose
 
+    def _solve_device(self, budget, eps, x0, prm):
+        """solve() with the device-resident loop.  All vector bookkeeping between the runs (pruning, support selection, pricing)
+        is numpy on the host: the vectors are <= a few MB, and no torch compute operator is touched -- on ROCm the first use
+        of each one loads its kernels (30-150 ms a piece), which used to triple the first solve of a process."""
+        from .spg_device import DeviceSpg
+        plan, dev = self.plan, self.dev
+        n_out, L, N = plan.n_out, plan.L, plan.N
+        s = np.ones(n_out) if budget is not None else np.asarray(eps, dtype=np.float64) ** 2
+        w = self.costs
+
+        def to_dev(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+
+        def ratios(pl, m_h):
+            """max_o V_o/s_o of allocation m_h on plan pl (inf if not evaluable)"""
+            var, _, status = pl.eval(m_h, want_grad=False)
+            if not (status[0].cpu().numpy() == EVAL_OK).all():
+                return np.inf
+            r = var[0].cpu().numpy() / s
+            return float(r.max()) if np.isfinite(r).all() else np.inf
+
+        if budget is not None:
+            B = float(budget)
+        else:
+            # eps mode: pick the working budget so that the uniform start already has max_o V_o/eps_o^2 ~ 1; sample counts
+            # then have their real magnitude for the reference's absolute thresholds (|m| > 1e-6, max|m| >= 0.05)
+            B_try = 1.0e6 * float(w.max())
+            r_try = ratios(plan, np.full(L, 1.0 / L) * (B_try / w))
+            if not np.isfinite(r_try):
+                raise BLUESTError("SPG: the uniform allocation is infeasible (model 0 unsampled or singular information matrix)")
+            B = B_try * r_try
+        p_list = prm["smoothing_p"] if isinstance(prm["smoothing_p"], (list, tuple)) else [prm["smoothing_p"]]
+        p_list = [float(q) for q in p_list] if n_out > 1 else [np.inf]
+        scale_h = B / w                                            # m = scale * x
+        scale = to_dev(scale_h)
+        floor = float(prm["scaling_floor"])
+        x = np.full(L, 1.0 / L) if x0 is None else np.asarray(x0, dtype=np.float64) * w / B
+        x = simplex_project(to_dev(x), want_d=False)[0].cpu().numpy()
+        if not np.isfinite(ratios(plan, scale_h * x)):
+            raise BLUESTError("SPG: the initial allocation does not sample model 0 / is infeasible")
+        tot = {"it": 0, "count": 0}
+
+        def run_stages(pl, sc_h, sc, xc, stages, polish_last, loose=5.0, window=None):
+            """the continuation stages on plan `pl` (variables scaled by sc) from xc; polish_last: the last stage gets the
+            restarts and the full stall tolerance.  Returns the last run's result (x as numpy), or None without budget left"""
+            def prune_dust(xq):
+                rel = float(prm["prune_rel"])
+                if rel <= 0.0:
+                    return xq
+                xp = np.where(xq < rel * xq.max(), 0.0, xq)
+                xp = xp / xp.sum()
+                return xp if ratios(pl, sc_h * xp) <= ratios(pl, sc_h * xq) * (1.0 + 1.0e-6) else xq
+
+            # ONE solver object for all stages: the smoothing exponent lives in the device state, so the captured hipGraphs
+            # are shared by the stages
+            dspg = DeviceSpg(pl, sc, s, stages[0], floor, lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"],
+                             Hlength=prm["linesearch_history_length"], slots=prm["slots"], check_every=prm["check_every"])
+            out = None
+            for stage, pq in enumerate(stages):
+                dspg.p = float(pq)
+                f_prev = None
+                last_stage = polish_last and stage == len(stages) - 1
+                # the earlier stages minimise a surrogate (a looser smooth max): one run to a looser stall tolerance is all the
+                # warm start needs; the restarts and the full tolerance are spent on the last stage only
+                maxit_left = int(prm["maxit"]) - tot["it"] if last_stage else int(prm["maxit"]) // len(p_list)
+                for restart in range((int(prm["restarts"]) if last_stage else 0) + 1):
+                    if maxit_left <= 0:
+                        break
+                    out = dspg.run(xc, eps=prm["eps"], maxit=maxit_left, max_fevals=prm["max_fevals"],
+                                   rel_tol=prm["rel_tol"] * (1.0 if last_stage else loose),
+                                   stall_window=prm["stall_window"] if window is None else window)
+                    xc = prune_dust(out["x"])
+                    out["x"] = xc
+                    tot["it"] += out["it"]
+                    tot["count"] += out["count"]
+                    maxit_left -= out["it"]
+                    f_abs = out["f"]
+                    if out["solver_info"] == 0 and not out["stalled"]:
+                        break                                          # converged in the projected-gradient sense
+                    if f_prev is not None and f_prev - f_abs <= float(prm["restart_tol"]) * abs(f_abs):
+                        break
+                    f_prev = f_abs
+            return out
+
+        # (working set only for long vectors: below a few thousand groups the full problem is cheap and converges as well)
+        working_set = bool(prm["polish"]) and self.subplan is not None and L > max(4096, 4 * int(prm["polish_support"]) * N)
+        if not working_set:
+            res = run_stages(plan, scale_h, scale, x, p_list, True)
+            x = res["x"]
+        else:
+            # WORKING SET: the smooth stages locate the support on the full problem; the last stages (where a first-order method
+            # crawls when it drags thousands of near-zero entries along) run on the plan RESTRICTED to the largest entries; the
+            # full operator then prices the excluded groups at that point (entries whose scaled gradient lies below the
+            # support's multiplier would lower the objective) and they join the set for another round.  Restricted and full
+            # operator agree exactly on allocations supported on the set.
+            res = run_stages(plan, scale_h, scale, x, p_list[:-1] if len(p_list) > 1 else p_list, False,
+                             loose=float(prm["polish_full_loose"]))
+            x = res["x"]
+            S = min(L, int(prm["polish_support"]) * N)
+            keep = np.sort(np.argsort(-x, kind="stable")[:S])
+            # on the restricted plan an iteration is cheap, so a sharp smooth max goes first again; the best point by the TRUE
+            # objective over all rounds is returned
+            sub_stages = [float(q) for q in prm["polish_stages"]] if n_out > 1 else [np.inf]
+            best_x, best_f, best_res = None, np.inf, None
+            for rnd in range(int(prm["polish_rounds"])):
+                try:
+                    sub = self.subplan(keep)
+                except BLUESTError:
+                    sub = None
+                if sub is None:
+                    res_full = run_stages(plan, scale_h, scale, x, p_list[-1:], True)   # cannot restrict (an output would lose model 0)
+                    if res_full is not None:
+                        res, x = res_full, res_full["x"]
+                    break
+                res_sub = run_stages(sub, scale_h[keep], to_dev(scale_h[keep]), x[keep] / x[keep].sum(), sub_stages, True,
+                                     window=int(prm["polish_stall_window"]))
+                if res_sub is None:                                           # iteration budget (maxit) exhausted
+                    break
+                res = res_sub
+                x = np.zeros(L)
+                x[keep] = res["x"]
+                # pricing with the gradient of a sharp smooth max at the polished point
+                var, grad, status = plan.eval(scale_h * x)
+                r = var[0].cpu().numpy() / s
+                if float(r.max()) < best_f:
+                    best_x, best_f, best_res = x.copy(), float(r.max()), res
+                q = (r / r.max()) ** 2047.0
+                coef = (q / (q * (r / r.max())).sum() ** (1.0 - 1.0 / 2048.0)) / s
+                g = plan.combine_grad(grad, to_dev(coef).reshape(1, -1), scale=scale)[0].cpu().numpy()
+                theta = float(g[keep] @ x[keep])                              # multiplier of sum x = 1 on the support
+                viol = g - theta
+                viol[keep] = 0.0
+                enter = np.flatnonzero(viol < -float(prm["price_tol"]) * abs(theta))
+                if len(enter) == 0:
+                    break
+                if len(enter) > S // 2:
+                    enter = enter[np.argsort(viol[enter], kind="stable")[:S // 2]]
+                keep = np.sort(np.concatenate([keep[x[keep] > 0], enter]))
+                x[enter] = 1.0e-6 / max(len(enter), 1)                        # seed: the scaled metric moves zeros slowly
+                x = x / x.sum()
+            if best_x is not None:
+                x, res = best_x, best_res
+        xs = x
+        # support selection by objective: a first-order iterate keeps hundreds of entries that together hold ~1e-4 of the
+        # budget (the optimum sits on <= N entries per output; the reference's SDP solvers return such a point).  Keep the S
+        # entries with the largest cost share, give the rest of the budget to them, and take the smallest S (doubling from N)
+        # whose objective is within sparsify_tol of the full iterate's: a handful of 15 us evaluations.  Without this the integer
+        # projection faces hundreds of fractional entries below one sample and cannot find a feasible point.
+        pruned = 0
+        stol, tol = float(prm["sparsify_tol"]), float(prm["prune_tol"])
+        if stol > 0.0:
+            order = np.argsort(-xs, kind="stable")
+            nnz = int((xs > 0).sum())
+            f0 = ratios(plan, scale_h * xs)
+            S = N
+            while S < nnz:
+                xp = np.zeros(L)
+                xp[order[:S]] = xs[order[:S]]
+                xp = xp / xp.sum()
+                if ratios(plan, scale_h * xp) <= f0 * (1.0 + stol):
+                    xs, pruned = xp, L - S
+                    break
+                S *= 2
+        if tol > 0.0 and pruned == 0:
+            # drop the smallest entries whose cumulative cost share is below prune_tol and give their budget to the rest
+            order = np.argsort(xs, kind="stable")
+            k = int((np.cumsum(xs[order]) <= tol).sum())
+            if 0 < k < L:
+                xp = xs.copy()
+                xp[order[:k]] = 0.0
+                xp = xp / xp.sum()
+                if ratios(plan, scale_h * xp) <= ratios(plan, scale_h * xs) * (1.0 + 10.0 * tol):
+                    xs, pruned = xp, k
+        m = scale_h * xs
+        if budget is None:
+            m = m * ratios(plan, m)        # rescale so that max_o V_o/eps_o^2 = 1 (V is homogeneous of degree -1)
+        self.info = {"it": tot["it"], "count": tot["count"], "gpmax": res["gpmax"], "f": res["f"], "solver_info": res["solver_info"],
+                     "fevals": tot["count"], "gevals": tot["it"] + len(p_list), "pruned": pruned}
+        return m
+
     def solve(self, budget=None, eps=None, x0=None, params=None):
         prm = dict(spg_sap_default_params)
         if params:
             prm.update(params)
+        if prm["device_loop"]:
+            return self._solve_device(budget, eps, x0, prm)
         plan = self.plan
         n_out = plan.n_out
         s = np.ones(n_out) if budget is not None else np.asarray(eps, dtype=np.float64) ** 2
@@ -225,131 +407,10 @@ class SpgAllocator(object):
         def stall(it, f, gpmax, lmbda):
             hist.append(f)
 
-        if prm["device_loop"]:
-            from .spg_device import DeviceSpg
-            # continuation in the smoothing exponent (p-norm -> max), each stage warm-started from the previous one; inside a
-            # stage the run is RESTARTED from its own result (dust pruned, spectral step re-initialised) while that still
-            # pays: a restart typically gains another 1e-4 in the objective on these flat optima
-            tot_it = tot_count = 0
-
-            def run_stages(pl, sc, xc, stages, polish_last, loose=5.0, window=None):
-                """the continuation stages on plan `pl` (variables scaled by `sc`) from xc; polish_last: the last stage gets the
-                restarts and the full stall tolerance"""
-                nonlocal tot_it, tot_count
-
-                def prune_dust(xq):
-                    rel = float(prm["prune_rel"])
-                    if rel <= 0.0:
-                        return xq
-                    xp = torch.where(xq < rel * xq.max(), torch.zeros_like(xq), xq)
-                    xp = xp / xp.sum()
-                    vp, _, sp = pl.eval(sc * xp, want_grad=False)
-                    v0, _, _ = pl.eval(sc * xq, want_grad=False)
-                    ok = bool((sp == EVAL_OK).all()) and float((vp[0] / v0[0]).max()) <= 1.0 + 1.0e-6
-                    return xp if ok else xq
-
-                # ONE solver object for all stages: the smoothing exponent lives in the device state, so the captured hipGraphs
-                # are shared by the stages (capturing them is a visible part of a 0.1 s solve)
-                dspg = DeviceSpg(pl, sc, s, stages[0], floor, lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"],
-                                 Hlength=prm["linesearch_history_length"], slots=prm["slots"], check_every=prm["check_every"])
-                out = None
-                for stage, pq in enumerate(stages):
-                    dspg.p = float(pq)
-                    f_prev = None
-                    last_stage = polish_last and stage == len(stages) - 1
-                    # the earlier stages minimise a surrogate (a looser smooth max): one run to a 5x looser stall tolerance is all
-                    # the warm start needs; the restarts and the full tolerance are spent on the last stage only
-                    maxit_left = int(prm["maxit"]) - tot_it if last_stage else int(prm["maxit"]) // len(p_list)
-                    for restart in range((int(prm["restarts"]) if last_stage else 0) + 1):
-                        if maxit_left <= 0:
-                            break
-                        out = dspg.run(xc, eps=prm["eps"], maxit=maxit_left, max_fevals=prm["max_fevals"],
-                                       rel_tol=prm["rel_tol"] * (1.0 if last_stage else loose),
-                                       stall_window=prm["stall_window"] if window is None else window)
-                        xc = prune_dust(out["x"])
-                        out["x"] = xc
-                        tot_it += out["it"]
-                        tot_count += out["count"]
-                        maxit_left -= out["it"]
-                        f_abs = out["f"]
-                        if out["solver_info"] == 0 and not out["stalled"]:
-                            break                                          # converged in the projected-gradient sense
-                        if f_prev is not None and f_prev - f_abs <= float(prm["restart_tol"]) * abs(f_abs):
-                            break
-                        f_prev = f_abs
-                return out
-
-            # (only for long vectors: below a few thousand groups the full problem is cheap and converges as well)
-            working_set = (bool(prm["polish"]) and self.subplan is not None
-                           and L > max(4096, 4 * int(prm["polish_support"]) * plan.N))
-            if not working_set:
-                res = run_stages(plan, scale, x, p_list, True)
-            else:
-                # WORKING SET: the smooth stages locate the support on the full problem; the last stage (the true max, where a
-                # first-order method crawls when it drags thousands of near-zero entries along) runs on the plan RESTRICTED to
-                # the largest entries; the full operator then prices the excluded groups at that point (entries whose scaled
-                # gradient lies below the support's multiplier would lower the objective) and they join the set for another
-                # round.  Restricted and full operator agree exactly on allocations supported on the set.
-                res = run_stages(plan, scale, x, p_list[:-1] if len(p_list) > 1 else p_list, False, loose=float(prm["polish_full_loose"]))
-                x = res["x"]
-                S = min(L, int(prm["polish_support"]) * plan.N)
-                keep = torch.sort(torch.argsort(x, descending=True)[:S]).values
-                s_dev = torch.from_numpy(s).to(self.dev)
-                # on the restricted plan an iteration is cheap, so the sharp smooth max goes first again (the plain max alone
-                # stalls in its line search at the kinks); the best point by the TRUE objective over all rounds is returned
-                sub_stages = ([p for p in p_list if np.isfinite(p)][-1:] + [p_list[-1]]) if np.isinf(p_list[-1]) and len(p_list) > 1 else p_list[-1:]
-                if prm.get("polish_stages"):
-                    sub_stages = [float(q) for q in prm["polish_stages"]] if n_out > 1 else [np.inf]
-                best_x, best_f, best_res = None, np.inf, None
-                for rnd in range(int(prm["polish_rounds"])):
-                    try:
-                        sub = self.subplan(keep.cpu().numpy())
-                    except BLUESTError:
-                        sub = None
-                    if sub is None:
-                        res_full = run_stages(plan, scale, x, p_list[-1:], True)  # cannot restrict (an output would lose model 0)
-                        if res_full is not None:
-                            res = res_full
-                            x = res["x"]
-                        break
-                    xs_sub = x[keep] / x[keep].sum()
-                    res_sub = run_stages(sub, scale[keep], xs_sub, sub_stages, True, window=int(prm["polish_stall_window"]))
-                    if res_sub is None:                                           # iteration budget (maxit) exhausted
-                        break
-                    res = res_sub
-                    x = torch.zeros_like(x)
-                    x[keep] = res["x"]
-                    # pricing with the gradient of a sharp smooth max at the polished point
-                    var, grad, status = plan.eval(scale * x)
-                    r = var[0] / s_dev
-                    if float(r.max()) < best_f:
-                        best_x, best_f, best_res = x.clone(), float(r.max()), res
-                    q = (r / r.max()) ** 2047.0
-                    coef = (q / (q * (r / r.max())).sum() ** (1.0 - 1.0 / 2048.0)) / s_dev
-                    g = plan.combine_grad(grad, coef.reshape(1, -1), scale=scale)[0]
-                    theta = float((g[keep] * x[keep]).sum())                      # multiplier of sum x = 1 on the support
-                    viol = g - theta
-                    viol[keep] = 0.0
-                    enter = torch.nonzero(viol < -float(prm["price_tol"]) * abs(theta)).flatten()
-                    if len(enter) == 0:
-                        break
-                    if len(enter) > S // 2:
-                        enter = enter[torch.argsort(viol[enter])[:S // 2]]
-                    keep = torch.sort(torch.cat([keep[x[keep] > 0], enter])).values
-                    x[enter] = 1.0e-6 / max(len(enter), 1)                        # seed: the scaled metric moves zeros slowly
-                    x = x / x.sum()
-                if best_x is not None:
-                    x, res = best_x, best_res
-                res = dict(res)
-                res["x"] = x
-            st["norm"] = res["norm"]
-            res["f"] = res["f"] / res["norm"]
-            res["it"], res["count"] = tot_it, tot_count
-            st["fevals"], st["gevals"] = tot_count, tot_it + len(p_list)
-        else:
-            res = spg(feval, geval, proj, x, eps=prm["eps"], maxit=prm["maxit"], max_fevals=prm["max_fevals"], verbose=self.verbose,
-                      lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"], Hlength=prm["linesearch_history_length"],
-                      proj_step=proj_step, callback=stall, metric_dot=metric_dot if floor > 0 else None)
+        # host-driven loop (the reference's driver with GPU callbacks; device_loop=True goes through _solve_device)
+        res = spg(feval, geval, proj, x, eps=prm["eps"], maxit=prm["maxit"], max_fevals=prm["max_fevals"], verbose=self.verbose,
+                  lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"], Hlength=prm["linesearch_history_length"],
+                  proj_step=proj_step, callback=stall, metric_dot=metric_dot if floor > 0 else None)
         xs = res["x"]
         # prune the dust: SPG iterates keep thousands of entries with a negligible share of the budget (the reference's SDP
         # returns a sparse point); drop the smallest entries whose cumulative cost share is below prune_tol and give their

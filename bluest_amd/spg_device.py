@@ -29,6 +29,11 @@ class DeviceSpg(object):
         self.plan, self.lib, self.dev = plan, plan.lib, plan.device
         self.L, self.n_out = plan.L, plan.n_out
         self.scale = scale.contiguous()
+        self.scale_h = self.scale.cpu().numpy()
+        # NOTE: no torch compute operator is used anywhere on this path (only allocations and copies): on ROCm the first use
+        # of each torch operator loads its kernels, 30-150 ms a piece, which used to triple the first solve of a process
+        self._one = torch.from_numpy(np.ones(1)).to(self.dev)
+        self._zero = torch.from_numpy(np.zeros(1)).to(self.dev)
         self.s_norm = np.asarray(s_norm, dtype=np.float64)
         self.p, self.floor = float(p), float(floor)
         self.lmin, self.lmax, self.H = float(lmbda_min), float(lmbda_max), int(Hlength)
@@ -38,11 +43,11 @@ class DeviceSpg(object):
         self.x, self.g, self.d = torch.empty(L, **d), torch.empty(L, **d), torch.empty(L, **d)
         self.xnew, self.gnew, self.m = torch.empty(L, **d), torch.empty(L, **d), torch.empty(L, **d)
         self.var = torch.empty((1, self.n_out), **d)
-        self.status = torch.zeros((1, self.n_out), dtype=torch.int32, device=self.dev)
+        self.status = torch.from_numpy(np.zeros((1, self.n_out), dtype=np.int32)).to(self.dev)
         self.grad = torch.empty((1, plan.grad_len), **d)
-        self.enable = torch.ones(1, dtype=torch.int32, device=self.dev)
-        self.st = torch.zeros(STATE_DOUBLES, **d)
-        self.work = torch.zeros(1024, **d)
+        self.enable = torch.from_numpy(np.ones(1, dtype=np.int32)).to(self.dev)
+        self.st = torch.from_numpy(np.zeros(STATE_DOUBLES)).to(self.dev)
+        self.work = torch.from_numpy(np.zeros(1024)).to(self.dev)
         self.pws = projection_workspace(L, self.dev)
         v = ctypes.c_void_p()
         check(self.lib.bluest_plan_v_workspace(plan._h, ctypes.byref(v), None))
@@ -101,8 +106,9 @@ class DeviceSpg(object):
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(side):
-            saved = self.st.clone()
-            self.st[DONE] = 1.0               # warm-up outside capture with every kernel predicated off
+            saved = torch.empty_like(self.st)
+            saved.copy_(self.st)
+            self.st[DONE:DONE + 1].copy_(self._one)   # warm-up outside capture with every kernel predicated off
             fn()
             self.st.copy_(saved)
         torch.cuda.current_stream(self.dev).wait_stream(side)
@@ -137,8 +143,10 @@ class DeviceSpg(object):
         plan, lib, st = self.plan, self.lib, self.st
         with torch.cuda.device(self.dev):
             check(lib.bluest_plan_set_gate(plan._h, None, 0))
+            if not isinstance(x0, torch.Tensor):
+                x0 = torch.from_numpy(np.ascontiguousarray(x0, dtype=np.float64))
             self.x.copy_(simplex_project(x0.to(self.dev), want_d=False)[0])
-            var, grad, status = plan.eval(self.scale * self.x)
+            var, grad, status = plan.eval(self.scale_h * self.x.cpu().numpy())
             if not (status[0].cpu().numpy() == EVAL_OK).all():
                 raise RuntimeError("device SPG: infeasible starting point")
             F0, coef = self._objective(var[0].cpu().numpy())
@@ -213,7 +221,7 @@ class DeviceSpg(object):
                         if hs[ALPHA] < 1e-300 or hs[COUNT] >= max_fevals:
                             info = 2
                             break
-                        st[FAIL] = 0.0
+                        st[FAIL:FAIL + 1].copy_(self._zero)
                         run_slots()
                         hs = st.cpu().numpy()
                         if hs[ACCEPT] != 0.0:
@@ -245,5 +253,5 @@ class DeviceSpg(object):
                 hs = st.cpu().numpy()
             finally:
                 check(lib.bluest_plan_set_gate(plan._h, None, 0))
-        return {"x": self.x.clone(), "f": float(hs[F]) * norm, "gpmax": gpmax, "it": int(hs[IT]), "count": int(hs[COUNT]),
+        return {"x": self.x.cpu().numpy(), "f": float(hs[F]) * norm, "gpmax": gpmax, "it": int(hs[IT]), "count": int(hs[COUNT]),
                 "solver_info": info, "norm": norm, "stalled": stalled}

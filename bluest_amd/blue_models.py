@@ -366,8 +366,11 @@ class BLUEProblem(object):
 
         if all(same(multi_groups[n], multi_groups[0]) for n in range(1, self.n_outputs)):
             # identical lists: the union is the (sorted) list itself
-            groups = [np.array(sorted(map(tuple, np.asarray(gk).tolist())), dtype=np.int64).reshape(-1, k + 1) if len(gk) else []
-                      for k, gk in enumerate(multi_groups[0])]
+            def lexsorted(gk, k):
+                gk = np.asarray(gk, dtype=np.int64).reshape(-1, k + 1)
+                return gk[np.lexsort(gk.T[::-1])]             # rows in the order sorted(map(tuple, ...)) gives
+
+            groups = [lexsorted(gk, k) if len(gk) else [] for k, gk in enumerate(multi_groups[0])]
         else:
             seen = [set() for k in range(K)]                  # union over outputs, hashed (blue_models.py:493-501)
             for n in range(self.n_outputs):

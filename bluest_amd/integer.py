@@ -45,6 +45,13 @@ def get_feasible_integer_bounds(sol, N, e=None):
     return lb[idx], ub[idx], idx
 
 
+def _local_index(mapping, L):
+    """global group index -> position inside one output (-1: the output does not have the group)"""
+    local = np.full(L, -1, dtype=np.int64)
+    local[np.asarray(mapping)] = np.arange(len(mapping))
+    return local
+
+
 def psi_column(sap, li):
     """column li of SAP_n's psi (cmisc.cpp:10-23) from the group's inverse covariance: (N*N,) vector"""
     N = sap.N
@@ -94,10 +101,10 @@ def _search(sol, N, w, e, saps, mappings, plan, budget, eps, max_samples_info, l
     cols = np.zeros((No, LL, N * N))
     in_out = np.zeros((No, LL), dtype=bool)
     for n in range(No):
-        pos = {int(g): li for li, g in enumerate(mappings[n])}
+        local = _local_index(mappings[n], len(sol))
         for j, gidx in enumerate(idx):
-            li = pos.get(int(gidx))
-            if li is not None:
+            li = int(local[gidx])
+            if li >= 0:
                 cols[n, j] = psi_column(saps[n], li)
                 in_out[n, j] = True
 
@@ -129,7 +136,7 @@ def _search(sol, N, w, e, saps, mappings, plan, budget, eps, max_samples_info, l
             continue
         ms, costs = ms[:, keep], costs[keep]
         V = candidate_variances(N, base_phi, cols, ms, plan.device)
-        Vmax = V.max(dim=1).values.cpu().numpy()
+        Vmax = V.cpu().numpy().max(axis=1)
         if budget is not None:
             i = int(np.argmin(Vmax))
             # the reference reverses the candidate order before argmin: on exact ties the LAST candidate wins
@@ -213,11 +220,11 @@ def greedy_integer(sol, N, w, e, saps, mappings, plan, budget=None, eps=None, ma
         sup = sup[np.argsort(sol[sup])[-max_support:]]
     LL = len(sup)
     cols = np.zeros((No, LL, N * N))
+    locals_ = [_local_index(mappings[n], len(sol)) for n in range(No)]
     for n in range(No):
-        pos = {int(g): li for li, g in enumerate(mappings[n])}
         for j, gidx in enumerate(sup):
-            li = pos.get(int(gidx))
-            if li is not None:
+            li = int(locals_[n][gidx])
+            if li >= 0:
                 cols[n, j] = psi_column(saps[n], li)
     wsup = w[sup]
 
@@ -247,7 +254,7 @@ def greedy_integer(sol, N, w, e, saps, mappings, plan, budget=None, eps=None, ma
         m[sup] = np.floor(sol[sup]).astype(np.int64)
         while not sampled_once(m):                         # model 0 of some output is not sampled yet: cheapest group that has it
             lacking = [n for n in range(No) if e[mappings[n]] @ m[mappings[n]] < 1]
-            cand = [j for j in range(LL) if any(e[sup[j]] > 0 and sup[j] in set(mappings[n].tolist()) for n in lacking)]
+            cand = [j for j in range(LL) if any(e[sup[j]] > 0 and locals_[n][sup[j]] >= 0 for n in lacking)]
             if not cand:
                 return None, np.inf
             m[sup[min(cand, key=lambda j: wsup[j])]] += 1

@@ -174,10 +174,12 @@ class Plan(object):
         """Phi(m) + delta*I for every output as an (n_cand, n_out, N, N) device tensor (misc.py:459-461)"""
         rec = self.phi(m)
         N = self.N
-        PHI = rec[:, :, :N * N].reshape(rec.shape[0], self.n_out, N, N).clone()
+        # re-packed on the host (a few KB): a strided device copy would be the first use of a torch operator in the process,
+        # which costs ~100 ms of kernel loading on ROCm
+        PHI = np.ascontiguousarray(rec.cpu().numpy()[:, :, :N * N]).reshape(rec.shape[0], self.n_out, N, N)
         if delta:
-            PHI += float(delta) * torch.eye(N, dtype=torch.float64, device=self.device)
-        return PHI
+            PHI = PHI + float(delta) * np.eye(N)
+        return torch.from_numpy(PHI).to(self.device)
 
 
 def simplex_project(x, g=None, lmbda=0.0, z=1.0, want_p=True, want_d=True, floor=0.0):

@@ -439,10 +439,36 @@ __global__ void k_combine_grad(const double *__restrict__ grad, int64_t grad_str
 // ------------------------------------------------------------------------------------------------------
 // Part 2 host side: the plan
 // ------------------------------------------------------------------------------------------------------
+// The plan's two device buffers come from HIP's stream-ordered memory pool (null stream): a freed arena stays in the pool, so
+// building the next plan does not go back to the driver (hipMalloc / hipFree of 45 MB cost 10-80 ms depending on what else the
+// process holds).  The release threshold keeps the pool from trimming itself at every synchronisation.
+static hipError_t pool_alloc(void **p, size_t bytes)
+{
+    static bool configured = false;
+    if (!configured) {
+        int dev = 0;
+        hipMemPool_t pool;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+            uint64_t keep = 1ull << 32;     // up to 4 GB of freed plan memory stays cached
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        (void)hipGetLastError();
+        configured = true;
+    }
+    hipError_t e = hipMallocAsync(p, bytes, 0);
+    if (e == hipSuccess) e = hipStreamSynchronize(0);
+    return e;
+}
+static hipError_t pool_free(void *p)
+{
+    hipError_t e = hipFreeAsync(p, 0);
+    return e;
+}
+
 static void plan_free_device(bluest_plan_s *p)
 {
-    if (p->d_arena) (void)hipFree(p->d_arena);
-    if (p->d_scratch) (void)hipFree(p->d_scratch);
+    if (p->d_arena) (void)pool_free(p->d_arena);
+    if (p->d_scratch) (void)pool_free(p->d_scratch);
     p->d_arena = p->d_scratch = nullptr;
 }
 
@@ -533,9 +559,9 @@ extern "C" int bluest_plan_add_output_cov(bluest_plan_t plan, const double *C, i
     const size_t offG = offI + ((size_t)ni * sizeof(double) + 255) / 256 * 256;
     const size_t need = offG + (size_t)ng * sizeof(int64_t);
     if (need > plan->scratch_bytes) {
-        if (plan->d_scratch) (void)hipFree(plan->d_scratch);
+        if (plan->d_scratch) (void)pool_free(plan->d_scratch);
         plan->d_scratch = nullptr; plan->scratch_bytes = 0;
-        HIP_TRY(hipMalloc(&plan->d_scratch, need));
+        HIP_TRY(pool_alloc(&plan->d_scratch, need));
         plan->scratch_bytes = need;
     }
     double *dC = reinterpret_cast<double *>((char *)plan->d_scratch + offC), *dic = reinterpret_cast<double *>((char *)plan->d_scratch + offI);
@@ -795,7 +821,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
 
     timer.lap("tiles + inverse maps");
     int rc;
-    if (plan->d_scratch) { (void)hipFree(plan->d_scratch); plan->d_scratch = nullptr; plan->scratch_bytes = 0; }
+    if (plan->d_scratch) { (void)pool_free(plan->d_scratch); plan->d_scratch = nullptr; plan->scratch_bytes = 0; }
     Arena arena;
     const size_t o_vals = arena.reserve(vals.size() * sizeof(double)), o_cols = arena.reserve(cols.size() * sizeof(int32_t));
     const size_t o_rows = arena.reserve(rows.size() * sizeof(RowDesc)), o_orb = arena.reserve(out_row_begin.size() * sizeof(int32_t));
@@ -805,7 +831,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     const size_t o_partial = arena.reserve((size_t)max_candidates * n_chunks * sizeof(double2));
     const size_t o_v = arena.reserve((size_t)max_candidates * n_out * N * sizeof(double));
     const size_t o_status = arena.reserve((size_t)max_candidates * n_out * sizeof(int32_t));
-    HIP_TRY(hipMalloc(&plan->d_arena, arena.bytes));
+    HIP_TRY(pool_alloc(&plan->d_arena, arena.bytes));
     arena.base = (char *)plan->d_arena;
     if ((rc = upload(arena, o_vals, &plan->d_vals, vals))) return rc;
     if ((rc = upload(arena, o_cols, &plan->d_cols, cols))) return rc;

@@ -40,6 +40,7 @@ spg_sap_default_params = {
     "polish_stages": (2048.0, 65536.0),  # smoothing exponents on the working set (multi-output): 65536 is the max for all
                               # practical purposes but keeps near-ties smooth -- the plain max there cost 40 % more time on the
                               # hard cases (line-search stalls at the kinks) for objectives equal to 1e-5
+    "polish_full_stages": 0,  # how many leading stages run on the full problem (0 = all but the last)
     "polish_full_loose": 25.0, # stall tolerance of the full-problem stages in working-set mode, in units of rel_tol
     "sparsify_tol": 1.0e-5,   # final support selection: keep the fewest largest entries whose objective is within this (relative)
                               # of the full iterate's (0 = off)
@@ -230,7 +231,8 @@ class SpgAllocator(object):
             # full operator then prices the excluded groups at that point (entries whose scaled gradient lies below the
             # support's multiplier would lower the objective) and they join the set for another round.  Restricted and full
             # operator agree exactly on allocations supported on the set.
-            res = run_stages(plan, scale_h, scale, x, p_list[:-1] if len(p_list) > 1 else p_list, False,
+            n_full = int(prm["polish_full_stages"]) if prm.get("polish_full_stages") else max(1, len(p_list) - 1)
+            res = run_stages(plan, scale_h, scale, x, p_list[:max(1, min(n_full, len(p_list)))], False,
                              loose=float(prm["polish_full_loose"]))
             x = res["x"]
             S = min(L, int(prm["polish_support"]) * N)

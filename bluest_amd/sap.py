@@ -596,12 +596,14 @@ class SAP(object):
         K, L, sizes, cumsizes, groups, invcovs = self.K, self.L, self.sizes, self.cumsizes, self.groups, self.invcovs
         y = [0 for i in range(self.N)]
         sums = [sums[cumsizes[k]:cumsizes[k + 1]] for k in range(K)]
+        m = np.asarray(samples, dtype=np.float64)
         for k in range(1, K + 1):
-            for i in range(sizes[k]):
+            # only the sampled groups carry sums (the reference loops over all L groups in Python, sap.py:105-110: minutes at
+            # K_tot = 245505; their terms are invcov * 0)
+            for i in np.flatnonzero(m[cumsizes[k - 1]:cumsizes[k]] != 0).tolist():
                 for j in range(k):
                     for s in range(k):
                         y[groups[k - 1][i][j]] += invcovs[k - 1][k * k * i + k * j + s] * sums[k - 1][i][s]
-        m = np.asarray(samples, dtype=np.float64)
         if abs(m).max() < 0.05: return np.inf
         rec = self.plan.phi(m)
         var, v, status = self.plan.solve(rec)

@@ -161,6 +161,36 @@ def gen_sap(bluest, misc, n, kmax, n_out, fname, store_grad_outputs=None, with_p
     print(fname, "%.1f KB" % (os.path.getsize(os.path.join(OUT, fname)) / 1024))
 
 
+def gen_estimator(bluest, fname):
+    """compute_BLUE_estimator (sap.py:99-119 + misc.py:518-544) on the n = 6 all-groups problem: integer samples with most
+    groups unsampled, scalar sums per (group, model)"""
+    n, kmax = 6, 6
+    prob = synth.problem(n, kmax, 1)
+    sap = bluest.SAP(prob["C"][0].copy(), kmax, lists_of(prob["groups"]), prob["costs"], verbose=False)
+    rng = np.random.RandomState(21)
+    out = {"n": n, "kmax": kmax}
+    for case in range(3):
+        samples = np.zeros(sap.L, dtype=np.int64)
+        pick = rng.choice(sap.L, 9, replace=False)
+        samples[pick] = rng.randint(1, 40, size=9)
+        samples[0] = 3 + case                                  # the group {0}: model 0 is sampled
+        if case == 2:
+            samples[1] = 0; samples[2] = 0                     # some models never sampled -> restricted system (misc.py:523-525)
+        sums, flat = [], []
+        for k in range(1, kmax + 1):
+            for i in range(sap.sizes[k]):
+                li = sap.cumsizes[k - 1] + i
+                v = samples[li] * (1.0 + 0.1 * rng.randn(k)) if samples[li] > 0 else np.zeros(k)
+                sums.append(list(v)); flat.append(v)
+        mu, var = sap.compute_BLUE_estimator(sums, samples=samples)
+        out["samples%d" % case] = samples
+        out["sums%d" % case] = np.concatenate(flat)
+        out["mu%d" % case] = mu
+        out["var%d" % case] = var
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname)
+
+
 def gen_mosap(bluest, fname):
     """multi-output with DIFFERENT group sets per output (non-identity mappings, mosap.py:54-67)"""
     n, n_out, kmax = 6, 3, 3
@@ -315,6 +345,7 @@ def main():
     gen_sap(bluest, misc, 12, 12, 1, "sap_n12_all.npz")
     gen_sap(bluest, misc, 20, 5, 8, "sap_n20_k5_o8.npz", store_grad_outputs=(0,))
     gen_mosap(bluest, "mosap_n6_o3_ragged.npz")
+    gen_estimator(bluest, "estimator_n6_known_answers.npz")
     gen_hh(bluest, "hh_paper_known_answer.npz")
     gen_spg(bluest, spgmod, 6, 6, "spg_traj_n6.npz", maxit=60)
     gen_spg(bluest, spgmod, 12, 4, "spg_traj_n12_k4.npz", maxit=40)

@@ -240,6 +240,31 @@ class OracleSAP(object):
     def variance_GH(self, m, delta=0, nohess=False):
         return variance_GH_full(m, self.psi, self.groups, self.sizes, self.invcovs, delta=delta, nohess=nohess)
 
+    def compute_BLUE_estimator(self, sums, samples):
+        """bluest/sap.py:99-119 (y = sum_i R_i^T C_i^-1 sums_i, looped over ALL groups as the reference does) followed by
+        bluest/misc.py:518-544 (`PHIinvY0`: mu = sum_j pinv(Phi[idx])[0, j] y_j, var = pinv(Phi[idx])[0, 0])"""
+        K, sizes, cumsizes, groups, invcovs = self.K, self.sizes, self.cumsizes, self.groups, self.invcovs
+        y = [0 for i in range(self.L)]                     # the reference allocates L entries and uses the first N (sap.py:111)
+        per_size = [sums[cumsizes[k]:cumsizes[k + 1]] for k in range(K)]
+        for k in range(1, K + 1):
+            for i in range(sizes[k]):
+                for j in range(k):
+                    for t in range(k):
+                        y[groups[k - 1][i][j]] += invcovs[k - 1][k * k * i + k * j + t] * per_size[k - 1][i][t]
+        m = np.asarray(samples)
+        if abs(m).max() < 0.05:
+            return np.inf
+        PHI = get_phi_full(m, self.psi)
+        idx = get_nnz_rows_cols(m, groups, cumsizes)
+        PHI = PHI[idx]
+        yy = [y[item] for item in idx[0].flatten()]
+        assert idx[0].min() == 0
+        pinvPHI = np.linalg.pinv(PHI)
+        mu = 0
+        for j in range(len(yy)):
+            mu += pinvPHI[0, j] * yy[j]
+        return mu, pinvPHI[0, 0]
+
     def variance_GH_as_executed(self, m, delta=0.0):
         """bluest/misc.py:479-495 (nohess) exactly as the reference executes it on a CPU: dense psi@m (BLAS dgemv), two
         numpy pinv calls, and the reference's own compiled gradK_c (oracle/_ref).  Used as bench.py's cpu_baseline of kind

@@ -571,3 +571,27 @@ def test_edge_shapes_vs_oracle(gpu, oracle):
         SAP(np.eye(3), 1, [np.array([[0], [5]])], np.ones(2), verbose=False)          # model index 5 >= n
     with pytest.raises(_lib.BluestHipError):
         SAP(np.eye(70), 1, [np.arange(70).reshape(-1, 1)], np.ones(70), verbose=False)  # n > BLUEST_MAX_MODELS
+
+
+def test_blue_estimator_vs_reference_fixture(gpu):
+    """SAP / MOSAP.compute_BLUE_estimator(s) (sap.py:99-119, misc.py:518-544, mosap.py:113-123) against
+    values recorded from the reference; row 0 of the pseudo-inverse comes from the GPU solve"""
+    from bluest_amd.mosap import MOSAP
+    from bluest_amd.sap import SAP
+    G = golden("estimator_n6_known_answers.npz")
+    n, kmax = int(G["n"]), int(G["kmax"])
+    prob = synth.problem(n, kmax, 1)
+    sap = SAP(prob["C"][0], kmax, [g.copy() for g in prob["groups"]], prob["costs"], verbose=False)
+    mos = MOSAP(prob["C"], kmax, [kmax], [g.copy() for g in prob["groups"]], [[g.copy() for g in prob["groups"]]],
+                prob["costs"], [prob["costs"]], verbose=False)
+    for case in range(3):
+        samples, flat = G["samples%d" % case], G["sums%d" % case]
+        sums, off = [], 0
+        for k in range(1, kmax + 1):
+            for i in range(sap.sizes[k]):
+                sums.append(list(flat[off:off + k]))
+                off += k
+        mu, var = sap.compute_BLUE_estimator(sums, samples=samples)
+        assert abs(mu / float(G["mu%d" % case]) - 1) < TOL and abs(var / float(G["var%d" % case]) - 1) < TOL
+        mus, Vars = mos.compute_BLUE_estimators([sums], samples)
+        assert abs(mus[0] / float(G["mu%d" % case]) - 1) < TOL and abs(Vars[0] / float(G["var%d" % case]) - 1) < TOL

@@ -235,3 +235,27 @@ def test_reference_native_module_agrees_with_restatement(oracle):
         PHI = np.zeros(100)
         cm.objectiveK_c(PHI, 10, k, sap.sizes[k], m[sap.cumsizes[k - 1]:sap.cumsizes[k]], sap.groups[k - 1].ravel(), sap.invcovs[k - 1])
         assert rel_err(PHI, oracle.objectiveK(10, k, sap.sizes[k], m[sap.cumsizes[k - 1]:sap.cumsizes[k]], sap.groups[k - 1], sap.invcovs[k - 1])) < 1e-15
+
+
+def _estimator_case(G, case, sizes):
+    samples, flat = G["samples%d" % case], G["sums%d" % case]
+    sums, off = [], 0
+    for k in range(1, len(sizes)):
+        for i in range(sizes[k]):
+            sums.append(list(flat[off:off + k]))
+            off += k
+    return samples, sums
+
+
+def test_blue_estimator_vs_reference_fixture():
+    """compute_BLUE_estimator (sap.py:99-119 + misc.py:518-544) restated in the oracle vs values recorded from the reference,
+    including a case where some models are never sampled (restricted system)"""
+    from oracle import oracle
+    G = golden("estimator_n6_known_answers.npz")
+    n, kmax = int(G["n"]), int(G["kmax"])
+    prob = synth.problem(n, kmax, 1)
+    sap = oracle.OracleSAP(prob["C"][0], kmax, [g.copy() for g in prob["groups"]], prob["costs"])
+    for case in range(3):
+        samples, sums = _estimator_case(G, case, sap.sizes)
+        mu, var = sap.compute_BLUE_estimator(sums, samples)
+        assert abs(mu / float(G["mu%d" % case]) - 1) < 1e-12 and abs(var / float(G["var%d" % case]) - 1) < 1e-12

@@ -442,6 +442,7 @@ __global__ void k_combine_grad(const double *__restrict__ grad, int64_t grad_str
 // The plan's two device buffers come from HIP's stream-ordered memory pool (null stream): a freed arena stays in the pool, so
 // building the next plan does not go back to the driver (hipMalloc / hipFree of 45 MB cost 10-80 ms depending on what else the
 // process holds).  The release threshold keeps the pool from trimming itself at every synchronisation.
+static bool g_pool_usable = true;   // decided by the first allocation and never changed afterwards (free must match alloc)
 static hipError_t pool_alloc(void **p, size_t bytes)
 {
     static bool configured = false;
@@ -455,14 +456,18 @@ static hipError_t pool_alloc(void **p, size_t bytes)
         (void)hipGetLastError();
         configured = true;
     }
-    hipError_t e = hipMallocAsync(p, bytes, 0);
-    if (e == hipSuccess) e = hipStreamSynchronize(0);
-    return e;
+    if (g_pool_usable) {
+        hipError_t e = hipMallocAsync(p, bytes, 0);
+        if (e == hipSuccess) e = hipStreamSynchronize(0);
+        if (e == hipSuccess) return e;
+        (void)hipGetLastError();
+        g_pool_usable = false;              // no stream-ordered allocator on this device / driver: plain hipMalloc from now on
+    }
+    return hipMalloc(p, bytes);
 }
 static hipError_t pool_free(void *p)
 {
-    hipError_t e = hipFreeAsync(p, 0);
-    return e;
+    return g_pool_usable ? hipFreeAsync(p, 0) : hipFree(p);
 }
 
 static void plan_free_device(bluest_plan_s *p)

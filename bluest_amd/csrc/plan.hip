@@ -442,7 +442,7 @@ __global__ void k_combine_grad(const double *__restrict__ grad, int64_t grad_str
 // The plan's two device buffers come from HIP's stream-ordered memory pool (null stream): a freed arena stays in the pool, so
 // building the next plan does not go back to the driver (hipMalloc / hipFree of 45 MB cost 10-80 ms depending on what else the
 // process holds).  The release threshold keeps the pool from trimming itself at every synchronisation.
-static bool g_pool_usable = true;   // decided by the first allocation and never changed afterwards (free must match alloc)
+static bool g_pool_usable = true, g_pool_used = false;   // decided by the first allocation, then fixed (free must match alloc)
 static hipError_t pool_alloc(void **p, size_t bytes)
 {
     static bool configured = false;
@@ -459,8 +459,9 @@ static hipError_t pool_alloc(void **p, size_t bytes)
     if (g_pool_usable) {
         hipError_t e = hipMallocAsync(p, bytes, 0);
         if (e == hipSuccess) e = hipStreamSynchronize(0);
-        if (e == hipSuccess) return e;
+        if (e == hipSuccess) { g_pool_used = true; return e; }
         (void)hipGetLastError();
+        if (g_pool_used) return e;          // the pool works but this request failed (out of memory): report it
         g_pool_usable = false;              // no stream-ordered allocator on this device / driver: plain hipMalloc from now on
     }
     return hipMalloc(p, bytes);

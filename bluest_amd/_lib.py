@@ -53,6 +53,7 @@ SIGNATURES = {
     "bluest_spg_trial": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
     "bluest_spg_decide": [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp],
     "bluest_spg_update_fused": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp],
+    "bluest_spg_finish": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp],
     "bluest_spg_update": [c_vp, c_vp, c_vp, c_vp, c_vp, c_f64, c_i64, c_vp, c_vp],
     "bluest_intproj_eval": [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp],
     "bluest_simplex_workspace_doubles": [c_i64, c_i64p],

@@ -55,4 +55,91 @@ struct bluest_plan_s {
 };
 
 
+// ---- tile device code shared by plan.hip (gradient pass, fused kernel) and spg.hip (small-plan finish kernel) ----
+// gradient pass: one wavefront per tile, lane = group.  q = sum_j v_j (s_jj v_j + 2 sum_{l>j} s_jl v_l).
+template <int K>
+__device__ __forceinline__ void grad_tile(const TileDesc &td, const double *__restrict__ tvals,
+                                          const uint8_t *__restrict__ tidx, const double *__restrict__ v,
+                                          const int32_t *__restrict__ status, int N, int n_out, int n_cand,
+                                          double *__restrict__ grad, int64_t grad_stride, int lane)
+{
+    const double *vals = tvals + td.val_off + lane;
+    const uint8_t *idx = tidx + td.idx_off + lane;
+    int gi[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) gi[j] = idx[j * 64];
+    double s[K * (K + 1) / 2];
+#pragma unroll
+    for (int e = 0; e < K * (K + 1) / 2; e++) s[e] = vals[e * 64];
+    for (int c = 0; c < n_cand; c++) {
+        const int64_t eo = (int64_t)c * n_out + td.out;
+        const double *vc = v + eo * N;
+        double vj[K];
+#pragma unroll
+        for (int j = 0; j < K; j++) vj[j] = vc[gi[j]];
+        double q = 0.0;
+        int e = 0;
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            double t = 0.0;
+#pragma unroll
+            for (int l = j + 1; l < K; l++) t = fma(s[e + (l - j)], vj[l], t);
+            t = fma(s[e], vj[j], 2.0 * t);
+            q = fma(vj[j], t, q);
+            e += K - j;
+        }
+        if (lane < (td.n_valid & 0xffff))
+            grad[(int64_t)c * grad_stride + td.grad_off + lane] = (status[eo] == BLUEST_EVAL_INF) ? INFINITY : -q;
+    }
+}
+
+// the quadratic form of one group from a tile already in registers: q = v_g^T S v_g (packed symmetric S, K static)
+template <int K, int NE, int KU>
+__device__ __forceinline__ double tile_form(const double (&s)[NE], const int (&gi)[KU], const double *__restrict__ vc)
+{
+    double vj[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) vj[j] = vc[gi[j]];
+    double q = 0.0;
+    int e = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        double t = 0.0;
+#pragma unroll
+        for (int l = j + 1; l < K; l++) t = fma(s[e + (l - j)], vj[l], t);
+        t = fma(s[e], vj[j], 2.0 * t);
+        q = fma(vj[j], t, q);
+        e += K - j;
+    }
+    return q;
+}
+
+// generic k (13..16): entries re-read per candidate, no big register arrays
+__device__ __forceinline__ void grad_tile_generic(const TileDesc &td, const double *__restrict__ tvals,
+                                                  const uint8_t *__restrict__ tidx, const double *__restrict__ v,
+                                                  const int32_t *__restrict__ status, int N, int n_out, int n_cand,
+                                                  double *__restrict__ grad, int64_t grad_stride, int lane)
+{
+    const int K = td.k;
+    const double *vals = tvals + td.val_off + lane;
+    const uint8_t *idx = tidx + td.idx_off + lane;
+    for (int c = 0; c < n_cand; c++) {
+        const int64_t eo = (int64_t)c * n_out + td.out;
+        const double *vc = v + eo * N;
+        double q = 0.0;
+        int e = 0;
+        for (int j = 0; j < K; j++) {
+            const double vjj = vc[idx[j * 64]];
+            double t = 0.0;
+            for (int l = j + 1; l < K; l++) t = fma(vals[(e + (l - j)) * 64], vc[idx[l * 64]], t);
+            t = fma(vals[e * 64], vjj, 2.0 * t);
+            q = fma(vjj, t, q);
+            e += K - j;
+        }
+        if (lane < (td.n_valid & 0xffff))
+            grad[(int64_t)c * grad_stride + td.grad_off + lane] = (status[eo] == BLUEST_EVAL_INF) ? INFINITY : -q;
+    }
+}
+
+
 int plan_ready(bluest_plan_t plan, int n_cand);

@@ -266,6 +266,70 @@ __global__ __launch_bounds__(64) void k_spg_update_b(double *__restrict__ st, co
     }
 }
 
+// Small plans (K_tot <= 4096, a few hundred gradient tiles: the working set of the solver): the accepted step's gradient tiles,
+// the fused gradient fold + update and the Barzilai-Borwein bookkeeping in ONE single-workgroup kernel instead of three launches
+// (k_grad_tiles, k_spg_update_a_fused, k_spg_update_b) -- at this size every launch is pure latency.
+template <int KU>
+__global__ __launch_bounds__(1024) void k_spg_finish_small(const TileDesc *__restrict__ tiles, int64_t n_tiles,
+                                                           const double *__restrict__ tvals, const uint8_t *__restrict__ tidx,
+                                                           const double *__restrict__ v, const int32_t *__restrict__ status,
+                                                           int N, int n_out, double *__restrict__ grad,
+                                                           double *__restrict__ x, double *__restrict__ g,
+                                                           const double *__restrict__ xnew, const int64_t *__restrict__ goff,
+                                                           const int32_t *__restrict__ invmap, const double *__restrict__ scale,
+                                                           double *__restrict__ st, double floor, int64_t L)
+{
+    __shared__ ProjLds sm;
+    int ph = 0;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (st[SPG_DONE] != 0.0 || st[SPG_FAIL] != 0.0 || st[SPG_ACCEPT] == 0.0) return;
+    // (1) gradient tiles of the accepted trial point: one wavefront per tile, 16 at a time
+    for (int64_t t = wave; t < n_tiles; t += 16) {
+        const TileDesc td = tiles[t];
+        if ((td.n_valid & 0xffff) == 0) continue;
+#define GT(KK) case KK: if (KK <= KU) { grad_tile<(KK <= KU ? KK : 1)>(td, tvals, tidx, v, status, N, n_out, 1, grad, 0, lane); break; }
+        switch (td.k) {
+            GT(1) GT(2) GT(3) GT(4) GT(5) GT(6) GT(7) GT(8) GT(9) GT(10) GT(11) GT(12)
+            default: grad_tile_generic(td, tvals, tidx, v, status, N, n_out, 1, grad, 0, lane);
+        }
+#undef GT
+    }
+    __threadfence_block();
+    __syncthreads();
+    // (2) gnew_j = scale_j * sum_o coef_o grad_o[local_o(j)], s = xnew - x, y = gnew - g, x <- xnew, g <- gnew
+    double sdots = 0.0, sdoty = 0.0;
+    long long dummy = 0;
+    for (int64_t i = tid; i < L; i += 1024) {
+        double gn = 0.0;
+        for (int o = 0; o < n_out; o++) {
+            const int32_t li = invmap[(int64_t)o * L + i];
+            if (li >= 0) gn = fma(st[SPG_COEF + o], grad[goff[o] + li], gn);
+        }
+        gn *= scale[i];
+        const double xi = x[i], gi = g[i], xn = xnew[i];
+        const double sv = xn - xi, yv = gn - gi;
+        sdots += (floor > 0.0) ? sv * sv / fmax(xi, floor) : sv * sv;
+        sdoty = fma(sv, yv, sdoty);
+        x[i] = xn;
+        g[i] = gn;
+    }
+    block_sum2_cnt(sdots, sdoty, dummy, sm, tid, ph);
+    // (3) Barzilai-Borwein step, history, reset of the line-search state (as k_spg_update_b)
+    if (tid == 0) {
+        const double lmin = st[SPG_LMIN], lmax = st[SPG_LMAX], fnew = st[SPG_FNEW];
+        st[SPG_SDOTS] = sdots;
+        st[SPG_SDOTY] = sdoty;
+        st[SPG_LAMBDA] = (sdoty <= 0.0) ? lmax : fmin(lmax, fmax(lmin, sdots / sdoty));
+        const double it = st[SPG_IT] + 1.0;
+        st[SPG_IT] = it;
+        st[SPG_F] = fnew;
+        const int H = (int)st[SPG_HLEN];
+        st[SPG_HIST + ((long long)it % H)] = fnew;
+        st[SPG_ALPHA] = 1.0;
+        st[SPG_ACCEPT] = 0.0;
+    }
+}
+
 // p = argmin sum_i (p_i - u_i)^2 / s_i  s.t. p >= 0, sum p = z, with u = x - lambda*s*g:
 //   p_i = s_i * max(r_i - tau, 0),  r_i = x_i/s_i - lambda*g_i,  sum_i s_i max(r_i - tau, 0) = z.
 // floor == 0: s = 1 (plain Euclidean projection, the reference-style SPG step);
@@ -1001,6 +1065,31 @@ extern "C" int bluest_spg_update_fused(bluest_plan_t plan, double *x_dev, double
     hipLaunchKernelGGL(k_spg_update_b, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, (const double2 *)work_dev, nblocks);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
+}
+
+extern "C" int bluest_spg_finish(bluest_plan_t plan, const double *v_dev, const int32_t *status_dev, double *x_dev, double *g_dev,
+                                 const double *xnew_dev, double *grad_dev, const double *scale_dev, double *state_dev, double floor,
+                                 double *work_dev, void *stream)
+{
+    int rc = plan_ready(plan, 1); if (rc) return rc;
+    if (!v_dev || !status_dev || !x_dev || !g_dev || !xnew_dev || !grad_dev || !scale_dev || !state_dev || !work_dev)
+        return fail(BLUEST_ERR_ARG, "null pointer");
+    if (plan->L <= 4096 && plan->n_tiles <= 1024) {
+        int kmax = 0;
+        for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
+#define LFS(KU) hipLaunchKernelGGL((k_spg_finish_small<KU>), dim3(1), dim3(1024), 0, (hipStream_t)stream, plan->d_tiles, plan->n_tiles, \
+                                   plan->d_tvals, plan->d_tidx, v_dev, status_dev, plan->N, (int)plan->outs.size(), grad_dev, x_dev, g_dev,    \
+                                   xnew_dev, plan->d_goff, plan->d_invmap, scale_dev, state_dev, floor, plan->L)
+        if (kmax <= 5) LFS(5);
+        else if (kmax <= 8) LFS(8);
+        else LFS(12);
+#undef LFS
+        HIP_TRY(hipGetLastError());
+        return BLUEST_OK;
+    }
+    rc = bluest_plan_grad(plan, v_dev, status_dev, 1, grad_dev, plan->grad_len, stream);
+    if (rc) return rc;
+    return bluest_spg_update_fused(plan, x_dev, g_dev, xnew_dev, grad_dev, scale_dev, state_dev, floor, work_dev, stream);
 }
 
 extern "C" int bluest_spg_update(double *x_dev, double *g_dev, const double *xnew_dev, const double *gnew_dev, double *state_dev,

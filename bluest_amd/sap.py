@@ -36,6 +36,8 @@ spg_sap_default_params = {
     "polish_support": 8,      #   polish_support * N of them, price the excluded groups with the full gradient and let those
     "polish_rounds": 2,       #   below the support's multiplier by price_tol (relative) join, at most polish_rounds times
     "price_tol": 1.0e-3,
+    "polish_slots": 0,            # trial points inside the iteration graph on the working set (0 = as "slots"; the loop adds
+                                  # a second slot by itself when host continuations become frequent; 1/2/3 measured the same)
     "polish_stall_window": 100,   # stall window (iterations) of the runs on the working set
     "polish_stages": (2048.0, 65536.0),  # smoothing exponents on the working set (multi-output): 65536 is the max for all
                               # practical purposes but keeps near-ties smooth -- the plain max there cost 40 % more time on the
@@ -178,7 +180,7 @@ class SpgAllocator(object):
             raise BLUESTError("SPG: the initial allocation does not sample model 0 / is infeasible")
         tot = {"it": 0, "count": 0}
 
-        def run_stages(pl, sc_h, sc, xc, stages, polish_last, loose=5.0, window=None):
+        def run_stages(pl, sc_h, sc, xc, stages, polish_last, loose=5.0, window=None, slots=None):
             """the continuation stages on plan `pl` (variables scaled by sc) from xc; polish_last: the last stage gets the
             restarts and the full stall tolerance.  Returns the last run's result (x as numpy), or None without budget left"""
             def prune_dust(xq):
@@ -192,7 +194,8 @@ class SpgAllocator(object):
             # ONE solver object for all stages: the smoothing exponent lives in the device state, so the captured hipGraphs
             # are shared by the stages
             dspg = DeviceSpg(pl, sc, s, stages[0], floor, lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"],
-                             Hlength=prm["linesearch_history_length"], slots=prm["slots"], check_every=prm["check_every"])
+                             Hlength=prm["linesearch_history_length"], slots=prm["slots"] if slots is None else slots,
+                             check_every=prm["check_every"])
             out = None
             for stage, pq in enumerate(stages):
                 dspg.p = float(pq)
@@ -252,7 +255,7 @@ class SpgAllocator(object):
                         res, x = res_full, res_full["x"]
                     break
                 res_sub = run_stages(sub, scale_h[keep], to_dev(scale_h[keep]), x[keep] / x[keep].sum(), sub_stages, True,
-                                     window=int(prm["polish_stall_window"]))
+                                     window=int(prm["polish_stall_window"]), slots=int(prm["polish_slots"]) or None)
                 if res_sub is None:                                           # iteration budget (maxit) exhausted
                     break
                 res = res_sub

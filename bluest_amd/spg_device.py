@@ -77,9 +77,9 @@ class DeviceSpg(object):
 
     def _finish(self):
         plan = self.plan
-        check(self.lib.bluest_plan_grad(plan._h, self.v_ws, self.status.data_ptr(), 1, self.grad.data_ptr(), self.grad.stride(0), _stream()))
-        check(self.lib.bluest_spg_update_fused(plan._h, self.x.data_ptr(), self.g.data_ptr(), self.xnew.data_ptr(), self.grad.data_ptr(),
-                                               self.scale.data_ptr(), self.st.data_ptr(), self.floor, self.work.data_ptr(), _stream()))
+        check(self.lib.bluest_spg_finish(plan._h, self.v_ws, self.status.data_ptr(), self.x.data_ptr(), self.g.data_ptr(),
+                                         self.xnew.data_ptr(), self.grad.data_ptr(), self.scale.data_ptr(), self.st.data_ptr(),
+                                         self.floor, self.work.data_ptr(), _stream()))
 
     def _converged(self):
         check(self.lib.bluest_spg_converged(self.x.data_ptr(), self.g.data_ptr(), self.st.data_ptr(), 1.0, self.floor, self.L,

@@ -213,6 +213,12 @@ int bluest_spg_update(double *x_dev, double *g_dev, const double *xnew_dev, cons
  * the fly from the per-output gradients grad_dev (single candidate) */
 int bluest_spg_update_fused(bluest_plan_t plan, double *x_dev, double *g_dev, const double *xnew_dev, const double *grad_dev,
                             const double *scale_dev, double *state_dev, double floor, double *work_dev, void *stream);
+/* gradient of the accepted trial point + bluest_spg_update_fused in one call: bluest_plan_grad followed by the fused update, or --
+ * for small plans (K_tot <= 4096: the solver's working set) -- ONE single-workgroup kernel that does both.  v_dev / status_dev as
+ * handed out by bluest_plan_v_workspace. */
+int bluest_spg_finish(bluest_plan_t plan, const double *v_dev, const int32_t *status_dev, double *x_dev, double *g_dev,
+                      const double *xnew_dev, double *grad_dev, const double *scale_dev, double *state_dev, double floor,
+                      double *work_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Part 4 -- integer projection batch (bluest/misc.py:228-311 multi, :313-382 single)

@@ -259,3 +259,29 @@ def test_working_set_polish():
     Vp, Vn = max(mos.variances(m_p)), max(mos.variances(m_n))
     assert abs(m_p @ prob["costs"] / prob["budget"] - 1) < 1e-9 and (m_p >= 0).all()
     assert Vp <= Vn * (1 + 2e-5) and (m_p > 0).sum() <= 8 * n
+
+
+def test_setup_solver_integer_at_headline_size():
+    """the DEFAULT user path (integer projection) on the headline problem (n = 20, k_max = 5, K_tot = 21699, n_out = 8): a feasible
+    integer allocation close to the continuous optimum, budget mode and eps mode.  (With hundreds of sub-sample entries in the
+    SPG iterate this path once ended in "round everything up", 4 % over budget, after minutes of clean-up.)"""
+    import time
+    from bluest_amd import BLUEProblem
+    n, kmax, n_out = 20, 5, 8
+    prob = synth.problem(n, kmax, n_out)
+    p = BLUEProblem(n, C=[c.copy() for c in prob["C"]], costs=prob["w"], n_outputs=n_out, verbose=False)
+    B = prob["budget"]
+    cont = p.setup_solver(K=kmax, budget=B, solver="spg", continuous_relaxation=True)
+    t0 = time.perf_counter()
+    out = p.setup_solver(K=kmax, budget=B, solver="spg")
+    assert time.perf_counter() - t0 < 20.0
+    samples = np.asarray(out["samples"])
+    assert samples.dtype.kind == "i" and (samples >= 1).all() and len(out["models"]) <= 4 * n
+    assert out["total_cost"] <= 1.0001 * B
+    assert np.max(out["errors"]) <= 1.01 * np.max(cont["errors"])          # integrality costs < 1 % of the RMSE here
+    assert abs(np.max(cont["errors"]) ** 2 / 0.00094852 - 1) < 2e-4           # the continuous optimum itself (max_o V_o)
+    eps = [float(np.sqrt(c[0, 0]) / 30.0) for c in prob["C"]]
+    out_e = p.setup_solver(K=kmax, eps=eps, solver="spg")
+    assert (np.asarray(out_e["errors"]) <= np.sqrt(1.0001) * np.asarray(eps) * (1 + 1e-9)).all()
+    cont_e = p.setup_solver(K=kmax, eps=eps, solver="spg", continuous_relaxation=True)
+    assert out_e["total_cost"] <= 1.02 * cont_e["total_cost"]

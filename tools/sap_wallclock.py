@@ -15,6 +15,7 @@ from bluest_amd import synth  # noqa: E402
 from bluest_amd.mosap import MOSAP  # noqa: E402
 
 n, kmax, n_out = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (20, 5, 8)
+solver_params = {kv.split("=")[0]: eval(kv.split("=")[1]) for kv in sys.argv[4:]} or None     # e.g. polish_slots=3
 prob = synth.problem(n, kmax, n_out)
 groups = prob["groups"]
 torch.zeros(1, device="cuda")
@@ -31,7 +32,7 @@ for rep in range(2):        # second repetition = warm (library loaded, allocato
                 prob["costs"], [prob["costs"]] * n_out, verbose=False)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    m = mos.solve(budget=prob["budget"], solver="spg", continuous_relaxation=True)
+    m = mos.solve(budget=prob["budget"], solver="spg", continuous_relaxation=True, solver_params=solver_params)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     gc.enable()

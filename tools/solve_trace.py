@@ -51,8 +51,27 @@ def timed_capture(self, fn):
 
 
 spg_device.DeviceSpg._capture = timed_capture
-for rep in range(2):
+import gc
+run_total = [0.0]
+_logged = spg_device.DeviceSpg.run
+
+
+def summed(self, x0, **kw):
+    t0 = time.perf_counter()
+    r = _logged(self, x0, **kw)
+    run_total[0] += time.perf_counter() - t0
+    return r
+
+
+spg_device.DeviceSpg.run = summed
+for rep in range(3):
+    gc.collect()
+    gc.disable()
+    run_total[0] = 0.0
     t0 = time.perf_counter()
     m = mos.solve(budget=prob["budget"], solver="spg", continuous_relaxation=True, solver_params=params or None)
     torch.cuda.synchronize()
-    print("solve %.4f s  max V %.9g  nnz %d" % (time.perf_counter() - t0, max(mos.variances(m)), int((m > 0).sum())), mos.solver_info)
+    dt = time.perf_counter() - t0
+    gc.enable()
+    print("solve %.4f s (inside DeviceSpg.run incl. the trace's own syncs: %.4f s)  max V %.9g  nnz %d" % (
+        dt, run_total[0], max(mos.variances(m)), int((m > 0).sum())), mos.solver_info)

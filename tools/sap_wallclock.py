@@ -22,10 +22,11 @@ torch.zeros(1, device="cuda")
 torch.cuda.synchronize()
 out = {"n": n, "kmax": kmax, "n_out": n_out, "K_tot": prob["K_tot"]}
 mos = None
-for rep in range(2):        # second repetition = warm (library loaded, allocator warm)
+for rep in range(3):        # rep0 = cold; rep1 right after the first solve (HIP sometimes stalls ~80 ms tearing down its graphs); rep2 = warm
     mos = None              # release the previous plan (hipFree of ~45 MB) outside the timed region
     gc.collect()            # as timeit does: no cyclic-GC pause (30-70 ms with torch loaded) inside a 0.25 s measurement
-    gc.disable()
+    torch.zeros(1, device="cuda").cpu()   # a small synchronous copy: HIP finishes tearing down the PREVIOUS solve's graphs
+    gc.disable()                         # inside the next blocking copy (~80 ms, at random), which is not this repetition's work
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in groups] for _ in range(n_out)],

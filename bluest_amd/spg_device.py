@@ -253,5 +253,15 @@ class DeviceSpg(object):
                 hs = st.cpu().numpy()
             finally:
                 check(lib.bluest_plan_set_gate(plan._h, None, 0))
+        if not np.isfinite(hs[F]) or info == 2:
+            # a wait between the workgroups of the single-launch projection timed out (never observed; the kernel then returns
+            # NaN and raises a sticky flag in its workspace): say so instead of handing back a NaN allocation
+            L = self.L
+            if L > 4096:
+                off = 2 * L + 4 * ((L + 1023) // 1024)
+                if float(self.pws[off + 12]) != 0.0:
+                    self.pws[off + 12:off + 13].copy_(self._zero)
+                    raise RuntimeError("device SPG: the single-launch simplex projection timed out waiting for a workgroup "
+                                       "(BLUEST_PROJ_MULTI_LAUNCH=1 selects the multi-launch path)")
         return {"x": self.x.cpu().numpy(), "f": float(hs[F]) * norm, "gpmax": gpmax, "it": int(hs[IT]), "count": int(hs[COUNT]),
                 "solver_info": info, "norm": norm, "stalled": stalled}

@@ -4,21 +4,18 @@ bench.py -- headline benchmark of the BLUEST sample-allocation hot path on MI355
 
 metric   : Phi-assemblies/s.  One assembly = for ONE output, build Phi(m) over all K_tot groups, solve for
            V = e0^T Phi^-1 e0 and evaluate grad V for every group.
-workload : BASELINE.json configs[3]: n=20 models, groups up to size 5 (K_tot=21699), n_out=8 outputs,
-           synthetic Wishart covariances (bluest_amd/synth.py).  A "step" evaluates one allocation vector m for
-           all 8 outputs (what one SPG iteration / one MOSAP.variance_GH call does): 2 kernel launches
-           (Phi chunks -> fused fold + solve + gradient tiles), inputs resident in HBM, results left in HBM.
-N > 1    : one process per GPU.  Three ways to use more than one GPU:
-           --shard candidates (default): the unit of work is the evaluation of one allocation vector; independent vectors
-             (line-search trial points, integer-projection candidates, budget / tolerance sweeps) are the partition of the
-             path that has no exchange at all, so rank r evaluates ITS OWN allocation vector for all outputs in every
-             step.  Per-GPU work fixed => "scaling": "weak", value = N * n_out * steps / time; NO data-path collective.
-           --shard outputs: ONE allocation vector, rank r assembles outputs r*n_out/N.. (the outputs are independent
-             sample-allocation problems, bluest/mosap.py:39); no data-path collective; total work fixed ("strong"), and
-             latency-bound at the headline size: one output costs 13 us, eight cost 15 us.
-           --shard groups: ONE allocation vector, the group set is sharded, each step all-reduces the partial Phi records
-             (n_out*(n^2+2n+1) f64) over RCCL, every rank solves redundantly and evaluates the gradient of its shard
-             (bluest_amd/dist.py); "strong"; for K_tot in the 10^5..10^6 range.
+N = 1    : BASELINE.json configs[3] (the configuration the metric is quoted on): n=20 models, groups up to size 5
+           (K_tot=21699), n_out=8 outputs, synthetic Wishart covariances (bluest_amd/synth.py).  A "step" evaluates ONE allocation
+           vector m for all 8 outputs (what one SPG iteration / one MOSAP.variance_GH call does), inputs resident in HBM,
+           results left in HBM.  `value` is batch 1; `batched` reports the same workload with 4 / 16 allocation vectors per launch.
+N > 1    : BASELINE.json configs[4]: n=25, groups up to size 6 (K_tot=245505), single output, the GROUP SET sharded over
+           the N GPUs (bluest_amd/dist.py): every step each rank assembles the partial Phi of its groups, ONE all-reduce(SUM) of
+           the Phi record (n^2+2n+1 f64) over RCCL/xGMI, every rank solves redundantly and evaluates the gradient of its shard.
+           Total work fixed => "scaling": "strong".  The line also carries the same configuration on ONE GPU
+           (`single_gpu_value`) and N independent replicas of it (`replica_value`, no collective).
+           --shard candidates|outputs keep the headline configuration and split it by allocation vector / by output.
+timing   : W warm-up steps, then `repeats` x K steps between barrier + synchronize; `repeats` is chosen so that the timed region
+           lasts >= 50 ms (K as passed; ms_per_step = elapsed / (repeats*K)).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -34,8 +31,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_MODELS, KMAX, N_OUT = 20, 5, 8
-HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md
+HEADLINE = (20, 5, 8)      # n, k_max, n_out  -- BASELINE.json configs[3]
+SHARDED = (25, 6, 1)       # BASELINE.json configs[4]
+HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md
+MIN_TIMED_S = 0.05
 
 
 def build_outputs(prob):
@@ -45,21 +44,17 @@ def build_outputs(prob):
     return [{"K": prob["kmax"], "sizes": sizes, "groups": groups, "C": prob["C"][o], "mapping": None} for o in range(prob["n_out"])]
 
 
-def sap_wallclock(prob):
-    """second half of BASELINE.json's metric: setup_solver-style wall-clock from the covariances to the continuous optimum
-    m* (MOSAP construction: group pseudo-inverses + HBM layouts, then solver="spg" on the GPU), third (warm) repetition"""
+def sap_wallclock(prob, reps=4):
+    """second half of BASELINE.json's metric: wall-clock from the covariances to the continuous optimum m* (MOSAP construction:
+    group pseudo-inverses + HBM layouts, then solver="spg" on the GPU).  Nothing is hidden: repetition 0 is the cold one (first
+    launches, hipGraph captures), the others are warm; releasing a problem (plan memory + its captured graphs) is timed as
+    `release_s` of the repetition that created it, the garbage collector stays on."""
+    import gc
     import torch
     from bluest_amd.mosap import MOSAP
     groups, n_out, kmax = prob["groups"], prob["n_out"], prob["kmax"]
-    import gc
-    res = None
-    mos = None
-    for rep in range(3):                # the LAST repetition is reported: the first is cold, and the construction right after
-        # the first solve of a process sometimes stalls ~80 ms inside one HIP call while the runtime tears down that solve's graphs
-        mos = None                      # release the previous plan (hipFree of ~45 MB) outside the timed region
-        gc.collect()                    # as timeit does: no cyclic-GC pause (30-70 ms in a process with torch loaded) inside
-        torch.zeros(1, device="cuda").cpu()   # a small synchronous copy: HIP finishes tearing down the PREVIOUS solve's graphs
-        gc.disable()                         # inside the next blocking copy (~80 ms, at random), which is not this repetition's work                    # a 0.25 s measurement
+    rows = []
+    for rep in range(reps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in groups] for _ in range(n_out)],
@@ -69,25 +64,47 @@ def sap_wallclock(prob):
         m = mos.solve(budget=prob["budget"], solver="spg", continuous_relaxation=True)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        gc.enable()
-        res = {"setup_s": t1 - t0, "solve_s": t2 - t1, "total_s": t2 - t0, "spg_iterations": int(mos.solver_info["it"]),
-               "objective_evaluations": int(mos.solver_info["count"]), "max_variance": float(max(mos.variances(m))),
-               "budget": float(prob["budget"]), "solver": "spg (scaled metric, device-resident loop), continuous relaxation"}
-    return res
+        row = {"setup_s": t1 - t0, "solve_s": t2 - t1, "total_s": t2 - t0, "spg_iterations": int(mos.solver_info["it"]),
+               "objective_evaluations": int(mos.solver_info["count"]), "max_variance": float(max(mos.variances(m)))}
+        t3 = time.perf_counter()
+        mos = None
+        gc.collect()
+        torch.cuda.synchronize()
+        row["release_s"] = time.perf_counter() - t3
+        rows.append(row)
+    warm = rows[1:]
+    med = sorted(warm, key=lambda r: r["total_s"])[len(warm) // 2]
+    return {"cold_s": rows[0]["total_s"], "cold": rows[0], "warm_total_s": med["total_s"], "warm": med,
+            "warm_all_total_s": [r["total_s"] for r in warm], "release_s_all": [r["release_s"] for r in rows],
+            "budget": float(prob["budget"]), "solver": "spg (scaled metric, device-resident loop), continuous relaxation",
+            "note": "total_s = set-up + solve; cold = first repetition of the process; warm = median of the following %d; release_s = "
+                    "dropping the problem afterwards (plan memory, captured hipGraphs, a full Python collection)" % len(warm)}
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json, written
     by tools/pmc_traffic.py with the guide's gfx950 FETCH_SIZE correction); None if that profile is absent"""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    if not files:
-        return None
-    try:
-        d = json.load(open(files[-1]))
-        return d["kernels"][kernel]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            return json.load(open(f))["kernels"][kernel]["hbm_bytes_per_launch"]
+        except Exception:
+            continue
+    return None
+
+
+def rocprof_avg_us(kernel):
+    """average dispatch duration of `kernel` in the newest committed rocprofv3 --kernel-trace --stats summary (profiles/)"""
+    import csv
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats.csv")), reverse=True):
+        try:
+            for row in csv.DictReader(open(f)):
+                if kernel + "<" in row["Name"] or kernel + "(" in row["Name"]:
+                    return float(row["AverageNs"]) * 1e-3
+        except Exception:
+            continue
+    return None
 
 
 def cpu_baseline(prob, seconds=14.0):
@@ -131,19 +148,95 @@ def cpu_baseline(prob, seconds=14.0):
             "host_cores_available": os.cpu_count()}
 
 
-def rocprof_avg_us(kernel):
-    """average dispatch duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary (profiles/), or None"""
-    import csv
-    import glob
-    here = os.path.dirname(os.path.abspath(__file__))
-    for f in sorted(glob.glob(os.path.join(here, "profiles", "*_kernel_stats.csv")), reverse=True):
-        try:
-            for row in csv.DictReader(open(f)):
-                if kernel + "<" in row["Name"] or kernel + "(" in row["Name"]:
-                    return float(row["AverageNs"]) * 1e-3
-        except Exception:
-            continue
-    return None
+class Stepper(object):
+    """W warm-up steps, then repeats x K timed steps; a hipGraph of `cycle` consecutive steps is replayed when that is possible
+    (cycle <= K, so replays really happen inside the timed region) and everything else is launched eagerly -- the line says which"""
+
+    def __init__(self, torch, step, ring_len, steps, graph_steps, allow_graph, barrier):
+        self.torch, self.step, self.barrier = torch, step, barrier
+        self.steps = steps
+        self.cycle = 0
+        self.graph = None
+        cycle = min(graph_steps, steps)
+        cycle -= cycle % ring_len
+        if allow_graph and cycle >= ring_len:
+            try:
+                from bluest_amd._lib import capture_guard
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    for i in range(cycle):
+                        step(i)
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with capture_guard():
+                    # thread_local: a process-group watchdog thread may touch the runtime while we capture
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        for i in range(cycle):
+                            step(i)
+                self.graph, self.cycle = g, cycle
+            except Exception as err:   # keep the benchmark alive: eager launches measure the same work
+                sys.stderr.write("hipGraph capture failed (%s); falling back to eager launches\n" % err)
+                self.graph = None
+                torch.cuda.synchronize()
+
+    def run(self, nsteps):
+        done = 0
+        if self.graph is not None:
+            for _ in range(nsteps // self.cycle):
+                self.graph.replay()
+            done = nsteps - nsteps % self.cycle
+        for i in range(done, nsteps):
+            self.step(i)
+
+    def launch_label(self):
+        if self.graph is None:
+            return "eager"
+        replayed = self.steps - self.steps % self.cycle
+        return "hipGraph replay of %d-step graphs (%d of %d steps), rest eager" % (self.cycle, replayed, self.steps)
+
+    def timed(self, warmup):
+        """returns (seconds per step, repeats): the K-step block is repeated until the timed region is >= MIN_TIMED_S"""
+        self.run(warmup)
+        self.barrier()
+        t0 = time.perf_counter()
+        self.run(self.steps)
+        self.barrier()
+        pilot = time.perf_counter() - t0
+        repeats = max(1, int(np.ceil(MIN_TIMED_S / max(pilot, 1e-9))))
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(repeats):
+            self.run(self.steps)
+        self.barrier()
+        return (time.perf_counter() - t0) / (repeats * self.steps), repeats
+
+
+def chain_time(torch, fn, R=50, reps=20):
+    """average duration of one launch sequence fn(): hipGraph of R back-to-back calls on the launch stream, HIP events around
+    the replay (one "launch" = the kernels plus the dispatch gap to the successor), median of `reps` replays"""
+    from bluest_amd._lib import capture_guard
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with capture_guard():
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            for _ in range(R):
+                fn()
+    g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3 / R)
+    return float(np.median(ts))
 
 
 def main():
@@ -153,12 +246,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sap", action="store_true", help="skip the SAP wall-clock leg (covariances -> continuous optimum)")
+    ap.add_argument("--no-batched", action="store_true", help="skip the batched-throughput leg")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying a hipGraph")
-    ap.add_argument("--graph-steps", type=int, default=40, help="steps captured per hipGraph")
+    ap.add_argument("--graph-steps", type=int, default=40, help="steps captured per hipGraph (capped at --steps)")
     ap.add_argument("--shard", choices=["auto", "candidates", "outputs", "groups"], default="auto")
-    ap.add_argument("--n", type=int, default=N_MODELS)
-    ap.add_argument("--kmax", type=int, default=KMAX)
-    ap.add_argument("--n-out", type=int, default=N_OUT)
+    ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--kmax", type=int, default=None)
+    ap.add_argument("--n-out", type=int, default=None)
     args = ap.parse_args()
 
     import torch
@@ -178,37 +272,48 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ranks_seen = 1
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        ones = torch.ones(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks_seen = int(ones[0])
 
-    prob = synth.problem(args.n, args.kmax, args.n_out)
-    L = prob["K_tot"]
     shard = args.shard
     if shard == "auto":
-        shard = "candidates"
-    if shard == "outputs" and args.n_out % world:
+        shard = "groups" if world > 1 else "candidates"
+    base = SHARDED if (world > 1 and shard == "groups") else HEADLINE
+    n = args.n if args.n is not None else base[0]
+    kmax = args.kmax if args.kmax is not None else base[1]
+    n_out_all = args.n_out if args.n_out is not None else base[2]
+    prob = synth.problem(n, kmax, n_out_all)
+    L = prob["K_tot"]
+    if shard == "outputs" and n_out_all % world:
         raise SystemExit("--shard outputs needs n_out divisible by the number of GPUs")
-    my_outputs = list(range(args.n_out))
+    BATCHES = (4, 16)
+    max_cand = max(BATCHES) if (world == 1 and not args.no_batched) else 1
+    my_outputs = list(range(n_out_all))
+    sharded = None
     if world == 1 or shard == "candidates":
-        plan = Plan(args.n, L, build_outputs(prob), max_candidates=1, device=dev)
-        sharded = None
+        plan = Plan(n, L, build_outputs(prob), max_candidates=max_cand, device=dev)
     elif shard == "outputs":
-        per = args.n_out // world
+        per = n_out_all // world
         my_outputs = list(range(rank * per, (rank + 1) * per))
-        plan = Plan(args.n, L, [build_outputs(prob)[o] for o in my_outputs], max_candidates=1, device=dev)
-        sharded = None
+        plan = Plan(n, L, [build_outputs(prob)[o] for o in my_outputs], max_candidates=1, device=dev)
     else:
         from bluest_amd.dist import ShardedPlan
-        sharded = ShardedPlan(args.n, [len(g) for g in prob["groups"]], build_outputs(prob), max_candidates=1, device=dev)
+        sharded = ShardedPlan(n, [len(g) for g in prob["groups"]], build_outputs(prob), max_candidates=1, device=dev)
         plan = sharded.plan
     n_out = plan.n_out
 
     # a small ring of different allocation vectors so that consecutive steps do not repeat the same input
-    rng = np.random.RandomState(2024 + (rank if shard == "candidates" else 0))   # candidates: every rank its own vectors
-    ring = [torch.from_numpy(prob["m"][0] if rank == 0 or shard != "candidates" else 10.0 * rng.rand(L)).to(dev)] + [torch.from_numpy(10.0 * rng.rand(L)).to(dev) for _ in range(3)]
+    weak = world > 1 and shard == "candidates"
+    rng = np.random.RandomState(2024 + (rank if weak else 0))   # candidates: every rank its own vectors
+    first = prob["m"][0] if (rank == 0 or not weak) else 10.0 * rng.rand(L)
+    ring = [torch.from_numpy(v).to(dev) for v in [first] + [10.0 * rng.rand(L) for _ in range(3)]]
     var = torch.empty((1, n_out), dtype=torch.float64, device=dev)
     grad = torch.empty((1, plan.grad_len), dtype=torch.float64, device=dev)
     status = torch.empty((1, n_out), dtype=torch.int32, device=dev)
@@ -219,151 +324,142 @@ def main():
         if sharded is None:
             plan.eval(m, out=(var, grad, status))
         else:
-            v2, g2, st = sharded.eval(m, rec=rec)      # phi -> all-reduce(SUM) over RCCL -> solve -> grad of the shard
-            var.copy_(v2)
-
-    # ---- optional hipGraph of one ring cycle (single GPU; RCCL is left eager) -----------------------
-    use_graph = (sharded is None) and not args.no_graph
-    cycle = max(len(ring), args.graph_steps - args.graph_steps % len(ring))
-    graph = None
-    if use_graph:
-        try:
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                for i in range(cycle):
-                    step(i)
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            # thread_local: a process-group watchdog thread may touch the runtime while we capture
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                for i in range(cycle):
-                    step(i)
-        except Exception as err:   # keep the benchmark alive: eager launches measure the same work
-            sys.stderr.write("hipGraph capture failed (%s); falling back to eager launches\n" % err)
-            graph = None
-            torch.cuda.synchronize()
-
-    def run(nsteps):
-        if graph is not None:
-            for _ in range(nsteps // cycle):
-                graph.replay()
-            for i in range(nsteps % cycle):
-                step(i)
-        else:
-            for i in range(nsteps):
-                step(i)
+            sharded.eval(m, rec=rec, out=(var, grad, status))   # phi -> all-reduce(SUM) over RCCL -> solve -> grad of the shard
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # RCCL launches are left eager (a collective inside a captured graph is a different code path of the library)
+    stepper = Stepper(torch, step, len(ring), args.steps, args.graph_steps, (sharded is None) and not args.no_graph, barrier)
+    sec_per_step, repeats = stepper.timed(args.warmup)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([sec_per_step], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-    assert bool((status == 0).all()) or sharded is not None
+        sec_per_step = float(t[0])
+    assert bool((status == 0).all())
     assert bool(torch.isfinite(var).all())
-    weak = world > 1 and shard == "candidates"
+
+    extra = {}
     if world > 1 and not weak:
-        # self-check outside the timed region: the sharded evaluation equals the unsharded one
+        # outside the timed region: (1) the sharded evaluation equals the unsharded one; (2) the same configuration on ONE GPU
+        # and as N independent replicas (every rank the whole problem, no collective)
         step(0)
-        full = Plan(args.n, L, build_outputs(prob), max_candidates=1, device=dev)
-        v_full, g_full, _ = full.eval(ring[0])
+        torch.cuda.synchronize()
+        full = Plan(n, L, build_outputs(prob), max_candidates=1, device=dev)
+        v_full, g_full, st_full = full.eval(ring[0])
         v_mine = v_full[0, my_outputs] if sharded is None else v_full[0]
         assert float((var[0] / v_mine - 1).abs().max()) < 1e-10, "sharded evaluation disagrees with the single-GPU one"
+        fv = torch.empty_like(v_full); fg = torch.empty_like(g_full); fs = torch.empty_like(st_full)
+        full_step = lambda i: full.eval(ring[i % len(ring)], out=(fv, fg, fs))      # noqa: E731
+        rep_stepper = Stepper(torch, full_step, len(ring), args.steps, args.graph_steps, not args.no_graph, barrier)
+        rep_sec, _ = rep_stepper.timed(args.warmup)
+        t = torch.tensor([rep_sec], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        extra["replica_value"] = world * n_out_all / float(t[0])
+        extra["replica_note"] = "%d independent replicas of the same configuration (each GPU the whole group set, no collective); max over ranks" % world
+        # one GPU alone, the others idle at the barrier
+        solo = torch.zeros(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if rank == 0:
+            solo_stepper = Stepper(torch, full_step, len(ring), args.steps, args.graph_steps, not args.no_graph, lambda: torch.cuda.synchronize())
+            solo[0] = solo_stepper.timed(args.warmup)[0]
+        dist.all_reduce(solo)
+        extra["single_gpu_value"] = n_out_all / float(solo[0])
+        extra["single_gpu_ms_per_step"] = float(solo[0]) * 1e3
         del full
 
     # ---- per-kernel durations with HIP events on the launch stream (single GPU) -----------------------
     roofline = None
     kern = {}
+    batched = None
+    ab = synth.algorithmic_bytes(n, kmax)
+    if rank == 0 and world == 1:
+        from bluest_amd.plan import _stream
+        lib, h = plan.lib, plan._h
+        m = ring[0]
+        var2, vv, st2 = plan.solve(plan.phi(m, out=rec))
+        t_chunks = chain_time(torch, lambda: lib.bluest_plan_phi_chunks(h, m.data_ptr(), 1, L, _stream()))
+        t_nograd = chain_time(torch, lambda: plan.eval(m, want_grad=False, out=(var, None, status)))
+        t_grad = chain_time(torch, lambda: plan.grad(vv, st2, out=grad))
+        t_step = chain_time(torch, lambda: plan.eval(m, out=(var, grad, status)))
+        kern = {"method": "hipGraph of 50 back-to-back launches, HIP events around the replay, median of 20",
+                "k_phi_chunks_us": t_chunks * 1e6, "step_us": t_step * 1e6,
+                "k_solve_grad_us(step - chunks; fused solve+gradient)": (t_step - t_chunks) * 1e6,
+                "separate_path": {"k_phi_chunks+k_solve_from_chunks_us": t_nograd * 1e6,
+                                  "k_solve_from_chunks_us(by difference)": (t_nograd - t_chunks) * 1e6,
+                                  "k_grad_tiles_us": t_grad * 1e6}}
+        # dominant kernel = the longer of the two launches of a step
+        t_sg = t_step - t_chunks
+        if t_sg >= t_chunks:
+            kname, tk, abytes, lbytes = "k_solve_grad", max(t_sg, 1e-9), ab["grad"] * n_out, plan.grad_bytes
+        else:
+            kname = "k_phi_chunks_shared" if n_out >= 2 else "k_phi_chunks"
+            tk, abytes, lbytes = max(t_chunks, 1e-9), ab["phi"] * n_out, plan.phi_bytes
+        rp = rocprof_avg_us(kname)
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": abytes / tk / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": abytes / tk / HBM_PEAK, "headline_clock": "frac = frac_chain (measured live in this run)",
+                    "frac_chain": abytes / tk / HBM_PEAK,
+                    "frac_rocprof": None if rp is None else abytes / (rp * 1e-6) / HBM_PEAK,
+                    "traffic": pmc_traffic(kname),
+                    "traffic_source": "profiles/*_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)",
+                    "algorithmic_bytes_per_launch": abytes, "layout_bytes_per_launch": lbytes, "avg_launch_us": tk * 1e6,
+                    "clocks": "chain: HIP events around a graph of dependent launches, one launch = kernel + dispatch gap to its "
+                              "successor (this run); rocprof: begin-to-end of the dispatch alone from the committed "
+                              "rocprofv3 --kernel-trace summary under profiles/",
+                    "rocprof_avg_us": rp,
+                    "step": {"algorithmic_bytes": ab["eval"] * n_out, "achieved_GBps": ab["eval"] * n_out / sec_per_step / 1e9,
+                             "frac": ab["eval"] * n_out / sec_per_step / HBM_PEAK}}
+        if not args.no_batched:
+            # batched throughput: nc DIFFERENT allocation vectors per launch (line-search trial points, integer candidates);
+            # the inverse-covariance streams are read once per launch whatever nc is
+            batched = {}
+            for nc in BATCHES:
+                rngb = np.random.RandomState(77 + nc)
+                rings = [torch.from_numpy(10.0 * rngb.rand(nc, L)).to(dev) for _ in range(2)]
+                bv = torch.empty((nc, n_out), dtype=torch.float64, device=dev)
+                bg = torch.empty((nc, plan.grad_len), dtype=torch.float64, device=dev)
+                bs = torch.empty((nc, n_out), dtype=torch.int32, device=dev)
+                bstep = lambda i, rings=rings, bv=bv, bg=bg, bs=bs: plan.eval(rings[i % 2], out=(bv, bg, bs))   # noqa: E731
+                bst = Stepper(torch, bstep, 2, max(40, args.steps // nc), args.graph_steps, not args.no_graph, barrier)
+                sec, rpt = bst.timed(max(4, args.warmup // nc))
+                assert bool((bs == 0).all())
+                batched["n_cand=%d" % nc] = {"value": nc * n_out / sec, "ms_per_launch_sequence": sec * 1e3,
+                                             "steps": bst.steps, "repeats": rpt, "launch": bst.launch_label(),
+                                             "algorithmic_GBps": nc * ab["eval"] * n_out / sec / 1e9,
+                                             "frac_of_hbm_peak_algorithmic": nc * ab["eval"] * n_out / sec / HBM_PEAK}
+            batched["note"] = ("same workload, nc allocation vectors evaluated per launch sequence; algorithmic bytes count every "
+                               "evaluation in the reference layout, so a fraction above 1 only says that the streams are read "
+                               "once per batch, not once per vector")
+
     if rank == 0:
-        ab = synth.algorithmic_bytes(args.n, args.kmax)
         if world == 1:
-            from bluest_amd.plan import _stream
-            lib, h = plan.lib, plan._h
-            m = ring[0]
-            var2, vv, st2 = plan.solve(plan.phi(m, out=rec))
-            R = 50
-
-            def timed(fn):
-                """average duration of one launch: hipGraph of R back-to-back launches on the launch stream, HIP events
-                around the replay (this is what rocprofv3 --kernel-trace reports per dispatch: end-to-end on a busy queue)"""
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    fn()
-                torch.cuda.current_stream().wait_stream(side)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    for _ in range(R):
-                        fn()
-                g.replay()
-                torch.cuda.synchronize()
-                ts = []
-                for _ in range(20):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(); g.replay(); e1.record()
-                    torch.cuda.synchronize()
-                    ts.append(e0.elapsed_time(e1) * 1e-3 / R)
-                return float(np.median(ts))
-
-            t_chunks = timed(lambda: lib.bluest_plan_phi_chunks(h, m.data_ptr(), 1, L, _stream()))
-            t_nograd = timed(lambda: plan.eval(m, want_grad=False, out=(var, None, status)))
-            t_grad = timed(lambda: plan.grad(vv, st2, out=grad))
-            t_step = timed(lambda: plan.eval(m, out=(var, grad, status)))
-            kern = {"method": "hipGraph of %d back-to-back launches, HIP events around the replay, median of 20" % R,
-                    "k_phi_chunks_us": t_chunks * 1e6, "step_us": t_step * 1e6,
-                    "k_solve_grad_us(step - chunks; fused solve+gradient)": (t_step - t_chunks) * 1e6,
-                    "separate_path": {"k_phi_chunks+k_solve_from_chunks_us": t_nograd * 1e6,
-                                      "k_solve_from_chunks_us(by difference)": (t_nograd - t_chunks) * 1e6,
-                                      "k_grad_tiles_us": t_grad * 1e6}}
-            # dominant kernel = the longer of the two streaming passes
-            t_sg = t_step - t_chunks
-            if t_sg >= t_chunks:
-                kname, tk, abytes, lbytes = "k_solve_grad", max(t_sg, 1e-9), ab["grad"] * n_out, plan.grad_bytes
-            else:
-                kname = "k_phi_chunks_shared" if n_out >= 2 else "k_phi_chunks"
-                tk, abytes, lbytes = max(t_chunks, 1e-9), ab["phi"] * n_out, plan.phi_bytes
-            achieved = abytes / tk
-            roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(kname),
-                        "traffic_source": "profiles/*_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)",
-                        "algorithmic_bytes_per_launch": abytes, "layout_bytes_per_launch": lbytes, "avg_launch_us": tk * 1e6,
-                        "avg_launch_us_note": "HIP events around a chain of launches: one launch = kernel + the ~2.5 us dispatch gap to "
-                                              "its successor; rocprofv3 --kernel-trace (begin to end of the dispatch alone) is in rocprof_avg_us",
-                        "rocprof_avg_us": rocprof_avg_us(kname),
-                        "step": {"algorithmic_bytes": ab["eval"] * n_out, "achieved_GBps": ab["eval"] * n_out * args.steps / elapsed / 1e9,
-                                 "frac": ab["eval"] * n_out * args.steps / elapsed / HBM_PEAK}}
-
-    if rank == 0:
+            par = "single GPU"
+        elif weak:
+            par = "candidate axis over %d GPUs: every GPU evaluates its own allocation vector for all %d outputs per step, no data-path collective" % (world, n_out_all)
+        elif sharded is None:
+            par = "outputs sharded over %d GPUs (%d per GPU), no data-path collective" % (world, len(my_outputs))
+        else:
+            par = "group set sharded over %d GPUs (contiguous shards balanced by sum k^2), one all-reduce(SUM) of the Phi record (%d f64) per step" % (world, n_out * plan.reclen)
         out = {
-            "metric": "Phi-assemblies/s", "value": args.steps * args.n_out * (world if weak else 1) / elapsed, "unit": "assemblies/s (one output: Phi(m) over all groups -> V, grad V)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "metric": "Phi-assemblies/s", "value": n_out_all * (world if weak else 1) / sec_per_step,
+            "unit": "assemblies/s (one output: Phi(m) over all groups -> V, grad V)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "repeats": repeats, "ms_per_step": sec_per_step * 1e3,
+            "timed_region_s": sec_per_step * repeats * args.steps,
             "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "collective_backend": None if world == 1 else backend,
+            "collective_backend": None if (world == 1 or weak or sharded is None) else ("rccl" if backend == "nccl" else backend),
+            "ranks_seen": ranks_seen,
             "config": {"workload": "n=%d models, groups up to size %d (K_tot=%d), n_out=%d, Wishart covariances; one step = V and grad V of one allocation for all outputs"
-                                   % (args.n, args.kmax, L, args.n_out),
-                       "n_models": args.n, "k_max": args.kmax, "K_tot": L, "n_out": args.n_out, "batch": 1,
-                       "parallelism": "single GPU" if world == 1 else (
-                           "candidate axis over %d GPUs: every GPU evaluates its own allocation vector for all %d outputs per step, no data-path collective"
-                           % (world, args.n_out) if weak else
-                           "outputs sharded over %d GPUs (%d per GPU), no data-path collective" % (world, len(my_outputs)) if sharded is None
-                           else "group set sharded over %d GPUs, all-reduce of the Phi records per step" % world),
-                       "launch": "hipGraph replay" if graph is not None else "eager"},
+                                   % (n, kmax, L, n_out_all),
+                       "n_models": n, "k_max": kmax, "K_tot": L, "n_out": n_out_all, "batch": 1, "parallelism": par,
+                       "launch": stepper.launch_label()},
             "kernels_us": kern,
         }
+        out.update(extra)
         if roofline is not None:
             out["roofline"] = roofline
+        if batched is not None:
+            out["batched"] = batched
         if world == 1 and not args.no_sap:
             out["sap_wallclock"] = sap_wallclock(prob)
         if world == 1 and not args.no_cpu_baseline:

@@ -7,7 +7,7 @@ raises loudly if either is missing (there is no CPU fallback).
 """
 from ._lib import BluestHipError  # noqa: F401
 
-__all__ = ["SAP", "MOSAP", "BLUESTError", "BLUEProblem", "blue_fn", "BluestHipError"]
+__all__ = ["SAP", "MOSAP", "BLUESTError", "BLUEProblem", "BluestHipError"]
 
 
 def __getattr__(name):
@@ -24,7 +24,4 @@ def __getattr__(name):
     if name == "BLUEProblem":
         from .blue_models import BLUEProblem
         return BLUEProblem
-    if name == "blue_fn":
-        from .blue_fn import blue_fn
-        return blue_fn
     raise AttributeError(name)

@@ -33,6 +33,8 @@ SIGNATURES = {
     "bluest_group_pinv": [c_vp, c_int, c_int, c_i64, c_vp, c_vp],
     "bluest_plan_create": [ctypes.POINTER(c_vp), c_int, c_i64],
     "bluest_plan_destroy": [c_vp],
+    "bluest_capture_guard": [c_int],
+    "bluest_deferred_plans": [ctypes.POINTER(c_int)],
     "bluest_plan_add_output": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp],
     "bluest_plan_add_output_cov": [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp],
     "bluest_plan_finalize": [c_vp, c_int],
@@ -112,3 +114,30 @@ def ptr(a):
     if hasattr(a, "data_ptr"):
         return a.data_ptr()
     return a.ctypes.data
+
+
+class capture_guard(object):
+    """with capture_guard(): ... -- plans (and anything registered with `park`) dropped while a hipGraph is being captured
+    are released only when the capture is over (include/bluest_hip.h: bluest_capture_guard)"""
+    depth = 0
+    parked = []
+
+    def __enter__(self):
+        lib().bluest_capture_guard(1)
+        capture_guard.depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        capture_guard.depth -= 1
+        lib().bluest_capture_guard(0)
+        if capture_guard.depth == 0:
+            del capture_guard.parked[:]          # destroys the parked hipGraphs now that no capture is running
+        return False
+
+    @staticmethod
+    def park(objects):
+        """keep `objects` (captured hipGraphs of a solver that is going away) alive until no capture is in progress"""
+        if capture_guard.depth > 0:
+            capture_guard.parked.extend(objects)
+            return True
+        return False

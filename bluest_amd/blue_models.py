@@ -1,98 +1,121 @@
 """
-BLUEProblem -- user-facing API for the sample-allocation path, mirroring bluest/blue_models.py: same constructor,
-`setup_solver()` / `solve()` signatures and return values (:448-576), same model-graph conventions (:160-179,
-:232-263: the graph adjacency is the covariance with 0 = not coupled and inf = uncorrelated), same group
-construction from cliques (:458-501, with hashing instead of the O(L_k^2) list search at :497) and group costs
-(:137-140).  The optimiser is `solver="spg"` on the GPU (the reference default "cvxopt" and its other third-party
-back-ends are outside this build); MLMC / MFMC / plain-MC drivers (:578-930) are out of scope.
+BLUEProblem -- the user-facing entry of the sample-allocation path: the signatures and return values
+of `setup_solver()` / `solve()` of bluest/blue_models.py:448-576, on top of bluest_amd.mosap.MOSAP.
+
+In scope here: given covariances and model costs -> model groups (cliques of the coupling graph up to size K, or the user's
+groups), their union over the outputs, group costs, one MOSAP on the GPU, `solver="spg"`, the reference's return dictionaries;
+`solve()` then samples the selected groups through the user's `sampler` / `evaluate` and forms the BLUE estimators.
+Out of scope (refused with BLUESTError): estimating covariances or costs by sampling, the SPD
+projection of incomplete covariances, saving / loading model graphs, MLMC / MFMC / plain-MC drivers, MPI sample splitting.
+
+Conventions kept from the reference (bluest/blue_models.py:43-56, :166-179): in a user covariance an infinite entry means "never
+couple these two models", a zero entry means "uncorrelated" (such pairs are not coupled either when `remove_uncorrelated`, the
+default); `get_covariance()` returns NaN where two models are not coupled.  Models that cannot be reached from model 0 through
+couplings are left out of every group (:312-322).
 """
 from itertools import combinations
 
 import numpy as np
 
-from .blue_fn import SerialComm, blue_fn
 from .mosap import MOSAP
 from .sap import BLUESTError
-from .spg import spg
 
-spg_default_params = {"maxit": 10000,           # bluest/blue_models.py:10-18
-                      "max_fevals": 10000 ** 2,
-                      "verbose": False,
-                      "spd_threshold": 5.0e-14,
-                      "eps": 1.0e-10,
-                      "lmbda_min": 10. ** -30,
-                      "lmbda_max": 10. ** 30,
-                      "linesearch_history_length": 10,
-                      }
-
-default_params = {                               # bluest/blue_models.py:20-31, optimiser default changed to "spg"
-    "verbose": True,
-    "comm": None,
-    "remove_uncorrelated": True,
-    "optimization_solver": "spg",
-    "covariance_estimation_samples": 100,
-    "sample_batch_size": 1,
-    "samplefile": None,
-    "outputs_to_save": None,
-    "skip_projection": False,
-    "spg_params": spg_default_params,
-}
+default_params = {"verbose": True, "comm": None, "remove_uncorrelated": True, "optimization_solver": "spg", "sample_batch_size": 1}
 
 
-def next_divisible_number(x, n):
-    return n * (x // n + int(x % n > 0))
+class _Coupling(object):
+    """coupling structure of ONE output: the covariance and which pairs of models may share a group"""
+
+    def __init__(self, C, remove_uncorrelated):
+        C = np.array(C, dtype=np.float64)
+        M = C.shape[0]
+        if C.shape != (M, M):
+            raise ValueError("covariance must be square")
+        if np.isnan(C).any():
+            raise BLUESTError("unknown (NaN) covariance entries would have to be estimated by sampling and projected to SPD "
+                              "(bluest/blue_models.py:326-433): outside this GPU build -- pass complete covariances")
+        never = np.isinf(C)
+        self.cov = np.where(never, 0.0, C)
+        self.linked = ~never
+        if remove_uncorrelated:
+            self.linked &= (self.cov != 0.0)
+        np.fill_diagonal(self.linked, True)
+        self.linked &= self.linked.T
+        # models reachable from model 0
+        seen, frontier = {0}, [0]
+        while frontier:
+            nxt = []
+            for i in frontier:
+                for j in np.flatnonzero(self.linked[i]).tolist():
+                    if j not in seen:
+                        seen.add(j)
+                        nxt.append(j)
+            frontier = nxt
+        self.component = sorted(seen)
+
+    def covariance(self):
+        out = self.cov.copy()
+        out[~self.linked] = np.nan
+        return out
+
+    def is_clique(self, group):
+        g = np.asarray(group, dtype=np.int64)
+        return bool(self.linked[np.ix_(g, g)].all()) and all(int(i) in set(self.component) for i in g)
+
+    def cliques(self, K):
+        """all cliques of up to K models inside model 0's component, per size, each sorted, lexicographic order"""
+        nodes = self.component
+        sub = self.linked[np.ix_(nodes, nodes)]
+        if sub.all():
+            return [np.array(list(combinations(nodes, k)), dtype=np.int64).reshape(-1, k) for k in range(1, K + 1)]
+        out = [[(i,) for i in nodes]]
+        for k in range(2, K + 1):                                # extend every (k-1)-clique by a larger, fully linked model
+            bigger = []
+            for c in out[-1]:
+                cand = self.linked[list(c)].all(axis=0)
+                bigger += [c + (j,) for j in nodes if j > c[-1] and cand[j]]
+            out.append(bigger)
+        return [np.array(level, dtype=np.int64).reshape(-1, k + 1) for k, level in enumerate(out)]
 
 
 class BLUEProblem(object):
     def __init__(self, M, C=None, costs=None, mlmc_variances=None, datafile=None, n_outputs=1, **params):
-        """bluest/blue_models.py:43-103.  C: M x M covariance (list over outputs for n_outputs > 1); NaN = unknown
-        (estimated by sampling), inf = models that must not be coupled."""
-        import networkx as nx
-        self._nx = nx
-        self.M = M
-        self.n_outputs = n_outputs
+        self.M, self.n_outputs = int(M), int(n_outputs)
+        self.params = dict(default_params, **params)
+        self.default_params = default_params
+        comm = self.params["comm"]
+        self.mpiRank = 0 if comm is None else comm.Get_rank()
+        self.mpiSize = 1 if comm is None else comm.Get_size()
+        self.comm = comm
+        self.warning = self.mpiRank == 0
+        self.verbose = bool(self.params["verbose"]) and self.warning
         self.MOSAP = None
         self.MOSAP_output = None
-
-        self.default_params = default_params
-        self.params = default_params.copy()
-        spg_params = spg_default_params.copy()
-        spg_params.update(params.get("spg_params", {}))
-        params["spg_params"] = spg_params
-        self.params.update(params)
-
-        self.comm = self.params["comm"] if self.params["comm"] is not None else SerialComm()
-        self.mpiSize = self.comm.Get_size()
-        self.mpiRank = self.comm.Get_rank()
-        self.warning = self.mpiRank == 0
-        self.verbose = self.params["verbose"] and self.warning
-
-        if C is None: C = [np.nan * np.ones((M, M)) for n in range(n_outputs)]
-        dV = [np.nan * np.ones((M, M)) for n in range(n_outputs)] if mlmc_variances is None else mlmc_variances
-
         if datafile is not None:
-            self.load_graph_data(datafile, costs)
-            self.check_costs(warning=True)
-        else:
-            if not isinstance(C, (list, tuple)): C = [C]
-            if not isinstance(dV, (list, tuple)): dV = [dV]
-            self.G = [self.get_model_graph(np.array(C[n], dtype=np.float64), costs=costs) for n in range(n_outputs)]
-            self.SG = [list(range(M)) for n in range(n_outputs)]
-            self.dV = dV
-            if costs is None: self.estimate_costs(self.get_comm().Get_size())
-            self.check_costs(warning=True)
-            self.estimate_missing_covariances(next_divisible_number(self.params["covariance_estimation_samples"], self.mpiSize))
-            if not self.params["skip_projection"]:
-                self.project_covariances()
-            self.check_graphs(remove_uncorrelated=self.params["remove_uncorrelated"])
+            raise BLUESTError("model-graph files (bluest/blue_models.py:265-299) are outside this GPU build: pass C and costs")
+        if C is None or costs is None:
+            raise BLUESTError("covariances and costs must be given: estimating them by sampling (bluest/blue_models.py:326-346, "
+                              ":435-441) is outside this GPU build")
+        Cs = list(C) if isinstance(C, (list, tuple)) else [C]
+        if len(Cs) != self.n_outputs or any(np.shape(c) != (self.M, self.M) for c in Cs):
+            raise ValueError("need one %d x %d covariance per output" % (self.M, self.M))
+        self._costs = np.array(costs, dtype=np.float64)
+        if self._costs.shape != (self.M,):
+            raise ValueError("costs must have one entry per model")
+        self._coupling = [_Coupling(c, self.params["remove_uncorrelated"]) for c in Cs]
+        self.SG = [cp.component for cp in self._coupling]
+        for n, cp in enumerate(self._coupling):
+            if len(cp.component) < self.M and self.warning:
+                print("WARNING! Model graph %d is not connected. Connected graph size: %d" % (n, len(cp.component)))
+        self.check_costs(warning=True)
         if self.verbose: print("\nBLUE estimator ready.\n")
 
-    # ---- to be overloaded by the user (blue_models.py:105-130) --------------------------------------------
+    # ---- supplied by the user (bluest/blue_models.py:105-119) -----------------------------------------------------------------
     def evaluate(self, ls, samples, N=1):
-        raise NotImplementedError
+        raise NotImplementedError("subclass BLUEProblem and implement evaluate(ls, samples)")
 
     def sampler(self, ls, N=1):
-        raise NotImplementedError
+        raise NotImplementedError("subclass BLUEProblem and implement sampler(ls)")
 
     def get_models_inner_products(self):
         return [lambda a, b: a * b for n in range(self.n_outputs)]
@@ -100,354 +123,156 @@ class BLUEProblem(object):
     def get_comm(self):
         return self.comm
 
-    # ---- utilities (blue_models.py:134-196) ----------------------------------------------------------------
+    # ---- data access ----------------------------------------------------------------------------------------------------------
     def get_costs(self):
-        return np.array([self.G[0].nodes[l]['cost'] for l in range(self.M)])
+        return self._costs.copy()
 
     def get_group_costs(self, groups):
-        """cost of a group = sum of its models' costs (blue_models.py:137-140), one vectorised sum per group size"""
-        model_costs = self.get_costs()
-        out = []
-        for groupsk in groups:
-            if len(groupsk) == 0:
-                continue
-            gk = np.asarray(groupsk)
-            if gk.dtype != object and gk.ndim == 2:
-                out.append(model_costs[gk].sum(axis=1))
-            else:                                   # ragged list (mixed sizes in one bucket): the reference's loop
-                out.append(np.array([sum(model_costs[group]) for group in groupsk]))
-        return np.concatenate(out) if out else np.zeros(0)
+        """cost of a group = sum of the costs of its models (bluest/blue_models.py:137-140); one entry per group, size-major"""
+        parts = [self._costs[np.asarray(gk, dtype=np.int64).reshape(len(gk), -1)].sum(axis=1) for gk in groups if len(gk)]
+        return np.concatenate(parts) if parts else np.zeros(0)
 
     def check_costs(self, warning=True):
-        more_expensive_models = []
-        costs = self.get_costs()
-        if costs[0] != costs.max():
-            more_expensive_models = [self.G[0].nodes[i]["model_number"] for i in np.argwhere(costs > costs[0]).flatten()]
-            if warning:
-                if self.warning: print("WARNING! Model zero is not the most expensive model. The more expensive models are: %s" % more_expensive_models)
-            else:
-                raise ValueError("Model zero is not the most expensive model. Consider removing the more expensive models %s" % more_expensive_models)
-        return more_expensive_models
+        dearer = np.flatnonzero(self._costs > self._costs[0]).tolist()
+        if dearer:
+            if not warning:
+                raise ValueError("Model zero is not the most expensive model. Consider removing the more expensive models %s" % dearer)
+            if self.warning:
+                print("WARNING! Model zero is not the most expensive model. The more expensive models are: %s" % dearer)
+        return dearer
+
+    def get_covariance(self, n=0):
+        return self._coupling[n].covariance()
 
     def get_covariances(self):
-        return [self.get_covariance(n) for n in range(self.n_outputs)]
+        return [cp.covariance() for cp in self._coupling]
+
+    def get_correlation(self, n=0):
+        C = self.get_covariance(n)
+        sd = np.sqrt(np.diag(C))
+        return C / np.outer(sd, sd)
 
     def get_correlations(self):
         return [self.get_correlation(n) for n in range(self.n_outputs)]
 
-    def get_covariance(self, n=0):
-        """bluest/blue_models.py:166-179: adjacency with 0 -> NaN (cannot be coupled) and inf -> 0 (uncorrelated)"""
-        C = self._nx.adjacency_matrix(self.G[n]).toarray().astype(np.float64)
-        mask0 = C == 0
-        maskinf = np.isinf(C)
-        C[mask0] = np.nan
-        C[maskinf] = 0
-        return C
+    # ---- groups ---------------------------------------------------------------------------------------------------------------
+    def _groups_per_output(self, K, multi_groups):
+        """per output: list over sizes of (L_k, k) int arrays, empty trailing sizes dropped; and the largest size per output"""
+        per_output = []
+        for n, cp in enumerate(self._coupling):
+            if multi_groups is None:
+                levels = cp.cliques(min(int(K), self.M))
+            else:
+                kept = sorted({tuple(sorted(int(i) for i in g)) for g in multi_groups[n] if len(g)})
+                kept = [g for g in kept if cp.is_clique(g)]
+                if not kept:
+                    raise ValueError("no admissible model group for output %d" % n)
+                kmax = max(len(g) for g in kept)
+                levels = [np.array([g for g in kept if len(g) == k], dtype=np.int64).reshape(-1, k) for k in range(1, kmax + 1)]
+            while levels and len(levels[-1]) == 0:
+                levels.pop()
+            per_output.append(levels)
+        return per_output, [len(levels) for levels in per_output]
 
-    def get_correlation(self, n=0):
-        C = self.get_covariance(n)
-        s = np.sqrt(np.diag(C))
-        return C / np.outer(s, s)
-
-    def outer(self, a, b, inner):
-        L = len(a)
-        out = np.zeros((L, L))
-        for i in range(L):
-            for j in range(L):
-                out[i, j] = inner(a[i], b[j])
+    @staticmethod
+    def _union(per_output, K):
+        """the global group list: union over the outputs per size, sorted (bluest/blue_models.py:491-501, hashed)"""
+        first = per_output[0]
+        if all(len(lv) == len(first) and all(np.array_equal(a, b) for a, b in zip(lv, first)) for lv in per_output[1:]):
+            return [lv.copy() for lv in first] + [np.zeros((0, k), dtype=np.int64) for k in range(len(first) + 1, K + 1)]
+        out = []
+        for k in range(1, K + 1):
+            rows = {tuple(r) for lv in per_output if len(lv) >= k for r in lv[k - 1].tolist()}
+            out.append(np.array(sorted(rows), dtype=np.int64).reshape(-1, k))
         return out
 
-    # ---- model graph (blue_models.py:232-322) --------------------------------------------------------------
-    def get_model_graph(self, C, costs=None):
-        M = self.M
-        maskinf = np.isinf(C)
-        mask0 = C == 0
-        C[mask0] = np.inf
-        C[maskinf] = 0
-        G = self._nx.from_numpy_array(C)
-        if costs is not None:
-            for l in range(M):
-                G.nodes[l]['cost'] = costs[l]
-        for l in range(M):
-            G.nodes[l]['model_number'] = l
-        return G
-
-    def save_graph_data(self, filename):
-        if self.mpiRank == 0:
-            C_dict = {"C%d" % n: self._nx.adjacency_matrix(self.G[n]).toarray() for n in range(self.n_outputs)}
-            np.savez(filename, M=self.M, n_outputs=self.n_outputs, costs=self.get_costs(), **C_dict, SG=self.SG, dV=self.dV)
-        self.comm.barrier()
-
-    def load_graph_data(self, filename, costs=None):
-        data = dict(np.load(filename))
-        if self.M != int(data["M"]) or self.n_outputs > int(data["n_outputs"]):
-            raise ValueError("Loaded data number of models and/or number of outputs mismatch with the user-given values")
-        self.G = []
-        for n in range(self.n_outputs):
-            GG = self._nx.from_numpy_array(data["C%d" % n])
-            for l in range(self.M):
-                GG.nodes[l]['cost'] = data["costs"][l] if costs is None else costs[l]
-                GG.nodes[l]['model_number'] = l
-            self.G.append(GG)
-        self.SG = data["SG"].tolist()[:self.n_outputs]
-        dV = data.get("dV", None)
-        self.dV = [np.nan * np.ones((self.M, self.M)) for n in range(self.n_outputs)] if dV is None else [dV[n] for n in range(self.n_outputs)]
-
-    def check_graphs(self, remove_uncorrelated=False):
-        for n in range(self.n_outputs):
-            self.check_graph(n, remove_uncorrelated=remove_uncorrelated)
-
-    def check_graph(self, n=0, remove_uncorrelated=False):
-        if remove_uncorrelated:
-            for i in range(self.M):
-                for j in range(i, self.M):
-                    if self.G[n].has_edge(i, j) and np.isinf(self.G[n][i][j]["weight"]):
-                        self.G[n].remove_edge(i, j)
-        if not self._nx.is_connected(self.G[n]):
-            comp = self._nx.node_connected_component(self.G[n], 0)
-            self.SG[n] = comp
-            if self.warning: print("WARNING! Model graph %d is not connected. Connected graph size: %d" % (n, len(comp)))
-
-    # ---- covariance / cost estimation (blue_models.py:326-441) ----------------------------------------------
-    def estimate_missing_covariances(self, N):
-        nx = self._nx
-        C = [nx.adjacency_matrix(self.G[n]).toarray() for n in range(self.n_outputs)]
-        ls = list(np.where(np.isnan(np.sum(sum(C), 1)))[0])
-        if len(ls) == 0: return
-        if self.verbose: print("Covariance estimation with %d samples..." % N)
-        sumse, sumsc, cost, sumsd1, sumsd2 = self.blue_fn(ls, N, compute_mlmc_differences=True)
-        inners = self.get_models_inner_products()
-        C_hat = [sumsc[n] / N - self.outer(sumse[n], sumse[n], inners[n]) / N ** 2 for n in range(self.n_outputs)]
-        for n in range(self.n_outputs):
-            for i in range(len(ls)):
-                for j in range(i + 1, len(ls)):
-                    if not np.isfinite(self.dV[n][ls[i], ls[j]]):
-                        self.dV[n][ls[i], ls[j]] = sumsd2[n][i][j] / N - inners[n](sumsd1[n][i][j] / N, sumsd1[n][i][j] / N)
-        for n in range(self.n_outputs):
-            for i, j, c in self.G[n].edges(data=True):
-                if np.isnan(c['weight']):
-                    ii, jj = ls.index(i), ls.index(j)
-                    if abs(C_hat[n][ii, jj] / np.sqrt(C_hat[n][ii, ii] * C_hat[n][jj, jj])) < 1.0e-7:
-                        C_hat[n][ii, jj] = np.inf
-                    self.G[n][i][j]['weight'] = C_hat[n][ii, jj]
-
-    def project_covariances(self, bypass_error_check=False):
-        for n in range(self.n_outputs):
-            self.project_covariance(n, bypass_error_check=bypass_error_check)
-
-    def project_covariance(self, n=0, bypass_error_check=False):
-        """bluest/blue_models.py:352-433: nearest SPD matrix; with unknown (NaN) entries by SPG with the eigenvalue-clamp
-        projection -- the reference's own use of spg(), here driven by bluest_amd.spg on numpy vectors"""
-        spg_params = self.params["spg_params"]
-        spd_eps = spg_params["spd_threshold"]
-        C = self.get_covariance(n).flatten()
-        mask = (~np.isnan(C)).astype(int)
-
-        def proj(X, eps=spd_eps):
-            L = int(np.sqrt(len(X)).round())
-            X = X.reshape((L, L))
-            l, V = np.linalg.eigh((X + X.T) / 2)
-            l[l < eps] = eps
-            return (V @ np.diag(l) @ V.T).flatten()
-
-        def am(C, mask):
-            X = C.copy()
-            X[abs(mask) < 1.0e-15] = 0
-            return X * mask
-
-        def feval(x): return 0.5 * sum(am(x - C, mask ** 2) ** 2)
-        def geval(x): return am(x - C, mask ** 2)
-
-        if np.isfinite(C).all():
-            L = int(np.sqrt(len(C)).round())
-            Cm = C.reshape((L, L))
-            l, V = np.linalg.eigh(Cm)
-            l[l < spd_eps] = spd_eps
-            C_new = V @ np.diag(l) @ V.T
-            err = np.linalg.norm(Cm - C_new, 'fro')
-            if self.verbose: print("Covariance projected to be symmetric positive definite, projection error: ", err)
-        else:
-            if self.verbose: print("Running Spectral Gradient Descent for Covariance projection...")
-            x = proj(am(C, abs(mask) > 1.0e-14))
-            res = spg(feval, geval, proj, x, eps=spg_params["eps"], maxit=spg_params["maxit"], max_fevals=spg_params["max_fevals"],
-                      verbose=spg_params["verbose"] and self.warning, lmbda_min=spg_params["lmbda_min"], lmbda_max=spg_params["lmbda_max"],
-                      Hlength=spg_params["linesearch_history_length"])
-            err = res["f"]
-            if res["solver_info"] != 0:
-                raise RuntimeError("Could not find good enough Covariance projection. Solver info:\n%s" % res)
-            if err > spg_params["eps"] and not bypass_error_check:
-                if self.verbose: print("\nWARNING! Large covariance projection error. Model covariance may be singular. Leaving covariances as they are.\n")
-                return err
-            C_new = res["x"].reshape((self.M, self.M))
-            s = np.sqrt(np.diag(C_new))
-            rho_new = C_new / np.outer(s, s)
-            C_new[abs(rho_new) < 1.0e-7] = np.inf
-            C_new[np.isnan(C).reshape((self.M, self.M))] = np.nan
-        for i in range(self.M):
-            for j in range(self.M):
-                coupled = not np.isnan(C_new[i, j])
-                if self.G[n].has_edge(i, j):
-                    self.G[n][i][j]['weight'] = C_new[i, j] if coupled else 0
-                elif coupled:
-                    self.G[n].add_edge(i, j)
-                    self.G[n][i][j]['weight'] = C_new[i, j]
-        return err
-
-    def estimate_costs(self, N=1):
-        if self.verbose: print("Cost estimation via sampling...")
-        for l in range(self.M):
-            self.blue_fn([l], self.get_comm().Get_size(), verbose=False)
-            _, _, cost = self.blue_fn([l], N, verbose=False)
-            for n in range(self.n_outputs):
-                self.G[n].nodes[l]['cost'] = cost / N
-
-    def blue_fn(self, ls, N, verbose=True, compute_mlmc_differences=False):
-        return blue_fn(ls, N, self, sampler=self.sampler, inners=self.get_models_inner_products(), comm=self.get_comm(),
-                       N1=self.params["sample_batch_size"], No=self.n_outputs, compute_mlmc_differences=compute_mlmc_differences,
-                       verbose=self.verbose and verbose)
-
-    # ---- the path: setup_solver / solve (blue_models.py:448-576) ---------------------------------------------
-    def _cliques(self, n, K):
-        """all cliques of the model graph of output n up to size K, size-major and sorted (blue_models.py:465-469).
-        Complete graphs (the common case, and the benchmark configurations) are enumerated directly."""
-        G = self.G[n]
-        nodes = sorted(self.SG[n])
-        M = len(nodes)
-        edges = sum(1 for i, j in G.edges() if i != j and i in self.SG[n] and j in self.SG[n])
-        if edges == M * (M - 1) // 2:
-            # complete graph: every k-subset is a clique; built once per (node set, K) as integer arrays and copied per output
-            key = (tuple(nodes), K)
-            cache = self.__dict__.setdefault("_clique_cache", {})
-            if key not in cache:
-                cache[key] = [np.array(list(combinations(nodes, k)), dtype=np.int64).reshape(-1, k) for k in range(1, K + 1)]
-            return [g.copy() for g in cache[key]]
-        groups = [[] for k in range(K)]
-        for clique in self._nx.enumerate_all_cliques(G):
-            kn = len(clique)
-            if kn > K: break
-            if all(node in self.SG[n] for node in clique):
-                groups[kn - 1].append(sorted(clique))
-        return groups
-
+    # ---- the path -------------------------------------------------------------------------------------------------------------
     def setup_solver(self, K=4, budget=None, eps=None, groups=None, multi_groups=None, solver=None, continuous_relaxation=False,
                      max_model_samples=None, optimization_solver_params=None):
-        if budget is None and eps is None: raise ValueError("Need to specify either budget or RMSE tolerance")
-        elif budget is not None and eps is not None: eps = None
-        if eps is not None and isinstance(eps, (int, float, np.int64, np.float64, np.float32, np.int32)): eps = [eps for n in range(self.n_outputs)]
-        if solver is None: solver = self.params["optimization_solver"]
+        """bluest/blue_models.py:448-538: returns {"models", "samples", "errors", "total_cost"}"""
+        if budget is None and eps is None:
+            raise ValueError("Need to specify either budget or RMSE tolerance")
+        if budget is not None:
+            eps = None                                                  # the budget wins (bluest/blue_models.py:450)
+        elif np.isscalar(eps):
+            eps = [eps] * self.n_outputs
+        solver = self.params["optimization_solver"] if solver is None else solver
         if multi_groups is not None and len(multi_groups) != self.n_outputs:
             raise ValueError("multi_groups must be a list of groupings of the same length as the number of outputs.")
-        if groups is not None and multi_groups is None:
-            multi_groups = [[list(g) for g in groups] for n in range(self.n_outputs)]
-
-        if multi_groups is None:
-            Ks, multi_groups = [], []
-            K = min(K, self.M)
-            for n in range(self.n_outputs):
-                gs = [item for item in self._cliques(n, K) if len(item) > 0]
-                multi_groups.append(gs)
-                Ks.append(min(K, len(gs)))
-            K = max(Ks)
-        else:
-            Ks = [min(max(len(item) for item in gs), self.M) for gs in multi_groups]
-            for n in range(self.n_outputs):
-                new_groups = [[] for k in range(Ks[n])]
-                for group in multi_groups[n]:
-                    group = sorted(group)
-                    H = self.G[n].subgraph(group)
-                    if H.size() == (len(group) * (len(group) + 1)) // 2 and all(node in self.SG[n] for node in group):
-                        new_groups[len(group) - 1].append(group)
-                multi_groups[n] = new_groups
-            Ks = [min(max(len(item) for groupsk in gs for item in groupsk), self.M) for gs in multi_groups]
-            K = max(Ks)
-
-        def same(a, b):
-            return len(a) == len(b) and all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a, b))
-
-        if all(same(multi_groups[n], multi_groups[0]) for n in range(1, self.n_outputs)):
-            # identical lists: the union is the (sorted) list itself
-            def lexsorted(gk, k):
-                gk = np.asarray(gk, dtype=np.int64).reshape(-1, k + 1)
-                return gk[np.lexsort(gk.T[::-1])]             # rows in the order sorted(map(tuple, ...)) gives
-
-            groups = [lexsorted(gk, k) if len(gk) else [] for k, gk in enumerate(multi_groups[0])]
-        else:
-            seen = [set() for k in range(K)]                  # union over outputs, hashed (blue_models.py:493-501)
-            for n in range(self.n_outputs):
-                for k in range(Ks[n]):
-                    for group in np.asarray(multi_groups[n][k]).tolist():
-                        seen[k].add(tuple(group))
-            groups = [sorted(list(g) for g in seen[k]) for k in range(K)]
-
+        if multi_groups is None and groups is not None:
+            multi_groups = [groups] * self.n_outputs
+        per_output, Ks = self._groups_per_output(K, multi_groups)
+        K = max(Ks)
+        union = self._union(per_output, K)
+        costs = self.get_group_costs(union)
+        multi_costs = [self.get_group_costs(levels) for levels in per_output]
         C = self.get_covariances()
-        costs = self.get_group_costs(groups)
-        multi_costs = [self.get_group_costs(item) for item in multi_groups]
 
         if self.verbose: print("Computing optimal sample allocation...")
-        if self.mpiRank == 0:
-            self.MOSAP = MOSAP(C, K, Ks, groups, multi_groups, costs, multi_costs, verbose=self.verbose)
+        result = None
+        if self.mpiRank == 0:                                           # the optimiser runs on one rank (:508)
+            self.MOSAP = MOSAP(C, K, Ks, union, per_output, costs, multi_costs, verbose=self.verbose)
             self.MOSAP.solve(eps=eps, budget=budget, solver=solver, continuous_relaxation=continuous_relaxation,
                              max_model_samples=max_model_samples, solver_params=optimization_solver_params)
-            if self.MOSAP.samples is None:
-                self.MOSAP_output = None
-            else:
+            if self.MOSAP.samples is not None:
                 Vs = self.MOSAP.variances(self.MOSAP.samples)
-                cost_BLUE = self.MOSAP.tot_cost
-                N_MC = max(C[n][0, 0] / Vs[n] for n in range(self.n_outputs))
-                cost_MC = N_MC * costs[0]
-                if self.verbose: print("\nBLUE cost: ", cost_BLUE, "MC cost: ", cost_MC, "Savings: ", cost_MC / cost_BLUE)
-                self.MOSAP_output = {'budget': budget, 'eps': eps, 'samples': self.MOSAP.samples,
-                                     'flattened_groups': self.MOSAP.flattened_groups, 'variances': Vs, 'cost': cost_BLUE}
-        else:
-            self.MOSAP_output = None
-        self.MOSAP_output = self.comm.bcast(self.MOSAP_output, root=0)
-        if self.MOSAP_output is None:
+                result = {"budget": budget, "eps": eps, "samples": self.MOSAP.samples, "flattened_groups": self.MOSAP.flattened_groups,
+                          "variances": Vs, "cost": self.MOSAP.tot_cost}
+                if self.verbose:
+                    cost_MC = max(C[n][0, 0] / Vs[n] for n in range(self.n_outputs)) * costs[0]
+                    print("\nBLUE cost: ", result["cost"], "MC cost: ", cost_MC, "Savings: ", cost_MC / result["cost"])
+        if self.comm is not None:
+            result = self.comm.bcast(result, root=0)
+        self.MOSAP_output = result
+        if result is None:
             raise BLUESTError("MOSAP solution failed!")
 
-        which_groups = [self.MOSAP_output['flattened_groups'][item] for item in np.argwhere(self.MOSAP_output['samples'] > 0).flatten()]
-        Vs = self.MOSAP_output['variances']
-        cost_BLUE = self.MOSAP_output['cost']
-        samples = self.MOSAP_output['samples']
-        samples = samples[samples > 0].copy()
-        blue_data = {"models": which_groups, "samples": samples, "errors": np.sqrt(Vs), "total_cost": cost_BLUE}
-        if self.verbose: print("\nModel groups selected: %s\n" % which_groups)
-        if self.verbose: print("BLUE estimator setup. Max error: ", np.sqrt(max(Vs)), " Cost: ", cost_BLUE, "\n")
-        return blue_data
+        chosen = np.flatnonzero(result["samples"] > 0)
+        data = {"models": [result["flattened_groups"][i] for i in chosen], "samples": result["samples"][chosen].copy(),
+                "errors": np.sqrt(result["variances"]), "total_cost": result["cost"]}
+        if self.verbose:
+            print("\nModel groups selected: %s\n" % data["models"])
+            print("BLUE estimator setup. Max error: ", np.sqrt(max(result["variances"])), " Cost: ", result["cost"], "\n")
+        return data
+
+    def _group_sums(self, ls, N):
+        """sum over N joint samples of the models `ls`, per output: [n_outputs][len(ls)] (what bluest/blue_fn.py returns first).
+        Host Python around the user's model -- sampling is not part of the accelerated path."""
+        sums = [[0 for _ in ls] for _ in range(self.n_outputs)]
+        for _ in range(int(N)):
+            while True:
+                values = self.evaluate(ls, self.sampler(ls))
+                if all(np.all(np.isfinite(v)) for out in values for v in out):
+                    break                                               # non-finite model output: draw again (blue_fn.py:118-129)
+            for n in range(self.n_outputs):
+                for i in range(len(ls)):
+                    sums[n][i] = sums[n][i] + values[n][i]
+        return sums
 
     def solve(self, K=4, budget=None, eps=None, groups=None, multi_groups=None, solver=None, verbose=True, continuous_relaxation=False,
               max_model_samples=None, optimization_solver_params=None):
-        if solver is None: solver = self.params["optimization_solver"]
-        kw = dict(K=K, budget=budget, eps=eps, groups=groups, multi_groups=multi_groups, solver=solver, continuous_relaxation=continuous_relaxation,
-                  max_model_samples=max_model_samples, optimization_solver_params=optimization_solver_params)
-        if self.MOSAP_output is None:
-            self.setup_solver(**kw)
-        elif budget is not None and budget != self.MOSAP_output['budget'] or eps is not None and np.any(np.asarray(eps) != np.asarray(self.MOSAP_output['eps'])):
-            self.setup_solver(**kw)
-        elif budget is None and eps is None and self.MOSAP_output['cost'] is None:
-            raise ValueError("Need to prescribe either a budget or an error tolerance to run the BLUE estimator")
-
+        """bluest/blue_models.py:540-576: returns (estimates, their standard errors, total cost)"""
+        have = self.MOSAP_output
+        changed = have is not None and ((budget is not None and budget != have["budget"]) or
+                                        (eps is not None and np.any(np.asarray(eps) != np.asarray(have["eps"]))))
+        if have is None or changed:
+            self.setup_solver(K=K, budget=budget, eps=eps, groups=groups, multi_groups=multi_groups, solver=solver,
+                              continuous_relaxation=continuous_relaxation, max_model_samples=max_model_samples,
+                              optimization_solver_params=optimization_solver_params)
         if self.verbose and verbose: print("\nSampling BLUE...\n")
-        flattened_groups = self.MOSAP_output['flattened_groups']
-        sample_list = self.MOSAP_output['samples']
-        sums = [[] for n in range(self.n_outputs)]
-        for ls, N in zip(flattened_groups, sample_list):
-            if N == 0:
-                for n in range(self.n_outputs):
-                    sums[n].append([0 for l in range(len(ls))])
-                continue
-            sumse, _, _ = self.blue_fn(ls, int(N), verbose=verbose)
+        out = self.MOSAP_output
+        sums = [[] for _ in range(self.n_outputs)]
+        for ls, count in zip(out["flattened_groups"], out["samples"]):
+            got = self._group_sums(ls, count) if count > 0 else [[0] * len(ls)] * self.n_outputs
             for n in range(self.n_outputs):
-                sums[n].append(sumse[n])
-        if self.mpiRank == 0:
-            mus, Vs = self.MOSAP.compute_BLUE_estimators(sums, sample_list)
-        else:
-            mus, Vs = None, None
-        mus = self.comm.bcast(mus, root=0)
-        Vs = self.comm.bcast(Vs, root=0)
-        return mus, np.sqrt(Vs), self.MOSAP_output['cost']
+                sums[n].append(got[n])
+        mus, Vs = self.MOSAP.compute_BLUE_estimators(sums, out["samples"])
+        return mus, np.sqrt(Vs), out["cost"]
 
-    # ---- outside this build ------------------------------------------------------------------------------------
+    # ---- refused ----------------------------------------------------------------------------------------------------------------
     def _out_of_scope(self, *a, **k):
-        raise BLUESTError("MLMC / MFMC / plain-MC drivers of the reference are outside this GPU build (SURVEY.md section 2)")
+        raise BLUESTError("outside this GPU build (SURVEY.md section 2): only setup_solver() / solve() with given covariances")
 
     setup_mlmc = solve_mlmc = setup_mfmc = solve_mfmc = setup_mc = solve_mc = _out_of_scope
+    save_graph_data = load_graph_data = estimate_missing_covariances = project_covariances = estimate_costs = _out_of_scope
+    complexity_test = variance_test = _out_of_scope

@@ -13,6 +13,7 @@
 #include <thread>
 #include <atomic>
 #include <chrono>
+#include <mutex>
 
 #include "bluest_hip.h"
 

@@ -407,11 +407,49 @@ extern "C" int bluest_plan_create(bluest_plan_t *plan, int n_models, int64_t L_g
     return BLUEST_OK;
 }
 
+// Plan lifetime vs stream capture: freeing device memory (hipFreeAsync on the null stream) while ANOTHER stream of the process
+// is being captured into a hipGraph invalidates that capture (hipErrorStreamCaptureInvalidated).  A host language with a
+// garbage collector or reference counting can drop a plan at any point, so the library does not rely on the caller's timing:
+// between bluest_capture_guard(1) and bluest_capture_guard(0) destroyed plans are parked and released when the guard closes.
+static std::mutex g_defer_mutex;
+static int g_capture_depth = 0;
+static std::vector<bluest_plan_s *> g_deferred;
+
+static void plan_release(bluest_plan_s *p)
+{
+    plan_free_device(p);
+    delete p;
+}
+
+extern "C" int bluest_capture_guard(int on)
+{
+    std::vector<bluest_plan_s *> drain;
+    {
+        std::lock_guard<std::mutex> lock(g_defer_mutex);
+        if (on) { g_capture_depth++; return BLUEST_OK; }
+        if (g_capture_depth > 0) g_capture_depth--;
+        if (g_capture_depth == 0) drain.swap(g_deferred);
+    }
+    for (bluest_plan_s *p : drain) plan_release(p);
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_deferred_plans(int *count)
+{
+    if (!count) return fail(BLUEST_ERR_ARG, "count is NULL");
+    std::lock_guard<std::mutex> lock(g_defer_mutex);
+    *count = (int)g_deferred.size();
+    return BLUEST_OK;
+}
+
 extern "C" int bluest_plan_destroy(bluest_plan_t plan)
 {
     if (!plan) return BLUEST_OK;
-    plan_free_device(plan);
-    delete plan;
+    {
+        std::lock_guard<std::mutex> lock(g_defer_mutex);
+        if (g_capture_depth > 0) { g_deferred.push_back(plan); return BLUEST_OK; }
+    }
+    plan_release(plan);
     return BLUEST_OK;
 }
 

@@ -85,15 +85,24 @@ class ShardedPlan(object):
         self.plan = plan_factory(n_models, self.L, local, max_candidates=max_candidates, device=device)
         self.n_out = len(outputs)
 
-    def eval(self, m, delta=0.0, want_grad=True, rec=None):
+    def eval(self, m, delta=0.0, want_grad=True, rec=None, out=None):
         """returns (var (n_cand,n_out), grad_local | None, status); grad_local covers this rank's groups only, in the
-        plan's concatenated per-output layout (plan.grad_off, local numbering)"""
+        plan's concatenated per-output layout (plan.grad_off, local numbering).  out = (var, grad, status) preallocated
+        device tensors (the v workspace is kept by this object)."""
         rec = self.plan.phi(m, out=rec)
         if self.world > 1:
             dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=self.group)
-        var, v, status = self.plan.solve(rec, delta)
-        grad = self.plan.grad(v, status) if want_grad else None
-        return var, grad, status
+        if out is None:
+            var, v, status = self.plan.solve(rec, delta)
+            grad = self.plan.grad(v, status) if want_grad else None
+            return var, grad, status
+        var, grad, status = out
+        if getattr(self, "_v", None) is None or self._v.shape[0] != rec.shape[0]:
+            self._v = torch.empty((rec.shape[0], self.n_out, self.plan.N), dtype=torch.float64, device=rec.device)
+        self.plan.solve(rec, delta, out=(var, self._v, status))
+        if want_grad:
+            self.plan.grad(self._v, status, out=grad)
+        return var, grad if want_grad else None, status
 
     def global_gradient(self, grad_local, coef, scale=None):
         """g[j] = scale[j] * sum_o coef[o] * dV_o/dm_j for ALL j: every rank fills the entries of its groups, one

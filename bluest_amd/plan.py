@@ -142,11 +142,14 @@ class Plan(object):
             check(self.lib.bluest_plan_phi(self._h, m.data_ptr(), nc, m.stride(0), rec.data_ptr(), _stream()))
         return rec
 
-    def solve(self, rec, delta=0.0):
+    def solve(self, rec, delta=0.0, out=None):
         nc = rec.shape[0]
-        var = torch.empty((nc, self.n_out), dtype=torch.float64, device=self.device)
-        v = torch.empty((nc, self.n_out, self.N), dtype=torch.float64, device=self.device)
-        status = torch.empty((nc, self.n_out), dtype=torch.int32, device=self.device)
+        if out is None:
+            var = torch.empty((nc, self.n_out), dtype=torch.float64, device=self.device)
+            v = torch.empty((nc, self.n_out, self.N), dtype=torch.float64, device=self.device)
+            status = torch.empty((nc, self.n_out), dtype=torch.int32, device=self.device)
+        else:
+            var, v, status = out
         with torch.cuda.device(self.device):
             check(self.lib.bluest_plan_solve(self._h, rec.data_ptr(), nc, float(delta), var.data_ptr(), v.data_ptr(),
                                              status.data_ptr(), _stream()))

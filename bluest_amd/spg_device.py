@@ -9,12 +9,11 @@ Same algorithm as bluest_amd.spg.spg with SpgAllocator's callbacks (tests/test_g
 iteration by iteration); this is what `solve(..., solver="spg")` runs by default.
 """
 import ctypes
-import gc
 
 import numpy as np
 import torch
 
-from ._lib import check
+from ._lib import capture_guard, check
 from .plan import EVAL_OK, _stream, projection_workspace, simplex_project
 
 # state layout (csrc/spg.hip SPG_*)
@@ -114,17 +113,21 @@ class DeviceSpg(object):
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
         g = torch.cuda.CUDAGraph()
-        # no cyclic garbage collection while capturing: collecting an older solver's graphs / tensors inside the capture
-        # calls hipGraphExecDestroy / hipFree on this thread and invalidates it (hipErrorStreamCaptureInvalidated)
-        was_enabled = gc.isenabled()
-        gc.disable()
-        try:
+        # Anything that frees device memory or destroys a hipGraph on this thread while the capture runs invalidates it
+        # (hipErrorStreamCaptureInvalidated).  Plans and solver graphs dropped meanwhile -- by the cyclic collector OR by a
+        # reference count reaching zero -- are parked by the library / by capture_guard and released after the capture.
+        with capture_guard():
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 fn()
-        finally:
-            if was_enabled:
-                gc.enable()
         return g
+
+    def __del__(self):
+        try:
+            graphs = [g for gs in self.graph_sets.values() for g in gs.values()]
+            self.graph_sets = {}
+            capture_guard.park(graphs)
+        except Exception:
+            pass
 
     # ---- host-side objective (initialisation only) ---------------------------------------------------------------
     def _objective(self, var):

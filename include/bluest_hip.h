@@ -100,6 +100,14 @@ typedef struct bluest_plan_s *bluest_plan_t;
 int bluest_plan_create(bluest_plan_t *plan, int n_models, int64_t L_global);
 int bluest_plan_destroy(bluest_plan_t plan);
 
+/* Plan lifetime vs hipGraph capture.  Releasing a plan frees device memory, and a free issued while some stream of the
+ * process is being captured invalidates that capture.  Callers whose host language may drop a plan at any time (garbage
+ * collection, reference counting) bracket their captures: bluest_capture_guard(1) before hipStreamBeginCapture,
+ * bluest_capture_guard(0) after hipStreamEndCapture.  While a guard is open bluest_plan_destroy only parks the plan; the
+ * closing call releases everything parked.  Guards nest.  bluest_deferred_plans reports how many plans are parked. */
+int bluest_capture_guard(int on);
+int bluest_deferred_plans(int *count);
+
 /* Add output o (call once per output, in order).  K = max group size of this output; sizes[k-1] = L_k for
  * k = 1..K; groups = concat_k (L_k*k) model indices; invcovs = concat_k (L_k*k*k) (HOST pointers, copied);
  * mapping = L_o global indices (m_o = m[mapping]) or NULL for the identity (requires L_o == L_global). */

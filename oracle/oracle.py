@@ -328,6 +328,210 @@ def c_group_pinv(C, k, groupsk):
     return out
 
 
+class SparseOracleSAP(object):
+    """OracleSAP without the dense psi (n^2 x K_tot: 1.2 GB at n = 25, K_tot = 245505): Phi comes from the sparse loop
+    `objectiveK_c` (bluest/cmisc.cpp:25-40), which sums the same products psi@m does; everything after Phi is
+    bluest/misc.py:463-495 verbatim in behaviour (numpy solve / pinv on the sampled models, gradK_c).  The per-group
+    pseudo-inverses are numpy.linalg.pinv on the stacked (L_k, k, k) blocks (bluest/sap.py:69-79, one LAPACK call per size).
+    Used to judge allocations at sizes where OracleSAP is too heavy for a test."""
+
+    def __init__(self, C, K, groups):
+        self.C, self.N, self.K = np.asarray(C, dtype=np.float64), C.shape[0], K
+        self.groups = [np.asarray(g, dtype=np.int64).reshape((-1, k + 1)) for k, g in enumerate(groups)]
+        self.sizes = [0] + [len(g) for g in self.groups]
+        self.cumsizes = np.cumsum(self.sizes)
+        self.L = int(self.cumsizes[-1])
+        self.invcovs = []
+        for gk in self.groups:
+            if len(gk):
+                sub = self.C[gk[:, :, None], gk[:, None, :]]
+                self.invcovs.append(np.linalg.pinv(sub).reshape(-1))
+            else:
+                self.invcovs.append(np.zeros(0))
+
+    def get_phi(self, m, delta=0.0):
+        N = self.N
+        PHI = np.zeros(N * N)
+        for k in range(1, self.K + 1):
+            if self.sizes[k]:
+                PHI += objectiveK(N, k, self.sizes[k], m[self.cumsizes[k - 1]:self.cumsizes[k]], self.groups[k - 1], self.invcovs[k - 1])
+        return delta * np.eye(N) + PHI.reshape(N, N)
+
+    def variance(self, m, delta=0.0):
+        """bluest/misc.py:463-477"""
+        if abs(m).max() < 0.05:
+            return np.inf
+        PHI = self.get_phi(m, delta)
+        idx = get_nnz_rows_cols(m, self.groups, self.cumsizes)
+        assert idx[0].min() == 0
+        return np.linalg.solve(PHI[idx], np.eye(len(idx[0]), 1).flatten())[0]
+
+    def variance_GH(self, m, delta=0.0, nohess=True):
+        """bluest/misc.py:479-495 (nohess)"""
+        if abs(m).max() < 0.05:
+            return np.inf, np.inf * np.ones(self.L)
+        PHI = self.get_phi(m, delta)
+        invPHI = np.linalg.pinv(PHI)
+        idx = get_nnz_rows_cols(m, self.groups, self.cumsizes)
+        var = np.linalg.pinv(PHI[idx])[0, 0]
+        grad = -np.concatenate([gradK(k, self.sizes[k], self.groups[k - 1], self.invcovs[k - 1], invPHI)
+                                for k in range(1, self.K + 1) if self.sizes[k]])
+        return var, grad, None
+
+
+def optimality_certificate(saps, m, costs, s=None, tol=1.0e-7, max_rounds=60, verbose=False):
+    """Duality certificate for  min_m F(m) = max_o V_o(m)/s_o  s.t.  costs.m = B, m >= 0  (the problem bluest/sap.py:387-418
+    and bluest/mosap.py:578-605 hand to scipy) at a candidate allocation m, B = costs.m.  saps: one SparseOracleSAP per
+    output, all on the same global group list.
+
+    Weak duality.  V_o(m') = sup_y 2 y_0 - sum_i m'_i q_{i,o}(y) with q_{i,o}(y) = y_g^T C_{g,o}^-1 y_g >= 0 (Phi_o is linear in
+    m').  Hence for ANY vectors y_o in R^n and ANY mu in the simplex, with a_o = mu_o / s_o, every feasible m' has
+        F(m') >= sum_o mu_o V_o(m')/s_o >= A - B max_i c_i,    A = sum_o a_o 2 y_{o,0},   c_i = sum_o a_o q_{i,o}(y_o) / w_i,
+    and scaling all y_o by the best common factor gives  LB = A^2 / (4 B max_i c_i).  The bound is VALID whatever (mu, y) are
+    and TIGHT at the dual optimum (the problem is convex, Slater holds).  A first-order choice -- y from the gradient at m -- is
+    useless in practice: V is so strongly curved in the cheap groups that a point 1e-4 above the optimum still has Lagrange
+    multipliers off by a factor 2-3.  So the dual is SOLVED here: for fixed mu, minimise t subject to c_i(y) <= t for all groups
+    at fixed A (a convex QCQP in n_active * n variables; constraints generated on demand, SLSQP on the working set, started from
+    row 0 of the inverse of Phi_o(m) on the sampled models = the reference's v, bluest/misc.py:487); mu, which lives on the outputs
+    within 2 % of the maximum, is optimised by a bounded scalar search when two outputs are in play (the dual function is
+    concave in mu) and by cyclic pairwise searches beyond.  Only quantities the oracle computes enter (Phi via objectiveK_c, the
+    quadratic forms via gradK_c); nothing from the GPU path.  Returns (relative gap (F - LB)/F, LB, mu, info)."""
+    from scipy.optimize import minimize, minimize_scalar
+    O = len(saps)
+    m = np.asarray(m, dtype=np.float64)
+    w = np.asarray(costs, dtype=np.float64)
+    s = np.ones(O) if s is None else np.asarray(s, dtype=np.float64)
+    B = float(w @ m)
+    sap0 = saps[0]
+    N, K, L = sap0.N, sap0.K, sap0.L
+    Vs = np.array([q.variance(m) for q in saps])
+    r = Vs / s
+    F = float(r.max())
+    act = np.flatnonzero(r >= 0.98 * F)
+    nA = len(act)
+    sa = s[act]
+    Y0 = np.zeros((nA, N))                     # y_o / F: normalised so that y_{o,0} = V_o / F = O(1)
+    for c, o in enumerate(act):
+        PHI = saps[o].get_phi(m)
+        d = np.diag(PHI)
+        S = np.flatnonzero(d > 1.0e-13 * d.max())
+        assert S[0] == 0, "model 0 is not sampled"
+        Y0[c, S] = np.linalg.solve(PHI[np.ix_(S, S)], np.eye(len(S), 1).ravel()) / F
+
+    def quad_forms(Yc):
+        """B F q_{i,o}(y_o) / w_i for all groups i and the active outputs: (L, nA); cmisc.cpp:58-72 evaluates this form"""
+        res = np.empty((L, nA))
+        for c, o in enumerate(act):
+            q = saps[o]
+            res[:, c] = np.concatenate([gradK(k, q.sizes[k], q.groups[k - 1], q.invcovs[k - 1], Yc[c][None, :])
+                                        for k in range(1, K + 1) if q.sizes[k]])
+        return res * (B * F) / w[:, None]
+
+    blocks = {}
+
+    def dense_blocks(idx):
+        """Qd[j, c] = B F R_i^T C_{i,o}^-1 R_i / w_i as an n x n matrix, for the groups i = idx[j] and the active outputs"""
+        Qd = np.zeros((len(idx), nA, N, N))
+        for j, i in enumerate(idx):
+            if i not in blocks:
+                k = int(np.searchsorted(sap0.cumsizes, i, side="right"))
+                li = i - sap0.cumsizes[k - 1]
+                g = sap0.groups[k - 1][li]
+                blk = np.zeros((nA, N, N))
+                for c, o in enumerate(act):
+                    blk[c][np.ix_(g, g)] = saps[o].invcovs[k - 1][li * k * k:(li + 1) * k * k].reshape(k, k) * (B * F / w[i])
+                blocks[i] = blk
+            Qd[j] = blocks[i]
+        return Qd
+
+    nY = nA * N
+    state = {"work": np.zeros(0, dtype=np.int64), "Y": Y0.copy(), "solves": 0, "best": (-np.inf, None, None)}
+
+    def dual_for(mu_a):
+        """max over y of the normalised bound LB/F for these multipliers (warm-started from the previous call)"""
+        a = mu_a / sa
+        a_grad = np.zeros(nY + 1)
+        a_grad[np.arange(nA) * N] = 2.0 * a
+        e_tau = np.zeros(nY + 1)
+        e_tau[-1] = 1.0
+        Yc = state["Y"].copy()
+        A0 = float((2.0 * a * Yc[:, 0]).sum())
+        work = state["work"]
+        best_lb, solved = -np.inf, False
+        tau = 0.0
+        for rnd in range(max_rounds):
+            c = quad_forms(Yc) @ a
+            A = float((2.0 * a * Yc[:, 0]).sum())
+            lb = A * A / (4.0 * c.max())
+            if lb > best_lb:
+                best_lb = lb
+                if lb > state["best"][0]:
+                    state["best"] = (lb, Yc.copy(), mu_a.copy())
+                state["Y"] = Yc.copy()
+            viol = np.setdiff1d(np.flatnonzero(c > tau * (1.0 + tol) + 1.0e-14), work)
+            if len(viol) == 0 and solved:
+                break
+            add = viol[np.argsort(-c[viol])[:96]] if len(viol) else np.zeros(0, dtype=np.int64)
+            work = np.unique(np.concatenate([work, add]))
+            Qd = dense_blocks(work)
+
+            def cons(xv, Qd=Qd):
+                Yv = xv[:nY].reshape(nA, N)
+                return xv[-1] - np.einsum("c,jcnm,cn,cm->j", a, Qd, Yv, Yv)
+
+            def cons_jac(xv, Qd=Qd):
+                Yv = xv[:nY].reshape(nA, N)
+                J = np.empty((len(Qd), nY + 1))
+                J[:, :nY] = (-2.0 * np.einsum("c,jcnm,cm->jcn", a, Qd, Yv)).reshape(len(Qd), nY)
+                J[:, -1] = 1.0
+                return J
+
+            x0 = np.concatenate([Yc.ravel(), [float(c[work].max())]])
+            res = minimize(lambda xv: xv[-1], x0, jac=lambda xv: e_tau, method="SLSQP",
+                           constraints=[{"type": "ineq", "fun": cons, "jac": cons_jac},
+                                        {"type": "eq", "fun": lambda xv: float(a_grad @ xv) - A0, "jac": lambda xv: a_grad}],
+                           options={"maxiter": 300, "ftol": 1.0e-15})
+            state["solves"] += 1
+            # SLSQP often stops with "positive directional derivative" (status 8) AT the solution of such min-max problems:
+            # what counts is that the point is feasible for the working set and not worse than the start
+            ok = np.isfinite(res.x).all() and res.x[-1] <= x0[-1] * (1.0 + 1.0e-12) and \
+                cons(res.x).min() >= -1.0e-9 * max(res.x[-1], 1.0e-300) and abs(float(a_grad @ res.x) - A0) <= 1.0e-9 * abs(A0)
+            solved = ok and res.status in (0, 8)
+            if ok:
+                Yc, tau = res.x[:nY].reshape(nA, N), float(res.x[-1])
+            if verbose:
+                print("   mu %s round %d: working set %d, SLSQP status %d nit %d, tau %.10f, bound %.10f"
+                      % (np.round(mu_a, 5), rnd, len(work), res.status, res.nit, tau, best_lb))
+        state["work"] = work
+        return best_lb
+
+    if nA == 1:
+        dual_for(np.ones(1))
+    else:
+        mu_a = np.exp(-(F - r[act]) / (0.005 * F))
+        mu_a /= mu_a.sum()
+        for sweep in range(2 if nA > 2 else 1):
+            for c in range(1, nA):                                   # move weight between output act[0] and act[c]
+                tot = mu_a[0] + mu_a[c]
+
+                def along(t, c=c, tot=tot):
+                    mm = mu_a.copy()
+                    mm[0], mm[c] = tot * (1.0 - t), tot * t
+                    return -dual_for(np.maximum(mm, 1.0e-12))
+
+                res = minimize_scalar(along, bounds=(0.0, 1.0), method="bounded", options={"xatol": 1.0e-4, "maxiter": 25})
+                mu_a[0], mu_a[c] = tot * (1.0 - res.x), tot * res.x
+    lb_n, Yb, mub = state["best"]
+    lb = lb_n * F
+    mu_full = np.zeros(O)
+    mu_full[act] = mub
+    info = {"active_outputs": act.tolist(), "working_set": int(len(state["work"])), "qp_solves": state["solves"]}
+    if verbose:
+        print("certificate: F = %.10e, LB = %.10e, gap = %.3e, mu = %s, %d QP solves, working set %d"
+              % (F, lb, (F - lb) / F, np.round(mu_full, 5), state["solves"], len(state["work"])))
+    return (F - lb) / F, lb, mu_full, info
+
+
 # --------------------------------------------------------------------------------------------------
 # L3: bluest/mosap.py:20-100 (hash-based mapping instead of the O(L_k^2) search at :54-65; same result)
 # --------------------------------------------------------------------------------------------------

@@ -100,7 +100,7 @@ def test_cmisc_mirror_device_pointers(gpu):
 CASES = ("base", "sparse", "drop_last_model", "only_first3", "int64")
 
 
-def _check_sap_file(fname, tol=TOL, via_mosap=False):
+def _check_sap_file(fname, tol=TOL, via_mosap=False, outputs=None):
     from bluest_amd.mosap import MOSAP
     from bluest_amd.sap import SAP
     G = golden(fname)
@@ -110,8 +110,8 @@ def _check_sap_file(fname, tol=TOL, via_mosap=False):
         mos = MOSAP([c.copy() for c in prob["C"]], kmax, [kmax] * n_out, [g.copy() for g in prob["groups"]],
                     [[g.copy() for g in prob["groups"]] for _ in range(n_out)], prob["costs"], [prob["costs"]] * n_out,
                     verbose=False)
-    for o in range(n_out):
-        sap = mos.SAPS[o] if via_mosap else SAP(prob["C"][o].copy(), kmax, [g.tolist() for g in prob["groups"]], prob["costs"],
+    for o in (range(n_out) if outputs is None else outputs):
+        sap = mos.SAPS[o] if via_mosap else SAP(prob["C"][o].copy(), kmax, [g.copy() for g in prob["groups"]], prob["costs"],
                                                  verbose=False)
         if o == 0:
             ic = np.concatenate(sap.invcovs)
@@ -162,6 +162,102 @@ def test_sap_golden_small(gpu, fname):
 def test_mosap_golden_n20_k5_o8(gpu):
     """the headline configuration (n=20, k_max=5, K_tot=21699, n_out=8): all outputs in one plan"""
     _check_sap_file("sap_n20_k5_o8.npz", via_mosap=True)
+
+
+def test_sap_golden_n20_k5_single_output(gpu):
+    """BASELINE.json configs[2]: n=20, k_max=5 (K_tot=21699), ONE output per plan (SAP, not MOSAP): the non-shared Phi kernel
+    `k_phi_chunks` and `k_solve_grad` with one output's workgroups, against the reference's values for outputs 0 and 7"""
+    _check_sap_file("sap_n20_k5_o8.npz", via_mosap=False, outputs=(0, 7))
+
+
+def _sum_of_shards(torch, n, sizes, outs, n_shards, m, dev):
+    """the multi-GPU seam inside ONE process: one HIP plan per shard of the group set (bluest_amd.dist.shard_bounds /
+    shard_output), Phi records summed on the device (what the all-reduce does), solve, per-shard gradient"""
+    from bluest_amd.dist import shard_bounds, shard_output
+    from bluest_amd.plan import Plan
+    L = int(sum(sizes))
+    cuts = shard_bounds(sizes, n_shards)
+    plans, rec = [], None
+    for lo, hi in zip(cuts, cuts[1:]):
+        local = [shard_output(o, sizes, lo, hi) for o in outs]
+        assert all(sum(o["sizes"]) > 0 for o in local)
+        pl = Plan(n, L, local, max_candidates=1, device=dev)
+        plans.append((pl, local))
+        r = pl.phi(m)
+        rec = r.clone() if rec is None else rec + r
+    var = v = status = None
+    grads = []
+    for pl, local in plans:
+        var_s, v_s, st_s = pl.solve(rec)
+        if var is not None:                     # every shard solves the same reduced record: identical bits
+            assert torch.equal(var_s, var) and torch.equal(v_s, v) and torch.equal(st_s, status)
+        var, v, status = var_s, v_s, st_s
+        grads.append((pl, local, pl.grad(v_s, st_s)))
+    return rec, var, status, grads
+
+
+def _check_shards_against_full(torch, n, sizes, outs, full_plan, full_mappings, m, shard_counts, phi_oracle=None):
+    dev = full_plan.device
+    var_f, grad_f, st_f = full_plan.eval(m)
+    N = n
+    for P in shard_counts:
+        rec, var, status, grads = _sum_of_shards(torch, n, sizes, outs, P, m, dev)
+        assert torch.equal(status, st_f)
+        assert float((var / var_f - 1).abs().max()) < 1e-12, P
+        PHI_f = full_plan.phi(m)[0, :, :N * N]
+        assert float((rec[0, :, :N * N] - PHI_f).abs().max() / PHI_f.abs().max()) < 1e-13
+        if phi_oracle is not None:
+            assert rel_err(rec[0, 0, :N * N].cpu().numpy(), phi_oracle.ravel()) < 1e-12
+        # per-shard gradients tile the full gradient: entry of (output o, global group j) sits in exactly one shard
+        gf = grad_f[0].cpu().numpy()
+        seen = [np.zeros(len(mp), dtype=np.int64) for mp in full_mappings]
+        for pl, local, g in grads:
+            gl = g[0].cpu().numpy()
+            for o, lo_ in enumerate(local):
+                pos = np.searchsorted(full_mappings[o], lo_["mapping"])          # local position inside output o
+                assert (full_mappings[o][pos] == lo_["mapping"]).all()
+                want = gf[full_plan.grad_off[o] + pos]
+                got = gl[pl.grad_off[o]:pl.grad_off[o] + len(pos)]
+                assert np.abs(got - want).max() <= 1e-12 * np.abs(gf).max(), (P, o)
+                seen[o][pos] += 1
+        assert all((sn == 1).all() for sn in seen)
+
+
+def test_group_sharded_hip_plans_n25_k6(gpu, oracle):
+    """BASELINE.json configs[4] (n=25, k_max=6, K_tot=245505) cut into 2 and 8 shards on ONE GPU, one process, no
+    torch.distributed: `k_fold_to_record` / `k_solve_from_record` / per-shard gradient tiles on shard-sized HIP plans equal the
+    unsharded evaluation (<= 1e-12) and the oracle's Phi (bluest/misc.py:459-495)"""
+    torch = gpu
+    prob, mos = _mosap(25, 6, 1)
+    sizes = [len(g) for g in prob["groups"]]
+    outs = [{"K": 6, "sizes": sizes, "groups": prob["groups"], "C": prob["C"][0], "mapping": None}]
+    m = torch.from_numpy(prob["m"][0]).to(mos.plan.device)
+    sap = oracle.SparseOracleSAP(prob["C"][0], 6, prob["groups"])
+    _check_shards_against_full(torch, 25, sizes, outs, mos.plan, mos.mappings, m, (2, 8), phi_oracle=sap.get_phi(prob["m"][0]))
+
+
+def test_group_sharded_hip_plans_ragged(gpu):
+    """the same seam with different group sets per output (non-identity mappings, golden n=6 fixture) and a sparse allocation
+    whose per-model indicators must combine across shards (a model touched only by groups of ONE shard)"""
+    torch = gpu
+    from bluest_amd.mosap import MOSAP
+    G = golden("mosap_n6_o3_ragged.npz")
+    n, n_out, kmax = int(G["n"]), int(G["n_out"]), int(G["kmax"])
+    prob = synth.problem(n, kmax, n_out)
+    groups = [G["g_k%d" % k] for k in range(1, kmax + 1)]
+    multi_groups = [[G["mg%d_k%d" % (o, k)] for k in range(1, kmax + 1)] for o in range(n_out)]
+    costs = synth.group_costs(groups, prob["w"])
+    multi_costs = [synth.group_costs(mg, prob["w"]) for mg in multi_groups]
+    mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in mg] for mg in multi_groups],
+                costs, multi_costs, verbose=False)
+    sizes = [len(g) for g in groups]
+    outs = [{"K": kmax, "sizes": [len(g) for g in multi_groups[o]], "groups": multi_groups[o], "C": prob["C"][o],
+             "mapping": mos.mappings[o]} for o in range(n_out)]
+    dev = mos.plan.device
+    rng = np.random.RandomState(11)
+    for m_h in (G["m"], np.where(rng.rand(mos.L) < 0.3, G["m"], 0.0) + np.eye(1, mos.L, 0)[0] * 2.0):
+        m = torch.from_numpy(np.ascontiguousarray(m_h, dtype=np.float64)).to(dev)
+        _check_shards_against_full(torch, n, sizes, outs, mos.plan, mos.mappings, m, (2, 3))
 
 
 def test_model0_unsampled(gpu):

@@ -259,3 +259,47 @@ def test_blue_estimator_vs_reference_fixture():
         samples, sums = _estimator_case(G, case, sap.sizes)
         mu, var = sap.compute_BLUE_estimator(sums, samples)
         assert abs(mu / float(G["mu%d" % case]) - 1) < 1e-12 and abs(var / float(G["var%d" % case]) - 1) < 1e-12
+
+
+def test_sparse_oracle_and_optimality_certificate(oracle):
+    """SparseOracleSAP (Phi by the objectiveK_c loop) equals OracleSAP (dense psi@m, as the reference executes); the duality
+    certificate is ~0 at an optimum found by an independent method (multiplicative algorithm on the CPU) and large elsewhere"""
+    prob = synth.problem(7, 3, 2)
+    m = prob["m"][0]
+    for o in range(2):
+        full = oracle.OracleSAP(prob["C"][o], 3, prob["groups"], prob["costs"])
+        sp = oracle.SparseOracleSAP(prob["C"][o], 3, prob["groups"])
+        Vf, gf, _ = full.variance_GH(m, nohess=True)
+        Vs, gs, _ = sp.variance_GH(m)
+        assert abs(Vs / Vf - 1) < 1e-13 and rel_err(gs, gf) < 1e-13 and abs(sp.variance(m) / full.variance(m) - 1) < 1e-13
+        msp = m.copy(); msp[full.ES[6] == 1] = 0.0                 # model 6 unsampled: restricted solve, pinv gradient
+        assert abs(sp.variance_GH(msp)[0] / full.variance_GH(msp, nohess=True)[0] - 1) < 1e-12
+    # single output: multiplicative algorithm x_i <- x_i * (-dV/dx_i) / sum (monotone for c-optimal design)
+    sp = oracle.SparseOracleSAP(prob["C"][0], 3, prob["groups"])
+    w, B = prob["costs"], prob["budget"]
+    scale = B / w
+    x = np.ones(sp.L) / sp.L
+    for it in range(4000):
+        V, g, _ = sp.variance_GH(scale * x)
+        x = x * (-(scale * g))
+        x /= x.sum()
+    V = sp.variance(scale * x)
+    gap, lb, mu, info = oracle.optimality_certificate([sp], scale * x, w)
+    assert -1e-10 <= gap < 1e-6 and lb <= V * (1 + 1e-10), (gap, info)
+    touched = np.unique(np.concatenate([g[x[c0:c1] > 1e-8].ravel() for g, c0, c1 in zip(sp.groups, sp.cumsizes, sp.cumsizes[1:])]))
+    assert len(touched) < sp.N                           # this optimum leaves models unsampled: the solved dual still closes the gap
+    gap_u = oracle.optimality_certificate([sp], scale / sp.L, w)[0]
+    assert gap_u > 0.05
+    # two outputs: the bound is valid (<= F at ANY feasible point, here random ones and sparse ones)
+    sps = [oracle.SparseOracleSAP(prob["C"][o], 3, prob["groups"]) for o in range(2)]
+    rng = np.random.RandomState(0)
+    pts = [rng.dirichlet(np.ones(sp.L)) for _ in range(3)]
+    sparse = np.zeros(sp.L); sparse[[0, 9, 30]] = [0.5, 0.3, 0.2]
+    pts.append(sparse)
+    Fs, lbs = [], []
+    for p in pts:
+        gap, lb, mu, info = oracle.optimality_certificate(sps, scale * p, w)
+        Fs.append(max(q.variance(scale * p) for q in sps))
+        lbs.append(lb)
+        assert gap >= -1e-10
+    assert max(lbs) <= min(Fs) * (1 + 1e-10)                      # every lower bound is below every attained value

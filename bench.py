@@ -449,6 +449,7 @@ def main():
             "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "collective_backend": None if (world == 1 or weak or sharded is None) else ("rccl" if backend == "nccl" else backend),
             "ranks_seen": ranks_seen,
+            "exchange": None if sharded is None else sharded.exchange_name,
             "config": {"workload": "n=%d models, groups up to size %d (K_tot=%d), n_out=%d, Wishart covariances; one step = V and grad V of one allocation for all outputs"
                                    % (n, kmax, L, n_out_all),
                        "n_models": n, "k_max": kmax, "K_tot": L, "n_out": n_out_all, "batch": 1, "parallelism": par,

@@ -58,6 +58,11 @@ SIGNATURES = {
     "bluest_spg_finish": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp],
     "bluest_spg_update": [c_vp, c_vp, c_vp, c_vp, c_vp, c_f64, c_i64, c_vp, c_vp],
     "bluest_intproj_eval": [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp],
+    "bluest_xchg_create": [ctypes.POINTER(c_vp), c_int, c_int, c_i64, c_vp],
+    "bluest_xchg_connect": [c_vp, c_vp],
+    "bluest_xchg_allreduce_sum": [c_vp, c_vp, c_i64, c_vp],
+    "bluest_xchg_status": [c_vp, c_i64p, ctypes.POINTER(c_int)],
+    "bluest_xchg_destroy": [c_vp],
     "bluest_simplex_workspace_doubles": [c_i64, c_i64p],
     "bluest_simplex_project": [c_vp, c_vp, c_f64, c_f64, c_f64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
 }

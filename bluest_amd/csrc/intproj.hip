@@ -18,13 +18,15 @@ __global__ __launch_bounds__(64) void k_intproj(int N, int n_out, int LL, const 
     const int NN = N * N;
     const double *b = base + (int64_t)o * NN;
     const double *cl = cols + (int64_t)o * LL * NN;
+    clear_pads(lds, N, lane, WAVE);
+    __syncthreads();
     for (int t = lane; t < NN; t += WAVE) {
         double x = b[t];
         for (int j = 0; j < LL; j++) x = fma(sms[j], cl[(int64_t)j * NN + t], x);
-        lds.phi[t] = x;
+        lds.at(t / N, t % N) = x;
     }
     __syncthreads();
-    const bool sup = lane < N && lds.phi[lane * N + lane] > 0.0;
+    const bool sup = lane < N && lds.at(lane, lane) > 0.0;
     double var = 0.0, vdummy = 0.0;
     int32_t status = 0;
     solve_wave<NT>(lds, N, 0.0, sup, sup, true, false, &var, &vdummy, &status, lane);

@@ -163,16 +163,14 @@ __global__ __launch_bounds__(fold_threads(NT)) void k_solve_from_chunks(int N, i
     __shared__ SolveLds<NT> lds;
     if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
     const int o = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
-    if (tid < N) lds.amax[tid] = 0.0;
-    for (int t = tid; t < N * N; t += fold_threads(NT)) lds.phi[t] = 0.0;
-    __syncthreads();
+    if (N < NT) { clear_pads(lds, N, tid, fold_threads(NT)); __syncthreads(); }   // uniform; every real entry is written by the fold
     fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, fold_threads(NT));
     __syncthreads();
     if (tid >= WAVE) return;   // single wavefront from here on
     const int lane = tid;
     const int64_t e = (int64_t)c * n_out + o;
     if (want_v & 2) {   // diagnostics: fold only (timing experiments)
-        if (lane == 0) { var[e] = lds.phi[0]; status[e] = 0; }
+        if (lane == 0) { var[e] = lds.at(0, 0); status[e] = 0; }
         return;
     }
     const double am = (lane < N) ? lds.amax[lane] : 0.0;
@@ -190,14 +188,11 @@ __global__ __launch_bounds__(fold_threads(NT)) void k_fold_to_record(int N, int 
 {
     __shared__ SolveLds<NT> lds;
     const int o = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
-    if (tid < N) lds.amax[tid] = 0.0;
-    for (int t = tid; t < N * N; t += fold_threads(NT)) lds.phi[t] = 0.0;
-    __syncthreads();
     fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, fold_threads(NT));
     __syncthreads();
     const int reclen = N * N + 2 * N + 1;
     double *r = rec + ((int64_t)c * n_out + o) * reclen;
-    for (int t = tid; t < N * N; t += fold_threads(NT)) r[t] = lds.phi[t];
+    for (int t = tid; t < N * N; t += fold_threads(NT)) r[t] = lds.at(t / N, t % N);
     if (tid >= WAVE) return;
     const double am = (tid < N) ? lds.amax[tid] : 0.0;
     if (tid < N) { r[N * N + tid] = (am > 1.0e-6) ? 1.0 : 0.0; r[N * N + N + tid] = (am > 0.0) ? 1.0 : 0.0; }
@@ -215,7 +210,9 @@ __global__ __launch_bounds__(64) void k_solve_from_record(int N, int n_out, cons
     const int o = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
     const int reclen = N * N + 2 * N + 1;
     const double *r = rec + ((int64_t)c * n_out + o) * reclen;
-    for (int t = lane; t < N * N; t += WAVE) lds.phi[t] = r[t];
+    clear_pads(lds, N, lane, WAVE);
+    __syncthreads();
+    for (int t = lane; t < N * N; t += WAVE) lds.at(t / N, t % N) = r[t];
     __syncthreads();
     const bool s1 = lane < N && r[N * N + lane] > 0.0;
     const bool s2 = lane < N && r[N * N + N + lane] > 0.0;
@@ -278,15 +275,16 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
     int o, first;
     if (bpo > 0) { o = blockIdx.x / bpo; first = (blockIdx.x % bpo) == 0; }
     else { const TileDesc td0 = tiles[t0]; o = td0.out; first = (td0.n_valid >> 30) & 1; }
-    if (tid < N) lds.amax[tid] = 0.0;
-    for (int t = tid; t < N * N; t += NTHREADS) lds.phi[t] = 0.0;
-    __syncthreads();
+    if (N < NT) { clear_pads(lds, N, tid, NTHREADS); __syncthreads(); }   // uniform; every real entry is written by the fold
     PHASE(1);
     fold_rows<NT>(lds, N, rows, o * nsym, nsym, partial, tid, NTHREADS);
+    // the list is padded to a multiple of FUSED_TPB tiles per output, so every tile of this workgroup belongs to output o
+    // (loaded by the tile wavefronts only: the solving wavefront must not wait for a descriptor it does not use)
+    TileDesc td;
+    td.k = 1; td.n_valid = 0; td.val_off = td.idx_off = td.grad_off = 0; td.out = (int16_t)o;
+    if (wave > 0) td = tiles[t0 + wave - 1];
     __syncthreads();
     PHASE(2);
-    // the list is padded to a multiple of FUSED_TPB tiles per output, so every tile of this workgroup belongs to output o
-    const TileDesc td = tiles[t0 + (wave > 0 ? wave - 1 : 0)];
     const int k = td.k;
     double s[NE];
     int gi[KU];
@@ -522,11 +520,14 @@ extern "C" int bluest_plan_add_output_cov(bluest_plan_t plan, const double *C, i
         plan->d_scratch = nullptr; plan->scratch_bytes = 0;
         HIP_TRY(pool_alloc(&plan->d_scratch, need));
         plan->scratch_bytes = need;
+        timer.lap("scratch allocation");
     }
     double *dC = reinterpret_cast<double *>((char *)plan->d_scratch + offC), *dic = reinterpret_cast<double *>((char *)plan->d_scratch + offI);
     int64_t *dg = reinterpret_cast<int64_t *>((char *)plan->d_scratch + offG);
     hipError_t e = hipMemcpy(dC, C, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice);
+    timer.lap("H2D covariance");
     if (e == hipSuccess) e = hipMemcpy(dg, groups, (size_t)ng * sizeof(int64_t), hipMemcpyHostToDevice);
+    timer.lap("H2D groups");
     rc = BLUEST_OK;
     if (e == hipSuccess) {
         int64_t go = 0, io = 0;

@@ -14,23 +14,32 @@ struct RowDesc {      // one symmetric destination (a <= b) of one output
 };
 
 
-// ---- solve: one workgroup of 256 threads folds the chunk partials, then wavefront 0 factorises in REGISTERS ----
+// ---- solve: the workgroup folds the chunk partials into Phi (LDS), then ONE wavefront eliminates in REGISTERS ----
 //
-// Ordering trick: the restricted system is permuted so that the TARGET model (model 0 if it is sampled, else the
-// smallest sampled model, as pinv(PHI[idx])[0,0] of misc.py:490 would pick) comes LAST.  With A = L L^T and
-// e = e_last:  L y = e  =>  y = e_last / L_nn, so V = e^T A^-1 e = 1/L_nn^2 needs NO triangular solve, and
-// x = A^-1 e needs only the backward one.  Lane i holds row i of A / L in registers (static indices after full
-// unrolling); column broadcasts are v_readlane (SGPR operands), no LDS and no barriers inside the factorisation.
-template <int NT>   // NT >= N: LDS footprint follows the problem (6.7 KB at NT = 20), not the 64-model maximum
+// Ordering: position p of the elimination holds model NT-1-p, so the TARGET model 0 comes LAST and the identity pads
+// (models N..NT-1 do not exist) come first -- a STATIC map: no permutation has to be computed, lane p reads its row as
+// NT contiguous doubles.  Phi is therefore kept REVERSED in LDS: entry (a, b) lives at [(NT-1-a) * LDP + (NT-1-b)], row
+// stride LDP = NT + 2 doubles (an odd number of 16-byte words: the 16-byte row reads of the 64 lanes do not collide on banks).
+// With A the restricted matrix and e = e_last: Gauss-Jordan leaves V = e^T A^-1 e = 1/p_last and x = A^-1 e without any
+// triangular solve (gj_regs below).  Models that are not sampled keep an identity row / column in place.
+template <int NT>   // NT >= N: LDS footprint follows the problem (3.8 KB at NT = 20), not the 64-model maximum
 struct SolveLds {
-    static constexpr int LDA = NT + 1;
-    double phi[NT * NT];        // full symmetric Phi (no delta), row stride N
-    double lt[NT * (NT + 1)];   // L, for the transposed read of the backward solve
+    static constexpr int LDP = NT + 2;
+    double phi[NT * LDP];       // reversed symmetric Phi (no delta); rows / columns of the pads are zero
     double amax[NT];            // per model: max |m_i| over groups containing it
     double vout[NT];            // row 0 of pinv(Phi) for the fused gradient pass
-    int model_of_pos[NT];
     int status;
+    __device__ __forceinline__ double &at(int a, int b) { return phi[(NT - 1 - a) * LDP + (NT - 1 - b)]; }
 };
+
+// zero-fill before a fold when pads exist (N < NT); the caller synchronises afterwards.  With N == NT every entry is
+// written by the fold itself (every symmetric destination has a row descriptor), so nothing needs clearing.
+template <int NT>
+__device__ __forceinline__ void clear_pads(SolveLds<NT> &lds, int N, int tid, int nthreads)
+{
+    if (N < NT)
+        for (int t = tid; t < NT * SolveLds<NT>::LDP; t += nthreads) lds.phi[t] = 0.0;
+}
 
 __device__ __forceinline__ double readlane_f64(double x, int l)
 {   // l must be wave-uniform (here: a compile-time constant after unrolling)
@@ -65,8 +74,8 @@ __device__ __forceinline__ void fold_rows(SolveLds<NT> &lds, int N, const RowDes
         s += __shfl_xor(s, 2);
         am = fmax(am, __shfl_xor(am, 2));
         if (q == 0) {
-            lds.phi[rd.a * N + rd.b] = s;
-            lds.phi[rd.b * N + rd.a] = s;
+            lds.at(rd.a, rd.b) = s;
+            lds.at(rd.b, rd.a) = s;
             if (rd.a == rd.b) lds.amax[rd.a] = am;
         }
     }
@@ -97,21 +106,27 @@ __device__ __forceinline__ double rcp_f64(double x)
 // `lane` sits in a[0..NT), straight-line code: no predicates, no LDS, no barriers.  Step j subtracts multiples of row j
 // from ALL other rows (the lanes above the diagonal are there anyway, so eliminating upwards is free and replaces the
 // backward substitution of a Cholesky solve).  Only columns c > j are touched.  The pivots are the same Schur-complement
-// diagonals a Cholesky factorisation squares-roots, so "not positive definite" is detected identically.
+// diagonals a Cholesky factorisation squares-roots.  "Not positive definite" = some pivot is not larger than
+// PIVOT_TOL times the ORIGINAL diagonal entry of its row (a relative test, in the spirit of the rcond of numpy's pinv;
+// each lane checks its own pivot when its turn comes, one compare per step).
 // The right-hand side is e_last and never stored: it stays e_last until the last step, hence on return
 //   x_last = 1/p_last,   x_i = -a[NT-1](lane i, before the last step) / (p_i p_last)   (i != last)
 // with p_i = pivot i; rinv_mine = 1/p_lane, last_pivot = p_last.
+#define BLUEST_PIVOT_TOL 1.0e-14
 template <int NT>
-__device__ __forceinline__ void gj_regs(double (&a)[NT], int lane, double &rinv_mine, double &last_pivot, int &bad)
+__device__ __forceinline__ void gj_regs(double (&a)[NT], int lane, double diag0, double &rinv_mine, double &last_pivot, int &bad)
 {
+    const double floor_mine = BLUEST_PIVOT_TOL * diag0;
+    bool flag = false;
 #pragma unroll
     for (int j = 0; j < NT; j++) {
         const double piv = readlane_f64(a[j], j);
-        bad |= (!(piv > 0.0) || !isfinite(piv)) ? 1 : 0;
+        const bool is = lane == j;
+        flag = is ? !(a[j] > floor_mine) : flag;           // NaN and non-positive pivots included
         const double rinv = rcp_f64(piv);
-        rinv_mine = (lane == j) ? rinv : rinv_mine;
+        rinv_mine = is ? rinv : rinv_mine;
         if (j == NT - 1) { last_pivot = piv; break; }
-        const double f = (lane == j) ? 0.0 : -a[j] * rinv;
+        const double f = is ? 0.0 : -a[j] * rinv;
         // pivot row first (scalar registers), then the updates: the broadcasts do not depend on each other, so issuing
         // them in a block hides the VALU-writes-SGPR -> VALU-reads-it wait states that a readlane/fma ping-pong pays
         double u[NT];
@@ -120,26 +135,29 @@ __device__ __forceinline__ void gj_regs(double (&a)[NT], int lane, double &rinv_
 #pragma unroll
         for (int c = j + 1; c < NT; c++) a[c] = fma(f, u[c], a[c]);
     }
+    bad |= (__ballot(flag && lane < NT) != 0ull || !isfinite(last_pivot)) ? 1 : 0;
 }
 
-// One (candidate, output): masks -> permuted, identity-padded restricted matrix in registers -> Cholesky -> V (-> v).
-// Called by ONE wavefront (lane = 0..63); lds.phi is ready.  Order of the NT positions:
-//   [ NT-nr identity pads | sampled models except the target, ascending | target ]
-// so the target always sits at the static position NT-1.
+// One (candidate, output): masks -> identity-padded restricted matrix in registers (static order) -> Gauss-Jordan -> V (-> v).
+// Called by ONE wavefront (lane = 0..63); lds.phi is ready.  s1 / s2 (lane = model): model touched by a group with
+// |m| > 1e-6 (misc.py:453-457, the rows of V's restricted system) / by a group with m != 0 (support of Phi, for v).
 template <int NT>
 __device__ __forceinline__ void solve_wave(SolveLds<NT> &lds, int N, double delta, bool s1, bool s2, bool big_in, bool want_v,
                                         double *__restrict__ var_out, double *__restrict__ v_out,
                                         int32_t *__restrict__ status_out, int lane)
 {
-    // mask1: models touched by a group with |m| > 1e-6 (misc.py:453-457) -> V; mask2: support of Phi+delta*I -> v
+    constexpr int LDP = SolveLds<NT>::LDP;
     const unsigned long long mask1 = __ballot(lane < N && s1);
     const unsigned long long mask2 = (delta != 0.0) ? __ballot(lane < N) : __ballot(lane < N && s2);
+    const unsigned long long all = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
     const bool big = uniform_i(big_in ? 1 : 0) != 0;
     int status = BLUEST_EVAL_OK;
-    double V = 0.0, vfill = 0.0, xpos = 0.0;
-    int xrow = -1;
-    unsigned long long xmask = 0ull;
-    bool have_x = false;
+    double V = 0.0;
+    // v defaults: zero everywhere (NaN after a singular elimination); filled per model below
+    double vmine = 0.0;                     // value of v for the model this lane's POSITION holds
+    unsigned long long vmask = 0ull;        // models for which vmine is meaningful
+    int vswap = 0;
+    const int p = lane < NT ? lane : NT - 1;          // lanes beyond NT shadow the last row (results unused)
     if (!big) {
         status = BLUEST_EVAL_INF;
         V = INFINITY;
@@ -150,58 +168,73 @@ __device__ __forceinline__ void solve_wave(SolveLds<NT> &lds, int N, double delt
         if (!(mask1 & 1ull)) status = BLUEST_EVAL_NO_MODEL0;
         const int npass = (mask1 == mask2 || !want_v) ? 1 : 2;
         for (int pass = 0; pass < npass; pass++) {
-            const unsigned long long mask = (pass == 0) ? mask1 : mask2;
+            unsigned long long mask = (pass == 0) ? mask1 : mask2;
             if (pass == 1 && !(mask & 1ull)) break;                     // row 0 of pinv(Phi) is zero
-            const int nr = __popcll(mask);
-            const int npad = NT - nr;
-            const int target = __ffsll((long long)mask) - 1;           // smallest sampled model, ordered LAST
-            // model at each position = inverse of "position of each model": every lane sends (its model + 1) to its
-            // position with one ds_permute (a bijection of the 64 lanes: sampled models -> their positions, everything else ->
-            // the pad / unused positions, carrying 0), then the columns' models are lane broadcasts of the result
-            const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-            const bool mine = lane < N && ((mask >> lane) & 1ull);
-            const int jfree = lane - below;                            // rank among the lanes that are not sampled models
-            const int dest = mine ? ((lane == target) ? NT - 1 : npad + below - 1) : (jfree < npad ? jfree : NT + (jfree - npad));
-            const int rowm = __builtin_amdgcn_ds_permute(dest << 2, mine ? lane + 1 : 0) - 1;
-            int colm[NT];
-#pragma unroll
-            for (int c = 0; c < NT; c++) colm[c] = __builtin_amdgcn_readlane(rowm, c);
+            // target = smallest sampled model (model 0 unless it is unsampled: pinv(PHI[idx])[0,0] of misc.py:490 then
+            // picks the first row of the restricted matrix); it must sit at the last position: swap models 0 <-> t
+            const int t = __ffsll((long long)mask) - 1;
+            int mp = NT - 1 - p;                                        // ORIGINAL model whose row this position holds
+            if (t != 0) {
+                mp = (mp == 0) ? t : (mp == t ? 0 : mp);
+                mask = (mask | 1ull) & ~(1ull << t);                    // membership by POSITION index: bits 0 and t exchanged
+            }
+            const bool mine = (NT - 1 - p) < N && ((mask >> (NT - 1 - p)) & 1ull);
+            const double *row = lds.phi + (NT - 1 - mp) * LDP;
             double a[NT];
             PHASE(9);
 #pragma unroll
+            for (int c = 0; c < NT; c += 2) {
+                const double2 x = *reinterpret_cast<const double2 *>(row + c);
+                a[c] = x.x; a[c + 1] = x.y;
+            }
+            if (t != 0) {   // column swap: position NT-1 <-> position NT-1-t
+#pragma unroll
+                for (int c = 0; c < NT - 1; c++)
+                    if (c == NT - 1 - t) { const double tmp = a[c]; a[c] = a[NT - 1]; a[NT - 1] = tmp; }
+            }
+            const unsigned long long smask = mask;                      // bit i: model at position NT-1-i is in the system
+            if (smask != all) {
+#pragma unroll
+                for (int c = 0; c < NT; c++) {
+                    const bool colin = (NT - 1 - c) < N && ((smask >> (NT - 1 - c)) & 1ull);
+                    a[c] = (mine && colin) ? a[c] : 0.0;
+                }
+            }
+            const double diag = mine ? delta : 1.0;                     // pads / unsampled models: identity row
+            double diag0 = 1.0;                                         // my original diagonal entry (lanes >= NT: unused)
+#pragma unroll
             for (int c = 0; c < NT; c++) {
-                const bool real = rowm >= 0 && colm[c] >= 0;
-                const double x = lds.phi[real ? rowm * N + colm[c] : 0];
-                const double diag = (c == lane) ? 1.0 : 0.0;
-                a[c] = real ? ((c == lane) ? x + delta : x) : diag;    // pads: identity
+                a[c] = (c == p) ? a[c] + diag : a[c];
+                diag0 = (c == p) ? a[c] : diag0;
             }
             double last_pivot = 1.0, rinv_mine = 0.0;
             int bad = 0;
             PHASE(5);
-            gj_regs<NT>(a, lane, rinv_mine, last_pivot, bad);
+            gj_regs<NT>(a, lane, diag0, rinv_mine, last_pivot, bad);
             PHASE(6);
             if (uniform_i(bad)) {
                 if (status == BLUEST_EVAL_OK) status = BLUEST_EVAL_SINGULAR;
                 if (pass == 0) V = NAN;
-                vfill = NAN;
-                have_x = false;
+                vmine = NAN; vmask = all; vswap = 0;
                 continue;
             }
             if (pass == 0) V = 1.0 / last_pivot;     // = (A^-1)_{target,target}
             if (want_v && pass == npass - 1) {
                 const double rl = readlane_f64(rinv_mine, NT - 1);
-                xpos = (lane == NT - 1) ? rl : -a[NT - 1] * rinv_mine * rl;   // x = A^-1 e_last at position `lane`
-                xrow = rowm;
-                xmask = mask;
-                vfill = 0.0;
-                have_x = (mask & 1ull) != 0ull;      // row 0 of pinv(Phi) is zero when model 0 is not in the support
+                const double x = (lane == NT - 1) ? rl : -a[NT - 1] * rinv_mine * rl;   // x = A^-1 e_last at position `lane`
+                // row 0 of pinv(Phi) is zero when model 0 is not in the support; otherwise x on the support, 0 elsewhere
+                const bool have = (mask2 & 1ull) != 0ull || delta != 0.0;
+                vmine = (have && mine) ? x : 0.0;
+                vmask = all;
+                vswap = t;
             }
         }
     }
     PHASE(7);
-    if (want_v) {   // v in model order: the support scattered from position order, zero (NaN if singular) elsewhere
-        if (lane < N && !(have_x && ((xmask >> lane) & 1ull))) v_out[lane] = vfill;
-        if (have_x && lane < NT && xrow >= 0) v_out[xrow] = xpos;
+    if (want_v) {   // position p holds model NT-1-p (0 <-> vswap exchanged)
+        int mp = NT - 1 - p;
+        if (vswap != 0) mp = (mp == 0) ? vswap : (mp == vswap ? 0 : mp);
+        if (lane < NT && mp < N) v_out[mp] = vmask ? vmine : 0.0;
         wave_lds_sync();
     }
     if (lane == 0) { *var_out = V; *status_out = status; }

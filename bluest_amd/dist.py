@@ -60,6 +60,86 @@ def shard_output(out, L_global_sizes, lo, hi):
     return new
 
 
+class PeerExchange(object):
+    """all-reduce(SUM) of a small float64 device buffer by direct peer writes (C-ABI Part 5, csrc/xchg.hip): one kernel launch
+    per rank instead of a ring collective -- the Phi record is 5-27 KB, so the exchange is latency-bound.
+    The mailbox handles travel through the torch.distributed group once, at construction.  `PeerExchange.create` returns None --
+    after telling why on stderr -- when the mailboxes cannot be set up or a self-test against the group's own all_reduce does not
+    reproduce it bit for bit on every rank; callers then keep using the group's all_reduce (RCCL)."""
+
+    def __init__(self, max_doubles, device, group=None):
+        import ctypes
+        from . import _lib
+        self.lib, self.group = _lib.lib(), group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device = torch.device(device)
+        self._h = ctypes.c_void_p()
+        handle = ctypes.create_string_buffer(64)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.bluest_xchg_create(ctypes.byref(self._h), self.world, self.rank, int(max_doubles), handle))
+            handles = [None] * self.world
+            dist.all_gather_object(handles, bytes(handle.raw), group=group)
+            _lib.check(self.lib.bluest_xchg_connect(self._h, b"".join(handles)))
+        self.max_doubles = int(max_doubles)
+
+    def all_reduce(self, t):
+        """in place; t: contiguous float64 device tensor with at most max_doubles entries"""
+        from . import _lib
+        from .plan import _stream
+        assert t.is_contiguous() and t.dtype == torch.float64 and t.numel() <= self.max_doubles
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.bluest_xchg_allreduce_sum(self._h, t.data_ptr(), t.numel(), _stream()))
+        return t
+
+    def timed_out(self):
+        import ctypes
+        flag = ctypes.c_int(0)
+        self.lib.bluest_xchg_status(self._h, None, ctypes.byref(flag))
+        return bool(flag.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.bluest_xchg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def create(max_doubles, device, group=None, rounds=8):
+        import sys
+        ok, why, ex = 1, "", None
+        try:
+            ex = PeerExchange(max_doubles, device, group=group)
+            rng = np.random.RandomState(99 + ex.rank)
+            for r in range(rounds):                               # self-test on THIS hardware against the group's all_reduce
+                n = max_doubles if r % 2 == 0 else max(1, max_doubles // 3)
+                a = torch.from_numpy(rng.randn(n) * 10.0 ** rng.randint(-3, 4)).to(ex.device)
+                b = a.clone()
+                ex.all_reduce(a)
+                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
+                torch.cuda.synchronize(ex.device)
+                if ex.timed_out() or not bool(torch.isfinite(a).all()) or float((a - b).abs().max()) > 1e-12 * float(b.abs().max() + 1e-300):
+                    ok, why = 0, "self-test round %d disagrees with all_reduce" % r
+                    break
+        except Exception as err:
+            ok, why = 0, "%s: %s" % (type(err).__name__, err)
+        # every rank must take the same decision
+        flag = torch.tensor([float(ok)], dtype=torch.float64, device=torch.device(device) if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if float(flag[0]) < 1.0:
+            if why:
+                sys.stderr.write("bluest_amd.dist: peer-write exchange unavailable on rank %d (%s); using the group's all_reduce\n"
+                                 % (dist.get_rank(group), why))
+            if ex is not None:
+                ex.close()
+            return None
+        return ex
+
+
 class ShardedPlan(object):
     """plan.Plan over this rank's shard of the groups + the all-reduce of the Phi records.
 
@@ -68,7 +148,10 @@ class ShardedPlan(object):
                   (default: the HIP plan; tests inject a CPU stand-in to exercise the wiring under gloo).
     """
 
-    def __init__(self, n_models, global_sizes, outputs, max_candidates=1, device=None, group=None, plan_factory=None):
+    def __init__(self, n_models, global_sizes, outputs, max_candidates=1, device=None, group=None, plan_factory=None,
+                 exchange="auto"):
+        """exchange: "auto" = the one-shot peer-write all-reduce (PeerExchange) when more than one rank runs on GPUs and its
+        self-test passes, else the group's all_reduce (RCCL); "collective" = always the group's all_reduce"""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -84,6 +167,14 @@ class ShardedPlan(object):
             plan_factory = Plan
         self.plan = plan_factory(n_models, self.L, local, max_candidates=max_candidates, device=device)
         self.n_out = len(outputs)
+        self.N = int(n_models)
+        self.device = getattr(self.plan, "device", None)
+        self.exchange = None
+        if exchange == "auto" and self.world > 1 and plan_factory.__name__ == "Plan" and self.device is not None:
+            reclen = self.N * self.N + 2 * self.N + 1
+            self.exchange = PeerExchange.create(max_candidates * self.n_out * reclen, self.device, group=group)
+        self.exchange_name = "peer-write (bluest_xchg)" if self.exchange is not None else "all_reduce (%s)" % (
+            dist.get_backend(group) if dist.is_initialized() else "none")
 
     def eval(self, m, delta=0.0, want_grad=True, rec=None, out=None):
         """returns (var (n_cand,n_out), grad_local | None, status); grad_local covers this rank's groups only, in the
@@ -91,7 +182,10 @@ class ShardedPlan(object):
         device tensors (the v workspace is kept by this object)."""
         rec = self.plan.phi(m, out=rec)
         if self.world > 1:
-            dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=self.group)
+            if self.exchange is not None:
+                self.exchange.all_reduce(rec)
+            else:
+                dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=self.group)
         if out is None:
             var, v, status = self.plan.solve(rec, delta)
             grad = self.plan.grad(v, status) if want_grad else None
@@ -104,6 +198,10 @@ class ShardedPlan(object):
             self.plan.grad(self._v, status, out=grad)
         return var, grad if want_grad else None, status
 
+    def combine_grad(self, grad_local, coef, scale=None, out=None):
+        """plan.Plan.combine_grad for the whole group set (same signature): see global_gradient"""
+        return self.global_gradient(grad_local, coef, scale=scale)
+
     def global_gradient(self, grad_local, coef, scale=None):
         """g[j] = scale[j] * sum_o coef[o] * dV_o/dm_j for ALL j: every rank fills the entries of its groups, one
         all-reduce(SUM) assembles the vector (entries owned by nobody stay 0)."""
@@ -111,3 +209,20 @@ class ShardedPlan(object):
         if self.world > 1:
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
         return g
+
+
+def sharded_spg(sharded, costs, budget=None, eps=None, x0=None, params=None):
+    """solver="spg" over a group-sharded plan: the host-driven SPG driver (bluest_amd.spg.spg = bluest/spg.py:39-132) with the
+    scaled metric, every rank running the SAME deterministic iteration on replicated vectors (x, g, d of length K_tot);
+    the callbacks are collective -- an objective evaluation is one all-reduce of the Phi records, a gradient evaluation one more
+    all-reduce of the gradient (every rank contributes the entries of its groups).  All ranks return the same allocation.
+    The reference runs its optimiser on one MPI rank (bluest/blue_models.py:508-526); this is the N-GPU counterpart of
+    SAP.solve / MOSAP.solve(..., continuous_relaxation=True).  Returns (samples, solver info)."""
+    from .sap import SpgAllocator
+    prm = {"device_loop": False, "maxit": 600, "eps": 1.0e-7}
+    if params:
+        prm.update(params)
+    prm["device_loop"] = False
+    alloc = SpgAllocator(sharded, costs, None, verbose=False, subplan=None)
+    m = alloc.solve(budget=budget, eps=eps, x0=x0, params=prm)
+    return m, alloc.info

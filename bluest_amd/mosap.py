@@ -12,7 +12,7 @@ import torch
 
 from . import misc
 from .plan import EVAL_INF, EVAL_SINGULAR, Plan
-from .sap import BLUESTError, LazyIndicators, SAP, SpgAllocator, normalise_groups, status_to_python
+from .sap import BLUESTError, LazyIndicators, SAP, SpgAllocator, enforce_sample_caps, no_gc_pause, normalise_groups, status_to_python
 
 
 def _group_keys(gk, N):
@@ -157,7 +157,14 @@ class MOSAP(object):
         self.costs = costs
         self.multi_groups = multi_groups
         self.multi_costs = multi_costs
+        self.samples = None
+        self.budget = None
+        self.eps = None
+        self.tot_cost = None
+        with no_gc_pause():
+            self._build(C, K, Ks, groups, multi_groups, device, max_candidates)
 
+    def _build(self, C, K, Ks, groups, multi_groups, device, max_candidates):
         normalise_groups(groups, K, flatten=False)                   # mosap.py:31-37 (in place)
         self.flattened_groups = _LazyFlat(groups)
         self.groups = groups
@@ -179,11 +186,6 @@ class MOSAP(object):
                          "mapping": None if ident else self.mappings[n]})
         self.plan = Plan(self.N, self.L, outs, max_candidates=max_candidates, device=device)
         self.SAPS = [_SapView(self, n) for n in range(self.n_outputs)]
-
-        self.samples = None
-        self.budget = None
-        self.eps = None
-        self.tot_cost = None
 
     def check_input(self, budget, eps):
         """bluest/mosap.py:74-84"""
@@ -389,8 +391,7 @@ class MOSAP(object):
             raise ValueError("Optimization solvers available: 'spg' (this build); the reference also lists 'scipy', 'ipopt', 'cvxopt', 'cvxpy'")
         if solver != "spg":
             raise BLUESTError("solver=%r is a third-party back-end of the reference that this GPU build does not ship; use solver='spg'" % solver)
-        if max_model_samples is not None:
-            raise BLUESTError("max_model_samples is not supported by solver='spg' (simplex projection only)")
+        cap_rows, cap_rhs = self.get_max_sample_constraints(max_model_samples)   # validates the argument as the reference does
         budget, eps = self.check_input(budget, eps)
 
         if self.verbose:
@@ -404,12 +405,14 @@ class MOSAP(object):
             es.append(ee)
         alloc = SpgAllocator(self.plan, self.costs, es, verbose=False, subplan=self._restricted_plan)
         try:
-            samples = alloc.solve(budget=budget, eps=eps, x0=x0, params=solver_params)
+            with no_gc_pause():
+                samples = alloc.solve(budget=budget, eps=eps, x0=x0, params=solver_params)
+                self.solver_info = alloc.info
+                samples = enforce_sample_caps(self.plan, self.costs, cap_rows, cap_rhs, samples, budget, eps, solver_params, self)
         except BLUESTError as err:
             if self.verbose: print(str(err))
             self.samples = None
             return None
-        self.solver_info = alloc.info
         if any(samples @ ee < 1.0 - 1.0e-9 for ee in es):
             if self.verbose: print("SPG solution samples model 0 less than once for some output; infeasible.")
             self.samples = None
@@ -418,7 +421,7 @@ class MOSAP(object):
         if not continuous_relaxation:
             from .integer import integer_projection_mosap
             try:
-                samples = integer_projection_mosap(self, samples, budget=budget, eps=eps)
+                samples = integer_projection_mosap(self, samples, budget=budget, eps=eps, max_model_samples=max_model_samples)
             except AssertionError as err:
                 print(str(err))
                 self.samples = None

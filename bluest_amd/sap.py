@@ -33,7 +33,7 @@ spg_sap_default_params = {
     "check_every": 20,        # iterations between host looks at the device state
     "scaling_floor": 1.0e-8,  # > 0: scaled SPG, steps and projections in the metric diag(1/max(x, floor)); 0: plain SPG
     "polish": True,           # working set: run the last continuation stage on the plan restricted to the largest entries,
-    "polish_support": 8,      #   polish_support * N of them, price the excluded groups with the full gradient and let those
+    "polish_support": 16,     #   polish_support * N of them, price the excluded groups with the full gradient and let those
     "polish_rounds": 2,       #   below the support's multiplier by price_tol (relative) join, at most polish_rounds times
     "price_tol": 1.0e-3,
     "polish_slots": 0,            # trial points inside the iteration graph on the working set (0 = as "slots"; the loop adds
@@ -58,6 +58,23 @@ spg_sap_default_params = {
 
 class BLUESTError(RuntimeError):
     pass
+
+
+class no_gc_pause(object):
+    """the constructors and solve() create ~1e5 short-lived Python objects (group lists, views); that is enough to trigger a
+    FULL pass of the cyclic collector, which in a process that has torch imported walks ~1e6 objects (30-70 ms, i.e. as long
+    as the whole set-up).  Inside these short sections the automatic collector is paused and the previous state restored."""
+
+    def __enter__(self):
+        import gc
+        self._was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        if self._was:
+            import gc
+            gc.enable()
+        return False
 
 
 def normalise_groups(groups, K, flatten=True):
@@ -120,6 +137,30 @@ def status_to_python(status, where):
         raise AssertionError("%s: model 0 is not sampled (bluest/misc.py:470)" % where)
     if status == EVAL_SINGULAR:
         raise AssertionError("%s: information matrix is singular on the sampled models (bluest/misc.py:473-474)" % where)
+
+
+def enforce_sample_caps(plan, costs, es, rhs, samples, budget, eps, solver_params, owner):
+    """max_model_samples (bluest/sap.py:222-240): if the unconstrained optimum already respects the caps it is the answer;
+    otherwise solve again over the capped set (bluest_amd/capped.py), started from the unconstrained allocation"""
+    if len(es) == 0 or samples is None:
+        return samples
+    if all(float(np.asarray(ee, dtype=np.float64) @ samples) <= rr for ee, rr in zip(es, rhs)):
+        return samples
+    from .capped import solve_capped
+    prm = dict(spg_sap_default_params)
+    if solver_params:
+        prm.update(solver_params)
+    clipped = samples.copy()
+    for ee, rr in zip(es, rhs):
+        tot = float(np.asarray(ee, dtype=np.float64) @ clipped)
+        if tot > rr:
+            clipped[np.asarray(ee) > 0] *= rr / tot
+    m, info = solve_capped(plan, costs, es, rhs, budget=budget, eps=eps, x0=clipped, prm=prm,
+                           unconstrained_cost=float(np.asarray(costs) @ samples))
+    if m is None:
+        raise BLUESTError("SPG with max_model_samples: %s" % info.get("reason", "no feasible allocation"))
+    owner.solver_info = info
+    return m
 
 
 class SpgAllocator(object):
@@ -481,7 +522,10 @@ class SAP(object):
         self.budget = None
         self.eps = None
         self.tot_cost = None
+        with no_gc_pause():
+            self._build(C, K, groups, device, max_candidates)
 
+    def _build(self, C, K, groups, device, max_candidates):
         sizes = [0] + [len(groupsk) for groupsk in groups]
         self.flattened_groups = normalise_groups(groups, K)
         self.sizes = sizes
@@ -644,8 +688,7 @@ class SAP(object):
             raise ValueError("Optimization solvers available: 'spg' (this build); the reference also lists 'scipy', 'ipopt', 'cvxopt', 'cvxpy'")
         if solver != "spg":
             raise BLUESTError("solver=%r is a third-party back-end of the reference that this GPU build does not ship; use solver='spg'" % solver)
-        if max_model_samples is not None:
-            raise BLUESTError("max_model_samples is not supported by solver='spg' (simplex projection only)")
+        es, rhs = self.get_max_sample_constraints(max_model_samples)      # validates the argument as the reference does
 
         if self.verbose:
             if eps is None: print("Minimizing statistical error for fixed cost...\n")
@@ -653,12 +696,18 @@ class SAP(object):
 
         alloc = SpgAllocator(self.plan, self.costs, [self.e], verbose=False, subplan=self._restricted_plan)
         try:
-            samples = alloc.solve(budget=budget, eps=None if eps is None else [eps], x0=x0, params=solver_params)
+            with no_gc_pause():
+                samples = alloc.solve(budget=budget, eps=None if eps is None else [eps], x0=x0, params=solver_params)
+                self.solver_info = alloc.info
+                samples = enforce_sample_caps(self.plan, self.costs, es, rhs, samples, budget, None if eps is None else [eps],
+                                              solver_params, self)
         except BLUESTError as err:
             if self.verbose: print(str(err))
             self.samples = None
             return None
-        self.solver_info = alloc.info
+        if samples is None:
+            self.samples = None
+            return None
         if samples @ self.e < 1.0 - 1.0e-9:
             if self.verbose: print("SPG solution samples model 0 less than once; infeasible for this budget.")
             self.samples = None
@@ -667,7 +716,7 @@ class SAP(object):
         if not continuous_relaxation:
             from .integer import integer_projection_sap
             try:
-                samples = integer_projection_sap(self, samples, budget=budget, eps=eps)
+                samples = integer_projection_sap(self, samples, budget=budget, eps=eps, max_model_samples=max_model_samples)
             except AssertionError as err:
                 print(str(err))
                 self.samples = None

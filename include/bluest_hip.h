@@ -240,6 +240,24 @@ int bluest_spg_finish(bluest_plan_t plan, const double *v_dev, const int32_t *st
 int bluest_intproj_eval(int N, int n_out, int LL, const double *base_dev, const double *cols_dev, const double *ms_dev,
                         int64_t n_cand, double *V_dev, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Part 5 -- one-shot all-reduce of the Phi records between the GPUs of ONE node
+ *
+ * NEW (the reference's optimiser runs on one MPI rank, bluest/blue_models.py:508-526).  One process per GPU.  Each rank
+ * creates its mailboxes, the ranks swap the 64-byte handles by any means (torch.distributed all_gather in bluest_amd/dist.py),
+ * connect, and then every bluest_xchg_allreduce_sum call -- issued by ALL ranks, in the same order -- replaces buf by the sum over
+ * ranks in ONE kernel launch per rank: direct peer writes of tagged 8-byte granules into fine-grained memory shared with
+ * hipIpc (csrc/xchg.hip).  The sum is formed in rank order, so all ranks hold identical bits.  Asynchronous on `stream`;
+ * bluest_xchg_status reports the number of completed calls and whether a wait ever timed out (the result is then NaN).
+ * ---------------------------------------------------------------------------------------------------- */
+#define BLUEST_XCHG_HANDLE_BYTES 64
+typedef struct bluest_xchg_s *bluest_xchg_t;
+int bluest_xchg_create(bluest_xchg_t *xchg, int world, int rank, int64_t max_doubles, void *handle_out /* 64 bytes */);
+int bluest_xchg_connect(bluest_xchg_t xchg, const void *all_handles /* world * 64 bytes, rank order */);
+int bluest_xchg_allreduce_sum(bluest_xchg_t xchg, double *buf_dev, int64_t n_doubles, void *stream);
+int bluest_xchg_status(bluest_xchg_t xchg, int64_t *calls, int *timed_out);
+int bluest_xchg_destroy(bluest_xchg_t xchg);
+
 #ifdef __cplusplus
 }
 #endif

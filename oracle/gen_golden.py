@@ -336,6 +336,59 @@ def gen_intproj(bluest, misc, fname):
     print(fname, out["s_budget_fval"], out["s_eps_fval"], out["m_budget_fval"], out["m_eps_fval"], len(out["s_idx"]))
 
 
+def gen_singular(bluest, fname):
+    """a rank-deficient information matrix with EVERY model touched: models 2 and 3 are perfectly correlated, so the covariance
+    blocks of the groups that contain both are singular and their pseudo-inverses (sap.py:74) leave Phi singular on span(e2 - e3).
+    Records what the reference returns there: `variance` goes through np.linalg.solve (misc.py:472), `variance_GH` through
+    np.linalg.pinv (misc.py:487,490) -- the two disagree with each other (the build reports BLUEST_EVAL_SINGULAR instead)."""
+    rng = np.random.RandomState(5)
+    n = 5
+    Z = rng.randn(n, 12)
+    C = Z @ Z.T / 12
+    C[3, :] = C[2, :]; C[:, 3] = C[:, 2]; C[3, 3] = C[2, 2]
+    groups = [[[0], [1], [4]], [[0, 1], [2, 3], [1, 4]], [[0, 2, 3], [1, 2, 3]]]
+    costs = np.ones(8)
+    sap = bluest.SAP(C.copy(), 3, [[list(g) for g in gk] for gk in groups], costs, verbose=False)
+    m = np.array([3.0, 2.0, 1.5, 4.0, 2.5, 1.0, 3.5, 2.0])
+    PHI = sap.get_phi(m)
+    try:
+        v_solve, asserted = sap.variance(m), 0
+    except AssertionError:
+        v_solve, asserted = np.nan, 1
+    V, g, _ = sap.variance_GH(m, nohess=True)
+    out = {"n": n, "C": C, "m": m, "PHI": PHI, "eigmin": np.linalg.eigvalsh(PHI)[0], "variance_solve": v_solve,
+           "variance_asserted": asserted, "Vgh_pinv": V, "grad_pinv": g, "invcovs": np.concatenate(sap.invcovs)}
+    for k, gk in enumerate(groups):
+        out["g_k%d" % (k + 1)] = np.array(gk, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, "eigmin", out["eigmin"], "variance (solve)", v_solve, "variance_GH (pinv)", V)
+
+
+def gen_spg_bound(bluest, spgmod, n, kmax, fname, maxit):
+    """best objective the reference's plain spg() (spg.py:39-132, its own defaults) reaches on the sample-allocation problem
+    with the reference's callbacks within `maxit` iterations: an upper bound the build's solver has to beat"""
+    prob = synth.problem(n, kmax, 1)
+    sap = bluest.SAP(prob["C"][0].copy(), kmax, lists_of(prob["groups"]), prob["costs"], verbose=False)
+    scale = prob["budget"] / prob["costs"]
+    best = [np.inf]
+
+    def feval(x):
+        try:
+            f = sap.variance(scale * x)
+        except AssertionError:
+            f = np.inf
+        best[0] = min(best[0], f)
+        return f
+
+    def geval(x):
+        return scale * sap.variance_GH(scale * x, nohess=True)[1]
+
+    res = spgmod.spg(feval, geval, orc.simplex_projection, np.ones(sap.L) / sap.L, eps=1.0e-9, maxit=maxit, max_fevals=10 ** 5, verbose=False)
+    np.savez_compressed(os.path.join(OUT, fname), n=n, kmax=kmax, maxit=maxit, best_f=best[0], it=res["it"], count=res["count"],
+                        gpmax=res["gpmax"], solver_info=res["solver_info"])
+    print(fname, "best f", best[0], "it", res["it"], "count", res["count"], "gpmax", res["gpmax"])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cm, bluest, misc, spgmod = import_reference()
@@ -350,7 +403,14 @@ def main():
     gen_spg(bluest, spgmod, 6, 6, "spg_traj_n6.npz", maxit=60)
     gen_spg(bluest, spgmod, 12, 4, "spg_traj_n12_k4.npz", maxit=40)
     gen_intproj(bluest, misc, "intproj_known_answers.npz")
+    gen_singular(bluest, "singular_phi_known_answer.npz")
+    gen_spg_bound(bluest, spgmod, 12, 12, "spg_bound_n12_all.npz", maxit=400)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--new-only":       # the fixtures added in round 2, leaving the others untouched
+        cm_, bluest_, misc_, spgmod_ = import_reference()
+        gen_singular(bluest_, "singular_phi_known_answer.npz")
+        gen_spg_bound(bluest_, spgmod_, 12, 12, "spg_bound_n12_all.npz", maxit=400)
+    else:
+        main()

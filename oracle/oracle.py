@@ -379,7 +379,7 @@ class SparseOracleSAP(object):
         return var, grad, None
 
 
-def optimality_certificate(saps, m, costs, s=None, tol=1.0e-7, max_rounds=60, verbose=False):
+def optimality_certificate(saps, m, costs, s=None, tol=1.0e-7, max_rounds=60, verbose=False, max_seconds=None):
     """Duality certificate for  min_m F(m) = max_o V_o(m)/s_o  s.t.  costs.m = B, m >= 0  (the problem bluest/sap.py:387-418
     and bluest/mosap.py:578-605 hand to scipy) at a candidate allocation m, B = costs.m.  saps: one SparseOracleSAP per
     output, all on the same global group list.
@@ -396,7 +396,9 @@ def optimality_certificate(saps, m, costs, s=None, tol=1.0e-7, max_rounds=60, ve
     within 2 % of the maximum, is optimised by a bounded scalar search when two outputs are in play (the dual function is
     concave in mu) and by cyclic pairwise searches beyond.  Only quantities the oracle computes enter (Phi via objectiveK_c, the
     quadratic forms via gradK_c); nothing from the GPU path.  Returns (relative gap (F - LB)/F, LB, mu, info)."""
+    import time
     from scipy.optimize import minimize, minimize_scalar
+    deadline = None if max_seconds is None else time.time() + float(max_seconds)
     O = len(saps)
     m = np.asarray(m, dtype=np.float64)
     w = np.asarray(costs, dtype=np.float64)
@@ -472,7 +474,11 @@ def optimality_certificate(saps, m, costs, s=None, tol=1.0e-7, max_rounds=60, ve
             if len(viol) == 0 and solved:
                 break
             add = viol[np.argsort(-c[viol])[:96]] if len(viol) else np.zeros(0, dtype=np.int64)
+            if len(work) > 600:                                      # keep the QP small: constraints far from active leave the working
+                work = work[c[work] >= 0.8 * max(tau, 1.0e-300)]     # set (they come back through `viol` if they matter again)
             work = np.unique(np.concatenate([work, add]))
+            if deadline is not None and time.time() > deadline:      # out of time: the best bound so far stays valid
+                break
             Qd = dense_blocks(work)
 
             def cons(xv, Qd=Qd):
@@ -494,8 +500,8 @@ def optimality_certificate(saps, m, costs, s=None, tol=1.0e-7, max_rounds=60, ve
             state["solves"] += 1
             # SLSQP often stops with "positive directional derivative" (status 8) AT the solution of such min-max problems:
             # what counts is that the point is feasible for the working set and not worse than the start
-            ok = np.isfinite(res.x).all() and res.x[-1] <= x0[-1] * (1.0 + 1.0e-12) and \
-                cons(res.x).min() >= -1.0e-9 * max(res.x[-1], 1.0e-300) and abs(float(a_grad @ res.x) - A0) <= 1.0e-9 * abs(A0)
+            ok = np.isfinite(res.x).all() and res.x[-1] <= x0[-1] * (1.0 + 1.0e-9) and \
+                cons(res.x).min() >= -1.0e-6 * max(res.x[-1], 1.0e-300) and abs(float(a_grad @ res.x) - A0) <= 1.0e-8 * abs(A0)
             solved = ok and res.status in (0, 8)
             if ok:
                 Yc, tau = res.x[:nY].reshape(nA, N), float(res.x[-1])
@@ -508,19 +514,37 @@ def optimality_certificate(saps, m, costs, s=None, tol=1.0e-7, max_rounds=60, ve
     if nA == 1:
         dual_for(np.ones(1))
     else:
-        mu_a = np.exp(-(F - r[act]) / (0.005 * F))
+        # multipliers from the stationarity of the candidate on its own support: sum_o mu_o grad r_o(m)_i / w_i = -lambda for the
+        # groups with m_i > 0 (there the pinv-based gradient is exact: those groups only contain sampled models) -- a small
+        # non-negative least-squares problem; exact at an optimum, a good start near one
+        from scipy.optimize import nnls
+        sup = np.flatnonzero(m > 1.0e-9 * m.max())
+        Gs = quad_forms(Y0)[sup] / (B * F) * (F * F)             # q_{i,o}(y_o) / w_i with y = F * Y0, i.e. -grad V_o / w_i
+        Gs = Gs / sa[None, :]
+        scale_rows = 1.0 / np.abs(Gs).max()
+        A_ls = np.vstack([np.hstack([Gs * scale_rows, -np.ones((len(sup), 1))]), np.concatenate([np.ones(nA), [0.0]])[None, :] * 10.0])
+        b_ls = np.concatenate([np.zeros(len(sup)), [10.0]])
+        sol, _ = nnls(A_ls, b_ls)
+        mu_a = np.maximum(sol[:nA], 1.0e-9)
         mu_a /= mu_a.sum()
-        for sweep in range(2 if nA > 2 else 1):
+        dual_for(mu_a.copy())
+        for sweep in range(2):
             for c in range(1, nA):                                   # move weight between output act[0] and act[c]
+                if deadline is not None and time.time() > deadline:
+                    break
                 tot = mu_a[0] + mu_a[c]
+                t0 = mu_a[c] / tot
 
                 def along(t, c=c, tot=tot):
                     mm = mu_a.copy()
                     mm[0], mm[c] = tot * (1.0 - t), tot * t
                     return -dual_for(np.maximum(mm, 1.0e-12))
 
-                res = minimize_scalar(along, bounds=(0.0, 1.0), method="bounded", options={"xatol": 1.0e-4, "maxiter": 25})
+                res = minimize_scalar(along, bounds=(max(0.0, t0 - 0.15), min(1.0, t0 + 0.15)), method="bounded",
+                                      options={"xatol": 2.0e-4, "maxiter": 10})
                 mu_a[0], mu_a[c] = tot * (1.0 - res.x), tot * res.x
+            if state["best"][0] > 1.0 - 1.0e-5:
+                break
     lb_n, Yb, mub = state["best"]
     lb = lb_n * F
     mu_full = np.zeros(O)

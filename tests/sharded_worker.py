@@ -1,0 +1,77 @@
+"""
+Worker of tests/test_gpu_dist.py (launched with torch.distributed.run, one process per rank, ALL ranks on cuda:0 with the gloo
+backend -- RCCL refuses two ranks per device; on a multi-GPU node the same code runs with one rank per GPU over RCCL).
+Group-sharded HIP plans: evaluation (Phi records all-reduced, redundant solves, per-shard gradients) and the sharded SPG solve;
+rank 0 writes what the test compares with the single-process results.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bluest_amd import synth                      # noqa: E402
+from bluest_amd.dist import ShardedPlan, sharded_spg   # noqa: E402
+from bluest_amd.plan import Plan                  # noqa: E402
+
+
+def main(out_path):
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    res = {"world": world}
+    # the one-shot peer-write exchange (C-ABI Part 5) against the group's all_reduce, incl. back-to-back calls of different length
+    from bluest_amd.dist import PeerExchange
+    ex = PeerExchange.create(2000, dev)
+    res["peer_exchange_available"] = ex is not None
+    if ex is not None:
+        rng = np.random.RandomState(5 + rank)
+        worst, same = 0.0, True
+        for n_ in (1, 63, 676, 2000, 7, 2000, 1999):
+            a = torch.from_numpy(rng.randn(n_)).to(dev)
+            b = a.clone()
+            ex.all_reduce(a)
+            dist.all_reduce(b)
+            torch.cuda.synchronize()
+            worst = max(worst, float((a - b).abs().max()))
+            gathered = [torch.empty(n_, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(gathered, a.cpu())
+            same = same and all(torch.equal(gathered[0], q) for q in gathered)
+        res["peer_exchange_err"], res["peer_exchange_identical_on_all_ranks"], res["peer_exchange_timed_out"] = worst, same, ex.timed_out()
+    for tag, (n, kmax, n_out) in (("n12_k4_o1", (12, 4, 1)), ("n10_k3_o3", (10, 3, 3))):
+        prob = synth.problem(n, kmax, n_out)
+        sizes = [len(g) for g in prob["groups"]]
+        outs = [{"K": kmax, "sizes": sizes, "groups": prob["groups"], "C": prob["C"][o], "mapping": None} for o in range(n_out)]
+        sp = ShardedPlan(n, sizes, outs, device=dev)
+        full = Plan(n, prob["K_tot"], outs, device=dev)
+        m = torch.from_numpy(prob["m"][0]).to(dev)
+        var, grad_local, status = sp.eval(m)
+        v_full, g_full, st_full = full.eval(m)
+        coef = torch.from_numpy(np.linspace(0.2, 1.0, n_out).reshape(1, -1)).to(dev)
+        g_glob = sp.combine_grad(grad_local, coef)
+        g_want = full.combine_grad(g_full, coef)
+        res[tag + "_eval_err"] = float((var / v_full - 1).abs().max())
+        res[tag + "_grad_err"] = float((g_glob - g_want).abs().max() / g_want.abs().max())
+        res[tag + "_status_equal"] = bool(torch.equal(status, st_full))
+        res[tag + "_shard"] = [sp.lo, sp.hi]
+        res[tag + "_exchange"] = sp.exchange_name
+        m_sh, info = sharded_spg(sp, prob["costs"], budget=prob["budget"], params={"smoothing_p": 512.0})
+        all_m = [torch.empty(prob["K_tot"], dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(all_m, torch.from_numpy(np.ascontiguousarray(m_sh)))
+        res[tag + "_ranks_agree"] = bool(all(torch.equal(all_m[0], q) for q in all_m))
+        vs, _, st = full.eval(torch.from_numpy(m_sh).to(dev), want_grad=False)
+        res[tag + "_F_sharded"] = float(vs.max())
+        res[tag + "_cost_ratio"] = float(m_sh @ prob["costs"] / prob["budget"])
+        res[tag + "_it"] = int(info["it"])
+    if rank == 0:
+        json.dump(res, open(out_path, "w"))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

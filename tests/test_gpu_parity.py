@@ -260,6 +260,29 @@ def test_group_sharded_hip_plans_ragged(gpu):
         _check_shards_against_full(torch, n, sizes, outs, mos.plan, mos.mappings, m, (2, 3))
 
 
+def test_singular_phi_is_reported(gpu):
+    """deliberate deviation, quantified by tests/golden/singular_phi_known_answer.npz: on a rank-deficient information matrix
+    (every model touched, two of them perfectly correlated) the reference returns a pinv value from variance_GH (0.0918,
+    misc.py:487,490) and an unrelated number from variance (0.0135, np.linalg.solve on a numerically singular matrix,
+    misc.py:472); the build assembles the same Phi (1e-12, incl. the pseudo-inverses of the singular blocks) and then reports
+    BLUEST_EVAL_SINGULAR -> AssertionError from both (relative pivot test, csrc/solve.hpp)"""
+    from bluest_amd.sap import SAP
+    G = golden("singular_phi_known_answer.npz")
+    groups = [G["g_k%d" % k].copy() for k in (1, 2, 3)]
+    sap = SAP(G["C"].copy(), 3, groups, np.ones(8), verbose=False)
+    assert rel_err(np.concatenate(sap.invcovs), G["invcovs"]) < 1e-10
+    assert rel_err(sap.get_phi(G["m"]), G["PHI"]) < 1e-12
+    with pytest.raises(AssertionError):
+        sap.variance(G["m"])
+    with pytest.raises(AssertionError):
+        sap.variance_GH(G["m"], nohess=True)
+    # with a regularisation the matrix is definite again and the three agree (reference semantics of delta, misc.py:461)
+    V = sap.variance(G["m"], delta=1e-3)
+    Vgh, grad, _ = sap.variance_GH(G["m"], delta=1e-3, nohess=True)
+    PHI = G["PHI"] + 1e-3 * np.eye(5)
+    assert abs(V / np.linalg.inv(PHI)[0, 0] - 1) < 1e-11 and abs(Vgh / V - 1) < 1e-12
+
+
 def test_model0_unsampled(gpu):
     """misc.py:470: variance() raises AssertionError; variance_GH() does not (it has no such assert)"""
     from bluest_amd.sap import SAP
@@ -409,6 +432,42 @@ def test_simplex_projection_vs_oracle(gpu, oracle):
                 assert abs(float(stats[0]) - gv @ (want - xv)) <= 1e-12 * max(1.0, np.abs(gv).sum())
         finally:
             os.environ.pop("BLUEST_PROJ_MULTI_LAUNCH", None)
+
+
+def test_simplex_projection_hypothesis(gpu, oracle):
+    """property-based: arbitrary vectors incl. exact ties, repeated values, magnitudes up to 1e30 (what
+    lmbda_max = 1e30 of bluest/spg.py:39 produces) and lengths on both sides of the single-workgroup limit -- the GPU projection
+    is feasible, idempotent, satisfies the KKT conditions of the Euclidean projection and equals the oracle's"""
+    from hypothesis import given, settings, strategies as st
+    torch = gpu
+    from bluest_amd.plan import simplex_project
+    dev = torch.device("cuda")
+
+    values = st.one_of(st.floats(-1e3, 1e3, allow_subnormal=False), st.floats(-1e30, 1e30, allow_subnormal=False), st.sampled_from([0.0, 1.0, -1.0, 0.5, 1e-300, 1e30, -1e30]),
+                       st.integers(-3, 3).map(float))
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(values, min_size=1, max_size=300), st.integers(1, 40), st.sampled_from([1.0, 1e-6, 7.5]))
+    def check(vals, repeat, z):
+        v = np.tile(np.array(vals, dtype=np.float64), repeat)            # tiling creates exact ties; lengths up to 12000
+        want = oracle.simplex_projection(v, z=z)
+        check.n += 1
+        p, d, stats = simplex_project(torch.from_numpy(v).to(dev), z=z)
+        p = p.cpu().numpy()
+        scale = max(1.0, np.abs(v).max())
+        assert p.min() >= 0.0 and abs(p.sum() - z) <= 1e-12 * z * max(1.0, len(v) ** 0.5)
+        assert np.abs(p - want).max() <= 1e-12 * z
+        # KKT of min |p - v|^2 on the simplex: p_i = max(v_i - tau, 0) with one threshold tau
+        pos = p > 0
+        tau = (v[pos] - p[pos])
+        assert tau.max() - tau.min() <= 1e-12 * scale and (v[~pos] <= tau.max() + 1e-12 * scale).all()
+        # idempotent
+        p2 = simplex_project(torch.from_numpy(p).to(dev), z=z)[0].cpu().numpy()
+        assert np.abs(p2 - p).max() <= 1e-15 * z * max(1.0, len(v) ** 0.5)
+
+    check.n = 0
+    check()
+    assert check.n >= 100
 
 
 def test_scaled_simplex_projection_vs_oracle(gpu, oracle):

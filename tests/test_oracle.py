@@ -303,3 +303,18 @@ def test_sparse_oracle_and_optimality_certificate(oracle):
         lbs.append(lb)
         assert gap >= -1e-10
     assert max(lbs) <= min(Fs) * (1 + 1e-10)                      # every lower bound is below every attained value
+
+
+def test_singular_phi_fixture(oracle):
+    """rank-deficient Phi with every model touched (two perfectly correlated models): the oracle reproduces what the reference's
+    pinv-based variance_GH returns (misc.py:487,490); the reference's solve-based variance (misc.py:472) returns a different
+    number for the same point -- the fixture records both"""
+    G = golden("singular_phi_known_answer.npz")
+    groups = [G["g_k%d" % k] for k in (1, 2, 3)]
+    sap = oracle.OracleSAP(G["C"], 3, groups, np.ones(8))
+    assert rel_err(np.concatenate(sap.invcovs), G["invcovs"]) < 1e-12
+    assert rel_err(sap.get_phi(G["m"]), G["PHI"]) < 1e-13
+    V, g, _ = sap.variance_GH(G["m"], nohess=True)
+    assert abs(V / float(G["Vgh_pinv"]) - 1) < 1e-9 and rel_err(g, G["grad_pinv"]) < 1e-9
+    assert abs(float(G["eigmin"])) < 1e-14 and int(G["variance_asserted"]) == 0
+    assert abs(float(G["variance_solve"]) / float(G["Vgh_pinv"]) - 1) > 0.5          # the reference disagrees with itself here

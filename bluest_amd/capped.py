@@ -7,7 +7,10 @@ a_i[g] = ES[i][g] * B / cost[g]; the slack entry is the unspent part of the budg
 it).  SPG needs the projection onto that set in the diagonal metric diag(1/s), s = max(x, floor): its dual has one multiplier
 nu_i >= 0 per cap and  p(nu) = P_simplex^s(u - s*A^T nu),  so every dual evaluation is ONE launch of the simplex-projection
 kernel (csrc/spg.hip); the multipliers are found by a semismooth Newton iteration (the dual is piecewise quadratic:
-Hessian A W A^T with W = diag(s_F) - s_F s_F^T / sum s_F on the positive entries F), 2-6 kernel launches per projection.
+Hessian A W A^T with W = diag(s_F) - s_F s_F^T / sum s_F on the positive entries F) with backtracking on the dual value, about
+3 kernel launches per projection.  The spectral step is capped at 1 here (`capped_lmbda_max`): with huge steps all mass sits on
+one entry, the dual Hessian vanishes and Newton degenerates (measured: cap 1 -> 0 fall-backs and 3 launches per iteration,
+cap 10 -> 511 fall-backs and 360 launches per iteration for the same objective).
 The loop around it is the host-driven reference driver (bluest_amd.spg.spg); this option is rarely used and not the hot path.
 """
 import numpy as np
@@ -15,6 +18,10 @@ import torch
 
 from .plan import EVAL_OK, simplex_project
 from .spg import spg
+
+
+DEBUG = False
+TRACE_FALLBACK = False
 
 
 class CappedSimplex(object):
@@ -29,37 +36,86 @@ class CappedSimplex(object):
         A, c, floor = self.A, self.c, self.floor
         lam_g = torch.zeros_like(x) if g is None else lmbda * g
         s = torch.clamp(x, min=floor) if floor > 0 else torch.ones_like(x)
-        nu = self.nu.clone()                                   # warm start: the active caps rarely change between iterations
+        u = x - s * lam_g
         tol = 1.0e-12
-        best = None
-        for it in range(40):
-            p = simplex_project(x, lam_g + A.T @ nu, 1.0, want_d=False, floor=floor)[0]
+        cmax = max(1.0, float(c.abs().max()))
+
+        def dual(nu_):
+            """value of the (concave) dual, the minimiser p(nu) and the dual gradient r = A p - c"""
+            p_ = simplex_project(x, lam_g + A.T @ nu_, 1.0, want_d=False, floor=floor)[0]
             self.launches += 1
-            r = A @ p - c                                      # gradient of the dual
-            viol = torch.maximum(r, -nu)                       # complementarity residual: r <= 0, nu >= 0, nu*r = 0
-            res = float(torch.where(nu > 0, r.abs(), torch.clamp(r, min=0.0)).max() / max(1.0, float(c.abs().max())))
-            if best is None or res < best[0]:
-                best = (res, p, nu.clone())
-            if res <= tol:
-                break
-            act = (nu > 0) | (r > 0)
-            F = p > 0
-            sF = torch.where(F, s, torch.zeros_like(s))
-            Aa = A[act]
-            As = Aa * sF
-            H = As @ Aa.T - torch.outer(As.sum(dim=1), As.sum(dim=1)) / sF.sum()
-            H = H + 1.0e-14 * torch.eye(H.shape[0], dtype=H.dtype, device=H.device) * float(H.diagonal().abs().max() + 1e-300)
-            try:
-                step = torch.linalg.solve(H, r[act])
-            except Exception:
-                step = r[act] / H.diagonal()
-            new = nu.clone()
-            new[act] = torch.clamp(nu[act] + step, min=0.0)
-            if torch.equal(new, nu):
-                break
-            nu = new
+            r_ = A @ p_ - c
+            return float(0.5 * ((p_ - u) ** 2 / s).sum() + nu_ @ r_), p_, r_
+
+        def newton(nu):
+            """semismooth Newton on the dual from nu, backtracking on the dual value; returns (residual, p, nu)"""
+            D, p, r = dual(nu)
+            best = None
+            for it in range(40):
+                res = float(torch.where(nu > 0, r.abs(), torch.clamp(r, min=0.0)).max()) / cmax
+                if DEBUG:
+                    print("    capped projection it %d: res %.3e dual %.6e nu %s nF %d" % (it, res, D, nu.cpu().numpy(), int((p > 0).sum())))
+                if best is None or res < best[0]:
+                    best = (res, p, nu.clone())
+                if res <= tol:
+                    break
+                act = (nu > 0) | (r > 0)
+                F = p > 0
+                sF = torch.where(F, s, torch.zeros_like(s))
+                Aa = A[act]
+                As = Aa * sF
+                H = As @ Aa.T - torch.outer(As.sum(dim=1), As.sum(dim=1)) / sF.sum()
+                H = H + 1.0e-12 * torch.eye(H.shape[0], dtype=H.dtype, device=H.device) * float(H.diagonal().abs().max() + 1e-300)
+                try:
+                    step = torch.linalg.solve(H, r[act])
+                except Exception:
+                    break
+                if not bool(torch.isfinite(step).all()):
+                    break
+                # semismooth Newton is only locally convergent (the Hessian changes with the support of p): backtrack on the dual
+                moved = False
+                t = 1.0
+                for _ in range(30):
+                    new = nu.clone()
+                    new[act] = torch.clamp(nu[act] + t * step, min=0.0)
+                    Dn, pn, rn = dual(new)
+                    if Dn >= D + 1.0e-4 * float(r @ (new - nu)) and np.isfinite(Dn):
+                        moved = not torch.equal(new, nu)
+                        nu, D, p, r = new, Dn, pn, rn
+                        break
+                    t *= 0.5
+                if not moved:
+                    break
+            res_last = float(torch.where(nu > 0, r.abs(), torch.clamp(r, min=0.0)).max()) / cmax
+            if best is None or res_last < best[0]:
+                best = (res_last, p, nu.clone())
+            return best
+
+        # warm start: the multipliers scale with the step length and the active caps rarely change between iterations; an
+        # over-sized start leaves no mass on the capped groups (vanishing dual Hessian), so a failed warm run restarts cold
+        warm = self.nu * float(lmbda) if g is not None else torch.zeros_like(self.nu)
+        best = newton(warm)
+        if best[0] > 1.0e-9 and bool((warm > 0).any()):
+            cold = newton(torch.zeros_like(self.nu))
+            best = cold if cold[0] < best[0] else best
         res, p, nu = best
-        self.nu = nu
+        if res <= 1.0e-9 and bool(torch.isfinite(p).all()):
+            if g is not None and lmbda > 0:
+                self.nu = nu / float(lmbda)
+        else:
+            # degenerate dual (e.g. a huge spectral step puts all mass on one entry: the dual Hessian vanishes and Newton has
+            # nothing to work with): fall back to the furthest feasible point on the segment from x (feasible) to the plain
+            # simplex projection p0 -- not the projection, but a feasible descent step that keeps the iteration going
+            self.fallbacks = getattr(self, "fallbacks", 0) + 1
+            if DEBUG or TRACE_FALLBACK:
+                print("    capped projection FALLBACK: best res %.3e, lmbda %g, nu %s" % (res, lmbda, nu.cpu().numpy()))
+            p0 = simplex_project(x, lam_g, 1.0, want_d=False, floor=floor)[0]
+            self.launches += 1
+            step = p0 - x
+            rate = A @ step
+            room = c - A @ x
+            t = torch.where(rate > 0, torch.clamp(room, min=0.0) / torch.clamp(rate, min=1e-300), torch.ones_like(rate)).min()
+            p = x + torch.clamp(t, max=1.0) * step
         d = p - x
         gd = float(g @ d) if g is not None else 0.0
         return p, d, gd, float(d.abs().max())
@@ -138,7 +194,8 @@ def solve_budget_capped(plan, costs, cap_rows, cap_rhs, budget, s_norm, prm, x0=
     for q in stages:
         st["p"] = q
         res = spg(feval, geval, proj, x, eps=prm["eps"], maxit=max(1, int(prm["maxit"]) // len(stages)), max_fevals=prm["max_fevals"],
-                  verbose=False, lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"], Hlength=prm["linesearch_history_length"],
+                  verbose=False, lmbda_min=prm["lmbda_min"], lmbda_max=min(float(prm["lmbda_max"]), float(prm.get("capped_lmbda_max", 1.0))),
+                  Hlength=prm["linesearch_history_length"],
                   proj_step=proj_step, metric_dot=metric_dot if floor > 0 else None)
         x = res["x"]
         tot_it += res["it"]
@@ -148,7 +205,7 @@ def solve_budget_capped(plan, costs, cap_rows, cap_rhs, budget, s_norm, prm, x0=
     m = scale_h * xs
     info = {"it": tot_it, "count": tot_count, "gpmax": res["gpmax"], "f": res["f"] * st["norm"], "solver_info": res["solver_info"],
             "fevals": st["fevals"], "gevals": st["gevals"], "pruned": int((xs == 0).sum()), "unspent_budget_share": float(x[L]),
-            "projection_launches": cs.launches}
+            "projection_launches": cs.launches, "projection_fallbacks": getattr(cs, "fallbacks", 0)}
     return m, info
 
 

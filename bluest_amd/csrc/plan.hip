@@ -352,36 +352,67 @@ __global__ void k_combine_grad(const double *__restrict__ grad, int64_t grad_str
 // ------------------------------------------------------------------------------------------------------
 // Part 2 host side: the plan
 // ------------------------------------------------------------------------------------------------------
-// The plan's two device buffers come from HIP's stream-ordered memory pool (null stream): a freed arena stays in the pool, so
-// building the next plan does not go back to the driver (hipMalloc / hipFree of 45 MB cost 10-80 ms depending on what else the
-// process holds).  The release threshold keeps the pool from trimming itself at every synchronisation.
-static bool g_pool_usable = true, g_pool_used = false;   // decided by the first allocation, then fixed (free must match alloc)
+// Device memory of plans comes from a small cache owned by the library: a released block is kept (up to CACHE_CAP bytes) and
+// handed to the next request of a similar size.  Measured alternatives: hipMalloc / hipFree of the 45 MB arena cost 10-80 ms
+// depending on what else the process holds; HIP's stream-ordered pool (hipMallocAsync) was fast to allocate from but every
+// second set-up stalled ~75 ms inside the next null-stream synchronisation while the runtime trimmed and re-mapped the pool.
+// Blocks are only recycled after a device synchronisation (plan_release), so no kernel of the previous owner is still running.
+#include <map>
+#include <unordered_map>
+static std::mutex g_cache_mutex;
+static std::multimap<size_t, void *> g_cache;              // free blocks by size
+static std::unordered_map<void *, size_t> g_block_size;    // every block handed out or cached
+static size_t g_cache_bytes = 0;
+static const size_t CACHE_CAP = 3ull << 30;
+
 static hipError_t pool_alloc(void **p, size_t bytes)
 {
-    static bool configured = false;
-    if (!configured) {
-        int dev = 0;
-        hipMemPool_t pool;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-            uint64_t keep = 1ull << 32;     // up to 4 GB of freed plan memory stays cached
-            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    const size_t want = (std::max<size_t>(bytes, 1) + 0x3ffff) & ~(size_t)0x3ffff;      // 256 KiB granules
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        auto it = g_cache.lower_bound(want);
+        if (it != g_cache.end() && it->first <= 2 * want + (1u << 20)) {
+            *p = it->second;
+            g_cache_bytes -= it->first;
+            g_cache.erase(it);
+            return hipSuccess;
         }
-        (void)hipGetLastError();
-        configured = true;
     }
-    if (g_pool_usable) {
-        hipError_t e = hipMallocAsync(p, bytes, 0);
-        if (e == hipSuccess) e = hipStreamSynchronize(0);
-        if (e == hipSuccess) { g_pool_used = true; return e; }
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) {       // out of memory: give the cached blocks back and try once more
         (void)hipGetLastError();
-        if (g_pool_used) return e;          // the pool works but this request failed (out of memory): report it
-        g_pool_usable = false;              // no stream-ordered allocator on this device / driver: plain hipMalloc from now on
+        std::vector<void *> drop;
+        {
+            std::lock_guard<std::mutex> lock(g_cache_mutex);
+            for (auto &kv : g_cache) { drop.push_back(kv.second); g_block_size.erase(kv.second); }
+            g_cache.clear();
+            g_cache_bytes = 0;
+        }
+        for (void *q : drop) (void)hipFree(q);
+        e = hipMalloc(p, want);
     }
-    return hipMalloc(p, bytes);
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        g_block_size[*p] = want;
+    }
+    return e;
 }
 static hipError_t pool_free(void *p)
 {
-    return g_pool_usable ? hipFreeAsync(p, 0) : hipFree(p);
+    size_t sz = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        auto it = g_block_size.find(p);
+        if (it == g_block_size.end()) return hipFree(p);
+        sz = it->second;
+        if (g_cache_bytes + sz <= CACHE_CAP) {
+            g_cache.emplace(sz, p);
+            g_cache_bytes += sz;
+            return hipSuccess;
+        }
+        g_block_size.erase(it);
+    }
+    return hipFree(p);
 }
 
 static void plan_free_device(bluest_plan_s *p)
@@ -389,6 +420,11 @@ static void plan_free_device(bluest_plan_s *p)
     if (p->d_arena) (void)pool_free(p->d_arena);
     if (p->d_scratch) (void)pool_free(p->d_scratch);
     p->d_arena = p->d_scratch = nullptr;
+    for (auto &od : p->outs) {
+        if (od.d_invcov) (void)pool_free(od.d_invcov);
+        if (od.d_groups && od.owns_groups) (void)pool_free(od.d_groups);
+        od.d_invcov = nullptr; od.d_groups = nullptr;
+    }
 }
 
 extern "C" int bluest_plan_create(bluest_plan_t *plan, int n_models, int64_t L_global)
@@ -415,6 +451,7 @@ static std::vector<bluest_plan_s *> g_deferred;
 
 static void plan_release(bluest_plan_s *p)
 {
+    (void)hipDeviceSynchronize();       // the blocks go back to the cache: nothing of this plan may still be running
     plan_free_device(p);
     delete p;
 }
@@ -484,6 +521,31 @@ static int plan_add_common(bluest_plan_t plan, int K, const int64_t *sizes, cons
     return BLUEST_OK;
 }
 
+// device copies of one output's inputs: the group list (shared with output 0 when identical) and room for its inverses
+static int output_to_device(bluest_plan_t plan, OutputDesc &od)
+{
+    int64_t ni = 0, ng = 0;
+    for (int k = 1; k <= od.K; k++) { ni += od.sizes[k - 1] * k * k; ng += od.sizes[k - 1] * k; }
+    od.n_inv = ni;
+    HIP_TRY(pool_alloc((void **)&od.d_invcov, (size_t)std::max<int64_t>(ni, 1) * sizeof(double)));
+    if (!plan->outs.empty() && plan->outs[0].groups == od.groups) {
+        od.d_groups = plan->outs[0].d_groups;
+        od.owns_groups = false;
+    } else {
+        HIP_TRY(pool_alloc((void **)&od.d_groups, (size_t)std::max<int64_t>(ng, 1) * sizeof(int64_t)));
+        od.owns_groups = true;
+        HIP_TRY(hipMemcpy(od.d_groups, od.groups.data(), (size_t)ng * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    return BLUEST_OK;
+}
+
+static void output_release(OutputDesc &od)
+{
+    if (od.d_invcov) (void)pool_free(od.d_invcov);
+    if (od.d_groups && od.owns_groups) (void)pool_free(od.d_groups);
+    od.d_invcov = nullptr; od.d_groups = nullptr;
+}
+
 extern "C" int bluest_plan_add_output(bluest_plan_t plan, int K, const int64_t *sizes, const int64_t *groups,
                                       const double *invcovs, const int64_t *mapping)
 {
@@ -491,9 +553,9 @@ extern "C" int bluest_plan_add_output(bluest_plan_t plan, int K, const int64_t *
     int rc = plan_add_common(plan, K, sizes, groups, mapping, od);
     if (rc) return rc;
     if (!invcovs) return fail(BLUEST_ERR_ARG, "invcovs is NULL");
-    int64_t ni = 0;
-    for (int k = 1; k <= K; k++) ni += sizes[k - 1] * k * k;
-    od.invcovs.assign(invcovs, invcovs + ni);
+    if ((rc = output_to_device(plan, od))) { output_release(od); return rc; }
+    hipError_t e = hipMemcpy(od.d_invcov, invcovs, (size_t)od.n_inv * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { output_release(od); HIP_TRY(e); }
     plan->outs.push_back(std::move(od));
     return BLUEST_OK;
 }
@@ -508,42 +570,136 @@ extern "C" int bluest_plan_add_output_cov(bluest_plan_t plan, const double *C, i
     timer.lap("copy groups / mapping");
     if (!C) return fail(BLUEST_ERR_ARG, "C is NULL");
     const int N = plan->N;
-    int64_t ni = 0, ng = 0;
-    for (int k = 1; k <= K; k++) { ni += sizes[k - 1] * k * k; ng += sizes[k - 1] * k; }
-    od.invcovs.resize(ni);
-    // scratch = [C | inverses | groups], kept for the next output (freed by finalize)
-    const size_t offC = 0, offI = ((size_t)N * N * sizeof(double) + 255) / 256 * 256;
-    const size_t offG = offI + ((size_t)ni * sizeof(double) + 255) / 256 * 256;
-    const size_t need = offG + (size_t)ng * sizeof(int64_t);
+    if ((rc = output_to_device(plan, od))) { output_release(od); return rc; }
+    timer.lap("device buffers + groups upload");
+    // the covariance goes through a small scratch that is reused across outputs (freed by finalize)
+    const size_t need = (size_t)N * N * sizeof(double);
     if (need > plan->scratch_bytes) {
         if (plan->d_scratch) (void)pool_free(plan->d_scratch);
         plan->d_scratch = nullptr; plan->scratch_bytes = 0;
-        HIP_TRY(pool_alloc(&plan->d_scratch, need));
+        hipError_t ea = pool_alloc(&plan->d_scratch, need);
+        if (ea != hipSuccess) { output_release(od); HIP_TRY(ea); }
         plan->scratch_bytes = need;
-        timer.lap("scratch allocation");
     }
-    double *dC = reinterpret_cast<double *>((char *)plan->d_scratch + offC), *dic = reinterpret_cast<double *>((char *)plan->d_scratch + offI);
-    int64_t *dg = reinterpret_cast<int64_t *>((char *)plan->d_scratch + offG);
-    hipError_t e = hipMemcpy(dC, C, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice);
+    double *dC = reinterpret_cast<double *>(plan->d_scratch);
+    hipError_t e = hipMemcpy(dC, C, need, hipMemcpyHostToDevice);     // synchronous: the scratch may be rewritten by the next call
     timer.lap("H2D covariance");
-    if (e == hipSuccess) e = hipMemcpy(dg, groups, (size_t)ng * sizeof(int64_t), hipMemcpyHostToDevice);
-    timer.lap("H2D groups");
-    rc = BLUEST_OK;
     if (e == hipSuccess) {
         int64_t go = 0, io = 0;
         for (int k = 1; k <= K && rc == BLUEST_OK; k++) {
             const int64_t Lk = sizes[k - 1];
-            if (Lk > 0) rc = launch_group_pinv(dC, N, k, Lk, dg + go, dic + io, 0);
+            if (Lk > 0) rc = launch_group_pinv(dC, N, k, Lk, od.d_groups + go, od.d_invcov + io, 0);
             go += Lk * k; io += Lk * k * k;
         }
-        if (rc == BLUEST_OK) e = hipMemcpy(od.invcovs.data(), dic, (size_t)ni * sizeof(double), hipMemcpyDeviceToHost);
+        // the next output's covariance upload overwrites dC: wait for the kernels (they take ~0.1 ms; the inverses stay on the device)
+        if (rc == BLUEST_OK) e = hipStreamSynchronize(0);
+        if (rc == BLUEST_OK && e == hipSuccess && invcovs_out)
+            e = hipMemcpy(invcovs_out, od.d_invcov, (size_t)od.n_inv * sizeof(double), hipMemcpyDeviceToHost);
     }
-    timer.lap("device pinv round trip (H2D, kernels, D2H)");
-    if (rc) return rc;
-    HIP_TRY(e);
-    if (invcovs_out) memcpy(invcovs_out, od.invcovs.data(), (size_t)ni * sizeof(double));
+    timer.lap("pseudo-inverse kernels");
+    if (rc) { output_release(od); return rc; }
+    if (e != hipSuccess) { output_release(od); HIP_TRY(e); }
     plan->outs.push_back(std::move(od));
     return BLUEST_OK;
+}
+
+// reference-layout inverses of output o back to the host (lazily: the plan itself never needs them there)
+extern "C" int bluest_plan_get_invcovs(bluest_plan_t plan, int output, double *invcovs_out)
+{
+    if (!plan || !invcovs_out) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (output < 0 || output >= (int)plan->outs.size()) return fail(BLUEST_ERR_ARG, "output %d out of range", output);
+    const OutputDesc &od = plan->outs[output];
+    HIP_TRY(hipMemcpy(invcovs_out, od.d_invcov, (size_t)od.n_inv * sizeof(double), hipMemcpyDeviceToHost));
+    return BLUEST_OK;
+}
+
+// inverses of SOME groups of output o (local indices, any order): gathered on the device, one small copy back.
+// out receives the k x k blocks one after the other (k = size of each requested group).
+__global__ void k_gather_blocks(const double *__restrict__ ic, const int64_t *__restrict__ src_off, const int64_t *__restrict__ dst_off,
+                                const int32_t *__restrict__ kk, int64_t n, double *__restrict__ out)
+{
+    const int64_t i = blockIdx.x;
+    if (i >= n) return;
+    const int k2 = kk[i] * kk[i];
+    for (int t = threadIdx.x; t < k2; t += blockDim.x) out[dst_off[i] + t] = ic[src_off[i] + t];
+}
+
+extern "C" int bluest_plan_gather_invcovs(bluest_plan_t plan, int output, const int64_t *local_idx, int64_t n, double *out)
+{
+    if (!plan || !local_idx || !out) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (output < 0 || output >= (int)plan->outs.size()) return fail(BLUEST_ERR_ARG, "output %d out of range", output);
+    if (n <= 0) return BLUEST_OK;
+    const OutputDesc &od = plan->outs[output];
+    std::vector<int64_t> cum(od.K + 1, 0), ioff(od.K + 1, 0);
+    for (int k = 1; k <= od.K; k++) { cum[k] = cum[k - 1] + od.sizes[k - 1]; ioff[k] = ioff[k - 1] + od.sizes[k - 1] * k * k; }
+    std::vector<int64_t> src(n), dst(n);
+    std::vector<int32_t> kk(n);
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t li = local_idx[i];
+        if (li < 0 || li >= od.L_o) return fail(BLUEST_ERR_ARG, "group index %lld out of range", (long long)li);
+        const int k = (int)(std::upper_bound(cum.begin(), cum.end(), li) - cum.begin());
+        src[i] = ioff[k - 1] + (li - cum[k - 1]) * k * k;
+        dst[i] = total;
+        kk[i] = k;
+        total += (int64_t)k * k;
+    }
+    void *d = nullptr;
+    const size_t b_off = (size_t)n * sizeof(int64_t), bytes = 2 * b_off + ((size_t)n * sizeof(int32_t) + 7) / 8 * 8 + (size_t)total * sizeof(double);
+    HIP_TRY(pool_alloc(&d, bytes));
+    int64_t *d_src = (int64_t *)d, *d_dst = d_src + n;
+    int32_t *d_k = (int32_t *)(d_dst + n);
+    double *d_out = (double *)((char *)d + 2 * b_off + ((size_t)n * sizeof(int32_t) + 7) / 8 * 8);
+    hipError_t e = hipMemcpy(d_src, src.data(), b_off, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_dst, dst.data(), b_off, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_k, kk.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_gather_blocks, dim3((unsigned)n), dim3(64), 0, 0, od.d_invcov, d_src, d_dst, d_k, n, d_out);
+        e = hipMemcpy(out, d_out, (size_t)total * sizeof(double), hipMemcpyDeviceToHost);
+    }
+    (void)pool_free(d);
+    HIP_TRY(e);
+    return BLUEST_OK;
+}
+
+// ---- device-side construction of the two streaming layouts ----------------------------------------------
+// The host only decides WHERE things go (a counting sort of the group list by destination row gives every packed-symmetric
+// entry its slot in the CSR; tiles are arithmetic); the VALUES never leave the device: they are scattered from the
+// reference-layout inverses (pinv output) by the two kernels below, for one (output, group size) at a time.
+__global__ __launch_bounds__(256) void k_fill_csr(const double *__restrict__ ic, int k, int64_t Lk, const int32_t *__restrict__ perm,
+                                                  double *__restrict__ vals)
+{
+    const int ne = k * (k + 1) / 2;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Lk * ne) return;
+    const int64_t gi = t / ne;
+    int e = (int)(t - gi * ne), j = 0;
+    while (e >= k - j) { e -= k - j; j++; }          // e-th entry of the packed upper triangle: row j, column l = j + e
+    const int l = j + e;
+    const double *b = ic + gi * k * k;
+    vals[perm[t]] = (j == l) ? b[j * k + j] : 0.5 * (b[j * k + l] + b[l * k + j]);
+}
+
+__global__ __launch_bounds__(256) void k_fill_tiles(const double *__restrict__ ic, const int64_t *__restrict__ groups, int k, int64_t Lk,
+                                                    double *__restrict__ tvals, uint8_t *__restrict__ tidx)
+{
+    const int ne = k * (k + 1) / 2;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Lk * (ne + k)) return;
+    const int64_t gi = t / (ne + k);
+    const int r = (int)(t - gi * (ne + k));
+    const int64_t tile = gi >> 6;
+    const int lane = (int)(gi & 63);
+    if (r < ne) {
+        int e = r, j = 0;
+        while (e >= k - j) { e -= k - j; j++; }
+        const int l = j + e;
+        const double *b = ic + gi * k * k;
+        tvals[tile * ne * 64 + (int64_t)r * 64 + lane] = (j == l) ? b[j * k + j] : 0.5 * (b[j * k + l] + b[l * k + j]);
+    } else {
+        const int j = r - ne;
+        tidx[tile * k * 64 + (int64_t)j * 64 + lane] = (uint8_t)groups[gi * k + j];
+    }
 }
 
 // the plan's device arrays live in one arena: reserve() collects sizes, then every array is copied to its slot
@@ -589,62 +745,69 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     auto tri = [N](int a, int b) { return a * N - a * (a - 1) / 2 + (b - a); };
     PhaseTimer timer("plan_finalize");
 
-    // ---- Phi pass: destination-major symmetric CSR ------------------------------------------------
-    // count entries per (output,row); pick the chunk size so that no row needs more than 64 chunks
-    std::vector<std::vector<int64_t>> counts(n_out, std::vector<int64_t>(nsym, 0));
-    int64_t max_row = 0;
-    // parallel counting sort: slice s of S owns a contiguous range of the output's groups; it counts its entries per row,
-    // the per-slice counts are prefix-summed into start offsets, then every slice writes its own entries -- rows keep their
-    // entries in group order whatever S is, so the layout (and every summation order on the GPU) is independent of threading
-    const int S = std::max(1, host_threads() / n_out);      // slices per output
-    std::vector<std::vector<int64_t>> slice_cnt((size_t)n_out * S, std::vector<int64_t>(nsym, 0));
-    auto for_groups_of_slice = [&](int o, int slice, auto &&body) {
-        const OutputDesc &od = plan->outs[o];
-        const int64_t lo = od.L_o * slice / S, hi = od.L_o * (slice + 1) / S;
-        int64_t go = 0, io = 0, l0 = 0;
-        for (int k = 1; k <= od.K; k++) {
-            const int64_t Lk = od.sizes[k - 1];
-            for (int64_t i = std::max<int64_t>(lo - l0, 0); i < std::min<int64_t>(hi - l0, Lk); i++)
-                body(k, od.groups.data() + go + i * k, od.invcovs.data() + io + i * k * k, l0 + i);
-            go += Lk * k; io += Lk * k * k; l0 += Lk;
-        }
-    };
-    parallel_items(n_out * S, [&](int item) {
-        std::vector<int64_t> &cnt = slice_cnt[item];
-        for_groups_of_slice(item / S, item % S, [&](int k, const int64_t *g, const double *, int64_t) {
-            for (int j = 0; j < k; j++)
-                for (int l = j; l < k; l++) cnt[tri((int)std::min(g[j], g[l]), (int)std::max(g[j], g[l]))]++;
-        });
-    });
-    for (int o = 0; o < n_out; o++)
-        for (int r = 0; r < nsym; r++) {
-            int64_t run = 0;
-            for (int sl = 0; sl < S; sl++) { const int64_t c = slice_cnt[(size_t)o * S + sl][r]; slice_cnt[(size_t)o * S + sl][r] = run; run += c; }
-            counts[o][r] = run;      // slice_cnt now holds each slice's start offset inside the row
-        }
-    for (int o = 0; o < n_out; o++)
-        for (int r = 0; r < nsym; r++) max_row = std::max(max_row, counts[o][r]);
-    timer.lap("count");
-    int iters = 1;
-    while ((max_row + 256LL * iters - 1) / (256LL * iters) > 64 && iters < 1024) iters *= 2;
-    const int64_t CH = 256LL * iters;
-    plan->iters = iters;
     plan->nsym = nsym;
     plan->shared = true;
     for (int o = 1; o < n_out; o++) {
         const OutputDesc &x = plan->outs[0], &y = plan->outs[o];
         if (x.K != y.K || x.sizes != y.sizes || x.groups != y.groups || x.mapping != y.mapping) { plan->shared = false; break; }
     }
+    // distinct STRUCTURES: with identical group lists and mappings every output has the same rows, chunks and slots, so the
+    // counting sort below runs once and the other outputs reuse its result shifted by their chunk base
+    const int n_struct = plan->shared ? 1 : n_out;
+
+    // ---- Phi pass: destination-major symmetric CSR, positions only ----------------------------------
+    // parallel counting sort: slice s of S owns a contiguous range of the output's groups; it counts its entries per row,
+    // the per-slice counts are prefix-summed into start offsets, then every slice writes the SLOT of its own entries -- rows
+    // keep their entries in group order whatever S is, so the layout (and every summation order on the GPU) is independent
+    // of threading
+    std::vector<std::vector<int64_t>> counts(n_struct, std::vector<int64_t>(nsym, 0));
+    int64_t max_row = 0;
+    const int S = std::max(1, host_threads() / n_struct);      // slices per structure
+    std::vector<std::vector<int64_t>> slice_cnt((size_t)n_struct * S, std::vector<int64_t>(nsym, 0));
+    auto for_groups_of_slice = [&](int o, int slice, auto &&body) {
+        const OutputDesc &od = plan->outs[o];
+        const int64_t lo = od.L_o * slice / S, hi = od.L_o * (slice + 1) / S;
+        int64_t go = 0, eo = 0, l0 = 0;
+        for (int k = 1; k <= od.K; k++) {
+            const int64_t Lk = od.sizes[k - 1];
+            const int ne = k * (k + 1) / 2;
+            for (int64_t i = std::max<int64_t>(lo - l0, 0); i < std::min<int64_t>(hi - l0, Lk); i++)
+                body(k, od.groups.data() + go + i * k, eo + i * ne, l0 + i);
+            go += Lk * k; eo += Lk * ne; l0 += Lk;
+        }
+    };
+    parallel_items(n_struct * S, [&](int item) {
+        std::vector<int64_t> &cnt = slice_cnt[item];
+        for_groups_of_slice(item / S, item % S, [&](int k, const int64_t *g, int64_t, int64_t) {
+            for (int j = 0; j < k; j++)
+                for (int l = j; l < k; l++) cnt[tri((int)std::min(g[j], g[l]), (int)std::max(g[j], g[l]))]++;
+        });
+    });
+    for (int o = 0; o < n_struct; o++)
+        for (int r = 0; r < nsym; r++) {
+            int64_t run = 0;
+            for (int sl = 0; sl < S; sl++) { const int64_t c = slice_cnt[(size_t)o * S + sl][r]; slice_cnt[(size_t)o * S + sl][r] = run; run += c; }
+            counts[o][r] = run;      // slice_cnt now holds each slice's start offset inside the row
+            max_row = std::max(max_row, run);
+        }
+    timer.lap("count");
+    int iters = 1;
+    while ((max_row + 256LL * iters - 1) / (256LL * iters) > 64 && iters < 1024) iters *= 2;
+    const int64_t CH = 256LL * iters;
+    plan->iters = iters;
 
     std::vector<RowDesc> rows((size_t)n_out * nsym);
     std::vector<int32_t> out_row_begin(n_out + 1);
+    std::vector<int64_t> out_chunk_begin(n_out + 1, 0);
     int64_t n_chunks = 0;
     for (int o = 0; o < n_out; o++) {
         out_row_begin[o] = o * nsym;
+        out_chunk_begin[o] = n_chunks;
+        const std::vector<int64_t> &cnt = counts[plan->shared ? 0 : o];
         for (int a = 0; a < N; a++)
             for (int b = a; b < N; b++) {
                 RowDesc &rd = rows[(size_t)o * nsym + tri(a, b)];
-                const int64_t nc = (counts[o][tri(a, b)] + CH - 1) / CH;
+                const int64_t nc = (cnt[tri(a, b)] + CH - 1) / CH;
                 rd.first_chunk = (int32_t)n_chunks;
                 rd.n_chunks = (int32_t)nc;
                 rd.out = (int16_t)o; rd.a = (int16_t)a; rd.b = (int16_t)b; rd.pad = 0;
@@ -652,44 +815,56 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
             }
     }
     out_row_begin[n_out] = n_out * nsym;
+    out_chunk_begin[n_out] = n_chunks;
     if (n_chunks <= 0 || n_chunks * CH > 0x7fffffff0LL) return fail(BLUEST_ERR_ARG, "problem too large for one plan (%lld chunks)", (long long)n_chunks);
-    std::vector<double> vals((size_t)(n_chunks * CH), 0.0);
-    std::vector<int32_t> cols((size_t)(n_chunks * CH), 0);
-    {
-        parallel_items(n_out * S, [&](int item) {
-            const int o = item / S;
-            std::vector<int64_t> &next = slice_cnt[item];     // start offsets, advanced as the slice writes
-            const OutputDesc &od = plan->outs[o];
-            for_groups_of_slice(o, item % S, [&](int k, const int64_t *g, const double *ic, int64_t li) {
-                for (int j = 0; j < k; j++)
-                    for (int l = j; l < k; l++) {
-                        const int rr = tri((int)std::min(g[j], g[l]), (int)std::max(g[j], g[l]));
-                        const int64_t pos = (int64_t)rows[(size_t)o * nsym + rr].first_chunk * CH + next[rr]++;
-                        vals[pos] = (j == l) ? ic[j * k + j] : 0.5 * (ic[j * k + l] + ic[l * k + j]);
-                        cols[pos] = (int32_t)od.mapping[li];
-                    }
-            });
-        });
-        // padding: value 0, column = the row's first column (keeps max|m| per row exact, adds nothing)
-        parallel_items(n_out, [&](int o) {
-            for (int rr = 0; rr < nsym; rr++) {
-                const size_t r = (size_t)o * nsym + rr;
-                const int64_t beg = (int64_t)rows[r].first_chunk * CH, end = beg + (int64_t)rows[r].n_chunks * CH;
-                for (int64_t pos = beg + counts[o][rr]; pos < end; pos++) cols[pos] = cols[beg];
-            }
-        });
+    // slot of every packed-symmetric entry (reference order: group-major, upper triangle row by row) and the column
+    // (= global index of the group) stored at that slot; per structure, relative to the structure's first chunk
+    std::vector<int64_t> struct_entries(n_struct + 1, 0), struct_slots(n_struct + 1, 0);
+    for (int o = 0; o < n_struct; o++) {
+        int64_t ne_all = 0;
+        for (int k = 1; k <= plan->outs[o].K; k++) ne_all += plan->outs[o].sizes[k - 1] * (k * (k + 1) / 2);
+        struct_entries[o + 1] = struct_entries[o] + ne_all;
+        struct_slots[o + 1] = struct_slots[o] + (out_chunk_begin[o + 1] - out_chunk_begin[o]) * CH;
     }
-    timer.lap("CSR alloc + fill");
-    // ---- gradient pass: group-major tiles ------------------------------------------------------------
+    if (struct_slots[n_struct] > 0x7fffffffLL) return fail(BLUEST_ERR_ARG, "problem too large for one plan (%lld slots per structure set)", (long long)struct_slots[n_struct]);
+    std::vector<int32_t> perm((size_t)struct_entries[n_struct]);
+    std::vector<int32_t> cols((size_t)struct_slots[n_struct], 0);
+    parallel_items(n_struct * S, [&](int item) {
+        const int o = item / S;
+        std::vector<int64_t> &next = slice_cnt[item];     // start offsets, advanced as the slice writes
+        const OutputDesc &od = plan->outs[o];
+        const int64_t chunk0 = out_chunk_begin[o];
+        int32_t *pm = perm.data() + struct_entries[o];
+        int32_t *cl = cols.data() + struct_slots[o];
+        for_groups_of_slice(o, item % S, [&](int k, const int64_t *g, int64_t e0, int64_t li) {
+            int e = 0;
+            for (int j = 0; j < k; j++)
+                for (int l = j; l < k; l++, e++) {
+                    const int rr = tri((int)std::min(g[j], g[l]), (int)std::max(g[j], g[l]));
+                    const int64_t pos = ((int64_t)rows[(size_t)o * nsym + rr].first_chunk - chunk0) * CH + next[rr]++;
+                    pm[e0 + e] = (int32_t)pos;
+                    cl[pos] = (int32_t)od.mapping[li];
+                }
+        });
+    });
+    // padding: value 0 (the device buffer is cleared), column = the row's first column (keeps max|m| per row exact, adds nothing)
+    parallel_items(n_struct, [&](int o) {
+        int32_t *cl = cols.data() + struct_slots[o];
+        for (int rr = 0; rr < nsym; rr++) {
+            const RowDesc &rd = rows[(size_t)o * nsym + rr];
+            const int64_t beg = ((int64_t)rd.first_chunk - out_chunk_begin[o]) * CH, end = beg + (int64_t)rd.n_chunks * CH;
+            for (int64_t pos = beg + counts[o][rr]; pos < end; pos++) cl[pos] = cl[beg];
+        }
+    });
+    timer.lap("CSR slots + columns");
+    // ---- gradient pass: group-major tiles (descriptors only; values are scattered on the device) ----------------
     {
         int kmax_all = 0;
         for (const auto &od : plan->outs) kmax_all = std::max(kmax_all, od.K);
         plan->fused_tpb = fused_tpb(pick_nt(N), pick_ku(kmax_all));
     }
-    // phase 1 (serial, cheap): descriptors and offsets; phase 2 (one thread per output): fill values and indices
     std::vector<TileDesc> tiles;
-    std::vector<int64_t> tile_t0;            // index of the tile's first group inside its size bucket
-    std::vector<size_t> tile_begin(n_out + 1, 0);
+    std::vector<std::vector<int64_t>> bucket_val(n_out), bucket_idx(n_out);    // first tile of size bucket k: offsets
     size_t n_tvals = 0, n_tidx = 0;
     plan->grad_off.assign(n_out, 0);
     int64_t grad_len = 0;
@@ -697,15 +872,16 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
         const OutputDesc &od = plan->outs[o];
         plan->grad_off[o] = grad_len;
         const size_t first_tile_of_output = tiles.size();
-        tile_begin[o] = first_tile_of_output;
+        bucket_val[o].assign(od.K + 1, 0); bucket_idx[o].assign(od.K + 1, 0);
         int64_t li = 0;
         for (int k = 1; k <= od.K; k++) {
             const int64_t Lk = od.sizes[k - 1];
             const int ne = k * (k + 1) / 2;
+            n_tidx = (n_tidx + 15) / 16 * 16;
+            bucket_val[o][k] = (int64_t)n_tvals; bucket_idx[o][k] = (int64_t)n_tidx;
             for (int64_t t0 = 0; t0 < Lk; t0 += 64) {
                 TileDesc td;
                 td.val_off = (int64_t)n_tvals;
-                n_tidx = (n_tidx + 15) / 16 * 16;
                 td.idx_off = (int64_t)n_tidx;
                 td.grad_off = grad_len + li + t0;
                 td.n_valid = (int32_t)std::min<int64_t>(64, Lk - t0);
@@ -713,102 +889,100 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
                 n_tvals += (size_t)ne * 64;
                 n_tidx += (size_t)k * 64;
                 tiles.push_back(td);
-                tile_t0.push_back(t0);
             }
             li += Lk;
         }
         // first tile of the output is flagged; the list is padded to a multiple of FUSED_TPB tiles per output with empty
         // tiles so that a workgroup of the fused solve+gradient kernel never straddles two outputs
         if (tiles.size() > first_tile_of_output) tiles[first_tile_of_output].n_valid |= (1 << 30);
-        tile_begin[o + 1] = tiles.size();       // real tiles of this output end here (padding follows)
         while ((tiles.size() - first_tile_of_output) % plan->fused_tpb || tiles.size() == first_tile_of_output) {
             TileDesc td;
             td.val_off = 0; td.idx_off = 0; td.grad_off = 0; td.n_valid = (tiles.size() == first_tile_of_output) ? (1 << 30) : 0;
             td.k = 1; td.out = (int16_t)o;
             tiles.push_back(td);
-            tile_t0.push_back(0);
         }
         const int bpo = (int)((tiles.size() - first_tile_of_output) / plan->fused_tpb);
         if (o == 0) plan->fused_bpo = bpo;
         else if (plan->fused_bpo != bpo) plan->fused_bpo = 0;
         grad_len += od.L_o;
     }
-    std::vector<double> tvals(n_tvals, 0.0);
-    std::vector<uint8_t> tidx(n_tidx, 0);
-    {
-        std::vector<std::vector<int64_t>> gofs(n_out), iofs(n_out);   // start of size bucket k in groups / invcovs
-        for (int o = 0; o < n_out; o++) {
-            const OutputDesc &od = plan->outs[o];
-            gofs[o].assign(od.K + 2, 0); iofs[o].assign(od.K + 2, 0);
-            for (int k = 1; k <= od.K; k++) { gofs[o][k + 1] = gofs[o][k] + od.sizes[k - 1] * k; iofs[o][k + 1] = iofs[o][k] + od.sizes[k - 1] * k * k; }
-        }
-        const int n_slices = host_threads() * 4;
-        const size_t nt_all = tiles.size();
-        parallel_items(n_slices, [&](int slice) {
-            for (size_t t = (size_t)slice * nt_all / n_slices; t < (size_t)(slice + 1) * nt_all / n_slices; t++) {
-                const TileDesc &td = tiles[t];
-                const int nv = td.n_valid & 0xffff;
-                if (nv == 0) continue;
-                const OutputDesc &od = plan->outs[td.out];
-                const int k = td.k;
-                for (int lane = 0; lane < nv; lane++) {
-                    const int64_t i = tile_t0[t] + lane;
-                    const int64_t *g = od.groups.data() + gofs[td.out][k] + i * k;
-                    const double *ic = od.invcovs.data() + iofs[td.out][k] + i * k * k;
-                    int e = 0;
-                    for (int j = 0; j < k; j++) {
-                        tidx[td.idx_off + j * 64 + lane] = (uint8_t)g[j];
-                        for (int l = j; l < k; l++, e++)
-                            tvals[td.val_off + e * 64 + lane] = (j == l) ? ic[j * k + j] : 0.5 * (ic[j * k + l] + ic[l * k + j]);
-                    }
-                }
-            }
-        });
-    }
+    n_tvals = std::max<size_t>(n_tvals, 64);        // the empty padding tiles read (and ignore) one tile's worth at offset 0
+    n_tidx = std::max<size_t>(n_tidx, 64);
     plan->grad_len = grad_len;
 
     // ---- inverse maps for combine_grad ------------------------------------------------------------
     std::vector<int32_t> invmap((size_t)n_out * plan->L, -1);
-    for (int o = 0; o < n_out; o++)
+    parallel_items(n_out, [&](int o) {
         for (int64_t li = 0; li < plan->outs[o].L_o; li++) invmap[(size_t)o * plan->L + plan->outs[o].mapping[li]] = (int32_t)li;
+    });
 
     plan->n_chunks = n_chunks;
     plan->n_rows = (int64_t)rows.size();
     plan->n_tiles = (int64_t)tiles.size();
     plan->max_cand = max_candidates;
     plan->phi_bytes = n_chunks * CH * 8 + (plan->shared ? n_chunks / n_out : n_chunks) * CH * 4 + n_chunks * 16;
-    plan->grad_bytes = (int64_t)tvals.size() * 8 + (int64_t)tidx.size() + grad_len * 8;
+    plan->grad_bytes = (int64_t)n_tvals * 8 + (int64_t)n_tidx + grad_len * 8;
 
-    timer.lap("tiles + inverse maps");
+    timer.lap("tile descriptors + inverse maps");
     int rc;
     if (plan->d_scratch) { (void)pool_free(plan->d_scratch); plan->d_scratch = nullptr; plan->scratch_bytes = 0; }
     Arena arena;
-    const size_t o_vals = arena.reserve(vals.size() * sizeof(double)), o_cols = arena.reserve(cols.size() * sizeof(int32_t));
+    const size_t o_vals = arena.reserve((size_t)n_chunks * CH * sizeof(double)), o_cols = arena.reserve((size_t)n_chunks * CH * sizeof(int32_t));
     const size_t o_rows = arena.reserve(rows.size() * sizeof(RowDesc)), o_orb = arena.reserve(out_row_begin.size() * sizeof(int32_t));
-    const size_t o_tiles = arena.reserve(tiles.size() * sizeof(TileDesc)), o_tvals = arena.reserve(tvals.size() * sizeof(double));
-    const size_t o_tidx = arena.reserve(tidx.size()), o_invmap = arena.reserve(invmap.size() * sizeof(int32_t));
+    const size_t o_tiles = arena.reserve(tiles.size() * sizeof(TileDesc)), o_tvals = arena.reserve(n_tvals * sizeof(double));
+    const size_t o_tidx = arena.reserve(n_tidx), o_invmap = arena.reserve(invmap.size() * sizeof(int32_t));
     const size_t o_goff = arena.reserve(plan->grad_off.size() * sizeof(int64_t));
+    const size_t o_perm = arena.reserve(perm.size() * sizeof(int32_t));
     const size_t o_partial = arena.reserve((size_t)max_candidates * n_chunks * sizeof(double2));
     const size_t o_v = arena.reserve((size_t)max_candidates * n_out * N * sizeof(double));
     const size_t o_status = arena.reserve((size_t)max_candidates * n_out * sizeof(int32_t));
     HIP_TRY(pool_alloc(&plan->d_arena, arena.bytes));
     arena.base = (char *)plan->d_arena;
-    if ((rc = upload(arena, o_vals, &plan->d_vals, vals))) return rc;
-    if ((rc = upload(arena, o_cols, &plan->d_cols, cols))) return rc;
+    plan->d_vals = reinterpret_cast<double *>(arena.base + o_vals);
+    plan->d_cols = reinterpret_cast<int32_t *>(arena.base + o_cols);
+    plan->d_tvals = reinterpret_cast<double *>(arena.base + o_tvals);
+    plan->d_tidx = reinterpret_cast<uint8_t *>(arena.base + o_tidx);
+    int32_t *d_perm = nullptr;
+    // clear what the scatter kernels do not write (padding slots, padding lanes); then the small tables
+    HIP_TRY(hipMemsetAsync(plan->d_vals, 0, (size_t)n_chunks * CH * sizeof(double), 0));
+    HIP_TRY(hipMemsetAsync(plan->d_tvals, 0, n_tvals * sizeof(double), 0));
+    HIP_TRY(hipMemsetAsync(plan->d_tidx, 0, n_tidx, 0));
+    // columns: the structure's list sits at the structure's own chunk range (shared plans: output 0's range is the one the
+    // Phi kernel reads; the other ranges stay unused)
+    for (int o = 0; o < n_struct; o++)
+        HIP_TRY(hipMemcpy(plan->d_cols + out_chunk_begin[o] * CH, cols.data() + struct_slots[o],
+                          (size_t)(struct_slots[o + 1] - struct_slots[o]) * sizeof(int32_t), hipMemcpyHostToDevice));
     if ((rc = upload(arena, o_rows, &plan->d_rows, rows))) return rc;
     if ((rc = upload(arena, o_orb, &plan->d_out_row_begin, out_row_begin))) return rc;
     if ((rc = upload(arena, o_tiles, &plan->d_tiles, tiles))) return rc;
-    if ((rc = upload(arena, o_tvals, &plan->d_tvals, tvals))) return rc;
-    if ((rc = upload(arena, o_tidx, &plan->d_tidx, tidx))) return rc;
     if ((rc = upload(arena, o_invmap, &plan->d_invmap, invmap))) return rc;
     if ((rc = upload(arena, o_goff, &plan->d_goff, plan->grad_off))) return rc;
+    if ((rc = upload(arena, o_perm, &d_perm, perm))) return rc;
+    timer.lap("device arena + small uploads");
+    // scatter the values on the device: one launch per (output, group size) and layout
+    for (int o = 0; o < n_out; o++) {
+        const OutputDesc &od = plan->outs[o];
+        const int st = plan->shared ? 0 : o;
+        int64_t io = 0, go = 0, eo = 0;
+        for (int k = 1; k <= od.K; k++) {
+            const int64_t Lk = od.sizes[k - 1];
+            const int ne = k * (k + 1) / 2;
+            if (Lk > 0) {
+                hipLaunchKernelGGL(k_fill_csr, dim3((unsigned)((Lk * ne + 255) / 256)), dim3(256), 0, 0, od.d_invcov + io, k, Lk,
+                                   d_perm + struct_entries[st] + eo, plan->d_vals + out_chunk_begin[o] * CH);
+                hipLaunchKernelGGL(k_fill_tiles, dim3((unsigned)((Lk * (ne + k) + 255) / 256)), dim3(256), 0, 0, od.d_invcov + io,
+                                   od.d_groups + go, k, Lk, plan->d_tvals + bucket_val[o][k], plan->d_tidx + bucket_idx[o][k]);
+            }
+            io += Lk * k * k; go += Lk * k; eo += Lk * ne;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(0));
     plan->d_partial = reinterpret_cast<double2 *>(arena.base + o_partial);
     plan->d_v = reinterpret_cast<double *>(arena.base + o_v);
     plan->d_status = reinterpret_cast<int32_t *>(arena.base + o_status);
     plan->finalized = true;
-    timer.lap("uploads + device allocations");
-    // host copies of the reference-layout inputs are no longer needed
-    for (auto &od : plan->outs) { std::vector<double>().swap(od.invcovs); std::vector<int64_t>().swap(od.groups); }
+    timer.lap("device scatter of the values");
     return BLUEST_OK;
 }
 

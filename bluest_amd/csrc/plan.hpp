@@ -14,10 +14,13 @@ struct TileDesc {     // 64 groups of equal size k of one output, for the gradie
 struct OutputDesc {
     int K = 0;
     std::vector<int64_t> sizes;    // K entries
-    std::vector<int64_t> groups;   // concat (L_k * k)
-    std::vector<double> invcovs;   // concat (L_k * k * k)
+    std::vector<int64_t> groups;   // concat (L_k * k), host copy (kept: restricted plans, descriptors)
     std::vector<int64_t> mapping;  // L_o global indices
     int64_t L_o = 0;
+    int64_t n_inv = 0;             // doubles of the reference-layout inverses: sum L_k k^2
+    double *d_invcov = nullptr;    // DEVICE, reference layout concat (L_k * k * k): pinv output or uploaded; lives as long as the plan
+    int64_t *d_groups = nullptr;   // DEVICE copy of `groups` (shared with output 0 when the lists are identical)
+    bool owns_groups = false;
 };
 
 struct bluest_plan_s {

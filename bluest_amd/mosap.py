@@ -116,13 +116,7 @@ class _SapView(SAP):
         self.flattened_groups = _LazyFlat(groups)
         self.cumsizes = np.cumsum(self.sizes)
         self.L = int(self.cumsizes[-1])
-        flat = parent.plan.invcovs[n]
-        invcovs, off = [], 0
-        for k in range(1, self.K + 1):
-            cnt = self.sizes[k] * k * k
-            invcovs.append(flat[off:off + cnt] if cnt > 0 else np.array([]))
-            off += cnt
-        self.invcovs = invcovs
+        self._plan_output = n
         self.ES = LazyIndicators(groups, self.N)
         self.e = self.ES[0]
         self._psi = None
@@ -136,6 +130,12 @@ class _SapView(SAP):
                               max_candidates=1, device=self._parent.plan.device)
             self.get_variance_functions()
         return self._plan
+
+    def _inverse_source(self):
+        return self._parent.plan.invcovs[self._n]
+
+    def _inverse_plan(self):
+        return self._parent.plan, self._n
 
     def __getattr__(self, name):
         if name in ("get_phi", "variance", "variance_GH"):
@@ -250,9 +250,9 @@ class MOSAP(object):
             groups, invcovs, sizes = [], [], []
             for k in range(1, sap.K + 1):
                 lo, hi = sap.cumsizes[k - 1], sap.cumsizes[k]
-                sel = local[(local >= lo) & (local < hi)] - lo
-                groups.append(np.asarray(sap.groups[k - 1]).reshape(-1, k)[sel])
-                invcovs.append(np.asarray(sap.invcovs[k - 1]).reshape(-1, k * k)[sel].ravel())
+                sel = local[(local >= lo) & (local < hi)]
+                groups.append(np.asarray(sap.groups[k - 1]).reshape(-1, k)[sel - lo])
+                invcovs.append(sap._gather_inverses(sel))
                 sizes.append(len(sel))
             if not any(len(g) and (g == 0).any() for g in groups):
                 raise BLUESTError("restricted plan: output %d would not sample model 0" % n)

@@ -32,6 +32,23 @@ def require_cuda():
         raise _lib.BluestHipError("no GPU visible to torch: bluest_amd computes on MI355X only (no CPU fallback)")
 
 
+class _LazyInverses(object):
+    def __init__(self, plan):
+        self._plan, self._cache = plan, {}
+
+    def __len__(self): return self._plan.n_out
+
+    def __getitem__(self, o):
+        o = int(o)
+        if o not in self._cache:
+            pl = self._plan
+            ic = np.empty(pl._n_inv[o], dtype=np.float64)
+            with torch.cuda.device(pl.device):
+                check(pl.lib.bluest_plan_get_invcovs(pl._h, o, ptr(ic)))
+            self._cache[o] = ic
+        return self._cache[o]
+
+
 class Plan(object):
     """One plan = all outputs of one (multi-output) sample-allocation problem, resident in HBM.
 
@@ -53,14 +70,16 @@ class Plan(object):
         self.n_out = len(outputs)
         self.max_candidates = int(max_candidates)
         self._h = ctypes.c_void_p()
-        self.invcovs = []  # reference-layout host copies when computed on device
+        self._n_inv = []
         with torch.cuda.device(self.device):
             check(self.lib.bluest_plan_create(ctypes.byref(self._h), self.N, self.L))
             try:
+                self._sizes = []
                 for out in outputs:
                     K = int(out["K"])
                     sizes = _i64(out["sizes"])
                     assert len(sizes) == K
+                    self._sizes.append(sizes.copy())
                     g = out["groups"]
                     groups = _i64(np.concatenate([np.asarray(x, dtype=np.int64).ravel() for x in g])
                                   if isinstance(g, (list, tuple)) else g)
@@ -70,13 +89,11 @@ class Plan(object):
                         ic = _f64(np.concatenate([np.asarray(x, dtype=np.float64).ravel() for x in ic])
                                   if isinstance(ic, (list, tuple)) else ic)
                         check(self.lib.bluest_plan_add_output(self._h, K, ptr(sizes), ptr(groups), ptr(ic), ptr(mapping)))
-                        self.invcovs.append(None)
                     else:
                         C = _f64(out["C"])
-                        n_ic = int(sum(int(sizes[k - 1]) * k * k for k in range(1, K + 1)))
-                        ic = np.empty(n_ic, dtype=np.float64)
-                        check(self.lib.bluest_plan_add_output_cov(self._h, ptr(C), K, ptr(sizes), ptr(groups), ptr(mapping), ptr(ic)))
-                        self.invcovs.append(ic)
+                        # the per-group pseudo-inverses are computed AND kept on the device; the host asks for them lazily
+                        check(self.lib.bluest_plan_add_output_cov(self._h, ptr(C), K, ptr(sizes), ptr(groups), ptr(mapping), None))
+                    self._n_inv.append(int(sum(int(sizes[k - 1]) * k * k for k in range(1, K + 1))))
                 check(self.lib.bluest_plan_finalize(self._h, self.max_candidates))
             except Exception:
                 self.lib.bluest_plan_destroy(self._h)
@@ -91,6 +108,31 @@ class Plan(object):
         check(self.lib.bluest_plan_traffic(self._h, ctypes.byref(pb), ctypes.byref(gb)))
         self.phi_bytes, self.grad_bytes = pb.value, gb.value
         self.reclen = self.N * self.N + 2 * self.N + 1
+
+    @property
+    def invcovs(self):
+        """list over outputs of the reference-layout pseudo-inverses (flat, concat over group sizes; sap.py:69-79), fetched
+        from the device on first use"""
+        if getattr(self, "_invcovs", None) is None:
+            self._invcovs = _LazyInverses(self)
+        return self._invcovs
+
+    def gather_invcovs(self, output, local_idx):
+        """k x k blocks of some groups of one output (local indices), concatenated: gathered on the device, one small copy"""
+        idx = _i64(local_idx)
+        if len(idx) == 0:
+            return np.zeros(0)
+        sizes = self._group_sizes(output)[idx]
+        out = np.empty(int((sizes * sizes).sum()), dtype=np.float64)
+        with torch.cuda.device(self.device):
+            check(self.lib.bluest_plan_gather_invcovs(self._h, int(output), ptr(idx), len(idx), ptr(out)))
+        return out
+
+    def _group_sizes(self, output):
+        cache = self.__dict__.setdefault("_gsizes", {})
+        if output not in cache:
+            cache[output] = np.concatenate([np.full(int(n), k + 1, dtype=np.int64) for k, n in enumerate(self._sizes[output])])
+        return cache[output]
 
     def __del__(self):
         try:

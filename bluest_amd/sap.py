@@ -535,18 +535,40 @@ class SAP(object):
 
         self.plan = Plan(self.N, self.L, [{"K": K, "sizes": sizes[1:], "groups": groups, "C": np.asarray(C, dtype=np.float64),
                                            "mapping": None}], max_candidates=max_candidates, device=device)
-        flat = self.plan.invcovs[0]
-        invcovs, off = [], 0
-        for k in range(1, K + 1):
-            n = sizes[k] * k * k
-            invcovs.append(flat[off:off + n] if n > 0 else np.array([]))
-            off += n
-        self.invcovs = invcovs
-
+        self._plan_output = 0              # which output of self.plan holds this SAP's inverses
         self.ES = LazyIndicators(groups, self.N)
         self.e = self.ES[0]
         self._psi = None
         self.get_variance_functions()
+
+    @property
+    def invcovs(self):
+        """list over k of the flattened pseudo-inverses pinv(C[g, g]) (sap.py:69-79).  They are computed and kept on the GPU;
+        this host copy is made when somebody asks for it"""
+        if self.__dict__.get("_invcovs") is None:
+            flat = self._inverse_source()
+            out, off = [], 0
+            for k in range(1, self.K + 1):
+                n = self.sizes[k] * k * k
+                out.append(flat[off:off + n] if n > 0 else np.array([]))
+                off += n
+            self.__dict__["_invcovs"] = out
+        return self.__dict__["_invcovs"]
+
+    def _inverse_source(self):
+        return self.plan.invcovs[self._plan_output]
+
+    def _gather_inverses(self, local_idx):
+        """inverses of some of this SAP's groups (local indices) without bringing all of them to the host"""
+        if self.__dict__.get("_invcovs") is not None:
+            ks = np.searchsorted(self.cumsizes, local_idx, side="right")
+            return np.concatenate([self._invcovs[k - 1][(i - self.cumsizes[k - 1]) * k * k:(i - self.cumsizes[k - 1] + 1) * k * k]
+                                   for i, k in zip(local_idx, ks)]) if len(local_idx) else np.zeros(0)
+        pl, o = self._inverse_plan()
+        return pl.gather_invcovs(o, local_idx)
+
+    def _inverse_plan(self):
+        return self.plan, self._plan_output
 
     # ---- psi is only needed by SDP solvers / integer projection: assembled on demand (sap.py:129) --------
     @property
@@ -600,9 +622,9 @@ class SAP(object):
         groups, invcovs, sizes = [], [], []
         for k in range(1, self.K + 1):
             lo, hi = self.cumsizes[k - 1], self.cumsizes[k]
-            sel = keep[(keep >= lo) & (keep < hi)] - lo
-            groups.append(np.asarray(self.groups[k - 1]).reshape(-1, k)[sel])
-            invcovs.append(np.asarray(self.invcovs[k - 1]).reshape(-1, k * k)[sel].ravel())
+            sel = keep[(keep >= lo) & (keep < hi)]
+            groups.append(np.asarray(self.groups[k - 1]).reshape(-1, k)[sel - lo])
+            invcovs.append(self._gather_inverses(sel))                   # k x k blocks of the kept groups only
             sizes.append(len(sel))
         if not any(len(g) and (g == 0).any() for g in groups):
             raise BLUESTError("restricted plan would not sample model 0")

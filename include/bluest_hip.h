@@ -119,6 +119,13 @@ int bluest_plan_add_output(bluest_plan_t plan, int K, const int64_t *sizes, cons
 int bluest_plan_add_output_cov(bluest_plan_t plan, const double *C, int K, const int64_t *sizes,
                                const int64_t *groups, const int64_t *mapping, double *invcovs_out);
 
+/* Reference-layout pseudo-inverses of output o (concat_k L_k*k*k doubles) back to a host buffer: they stay on the device
+ * after bluest_plan_add_output_cov (the plan is built from them there) and are only fetched when the host asks, e.g. for the
+ * `invcovs` attribute of SAP (bluest/sap.py:69-79).  bluest_plan_gather_invcovs fetches the k x k blocks of SOME groups of
+ * output o (local indices, any order, blocks written one after the other) -- what a restricted plan needs. */
+int bluest_plan_get_invcovs(bluest_plan_t plan, int output, double *invcovs_out);
+int bluest_plan_gather_invcovs(bluest_plan_t plan, int output, const int64_t *local_idx, int64_t n, double *out);
+
 /* Build the HBM layouts.  max_candidates = largest number of allocation vectors evaluated per call. */
 int bluest_plan_finalize(bluest_plan_t plan, int max_candidates);
 

@@ -81,10 +81,12 @@ def sap_wallclock(prob, reps=4):
                     "dropping the problem afterwards (plan memory, captured hipGraphs, a full Python collection)" % len(warm)}
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, cfg):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json, written
-    by tools/pmc_traffic.py with the guide's gfx950 FETCH_SIZE correction); None if that profile is absent"""
+    by tools/pmc_traffic.py with the guide's gfx950 FETCH_SIZE correction; taken on the headline workload); None otherwise"""
     import glob
+    if tuple(cfg) != HEADLINE:
+        return None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         try:
             return json.load(open(f))["kernels"][kernel]["hbm_bytes_per_launch"]
@@ -93,11 +95,14 @@ def pmc_traffic(kernel):
     return None
 
 
-def rocprof_avg_us(kernel):
-    """average dispatch duration of `kernel` in the newest committed rocprofv3 --kernel-trace --stats summary (profiles/)"""
+def rocprof_avg_us(kernel, cfg):
+    """average dispatch duration of `kernel` in the newest committed rocprofv3 --kernel-trace --stats summary for THIS
+    configuration: profiles/<tag>_kernel_stats.csv for the headline workload, profiles/<tag>_kernel_stats_n<n>_k<k>_o<o>.csv for
+    the others; None when no such profile is committed"""
     import csv
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats.csv")), reverse=True):
+    suffix = "" if tuple(cfg) == HEADLINE else "_n%d_k%d_o%d" % tuple(cfg)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats%s.csv" % suffix)), reverse=True):
         try:
             for row in csv.DictReader(open(f)):
                 if kernel + "<" in row["Name"] or kernel + "(" in row["Name"]:
@@ -331,8 +336,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # RCCL launches are left eager (a collective inside a captured graph is a different code path of the library)
-    stepper = Stepper(torch, step, len(ring), args.steps, args.graph_steps, (sharded is None) and not args.no_graph, barrier)
+    # RCCL launches are left eager (a collective inside a captured graph is a different code path of the library); the peer-write
+    # exchange is a plain kernel and is captured with the rest of the step
+    graphable = (sharded is None) or (sharded.exchange is not None)
+    stepper = Stepper(torch, step, len(ring), args.steps, args.graph_steps, graphable and not args.no_graph, barrier)
     sec_per_step, repeats = stepper.timed(args.warmup)
     if world > 1:
         t = torch.tensor([sec_per_step], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -396,12 +403,12 @@ def main():
         else:
             kname = "k_phi_chunks_shared" if n_out >= 2 else "k_phi_chunks"
             tk, abytes, lbytes = max(t_chunks, 1e-9), ab["phi"] * n_out, plan.phi_bytes
-        rp = rocprof_avg_us(kname)
+        rp = rocprof_avg_us(kname, (n, kmax, n_out_all))
         roofline = {"bound": "hbm", "kernel": kname, "achieved": abytes / tk / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": abytes / tk / HBM_PEAK, "headline_clock": "frac = frac_chain (measured live in this run)",
                     "frac_chain": abytes / tk / HBM_PEAK,
                     "frac_rocprof": None if rp is None else abytes / (rp * 1e-6) / HBM_PEAK,
-                    "traffic": pmc_traffic(kname),
+                    "traffic": pmc_traffic(kname, (n, kmax, n_out_all)),
                     "traffic_source": "profiles/*_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)",
                     "algorithmic_bytes_per_launch": abytes, "layout_bytes_per_launch": lbytes, "avg_launch_us": tk * 1e6,
                     "clocks": "chain: HIP events around a graph of dependent launches, one launch = kernel + dispatch gap to its "

@@ -193,7 +193,8 @@ def solve_budget_capped(plan, costs, cap_rows, cap_rhs, budget, s_norm, prm, x0=
     res = None
     for q in stages:
         st["p"] = q
-        res = spg(feval, geval, proj, x, eps=prm["eps"], maxit=max(1, int(prm["maxit"]) // len(stages)), max_fevals=prm["max_fevals"],
+        res = spg(feval, geval, proj, x, eps=prm["eps"], maxit=max(1, int(prm.get("capped_maxit", 600)) // len(stages)),
+                  max_fevals=prm["max_fevals"],
                   verbose=False, lmbda_min=prm["lmbda_min"], lmbda_max=min(float(prm["lmbda_max"]), float(prm.get("capped_lmbda_max", 1.0))),
                   Hlength=prm["linesearch_history_length"],
                   proj_step=proj_step, metric_dot=metric_dot if floor > 0 else None)
@@ -227,27 +228,32 @@ def solve_capped(plan, costs, cap_rows, cap_rhs, budget=None, eps=None, x0=None,
             return np.inf
         return float((var[0].cpu().numpy() / s_norm).max())
 
-    lo = float(unconstrained_cost)                       # without caps this budget gives ratio 1: a lower bound on the cost
-    m, info, _ = attempt(lo, None)
-    if m is not None and true_ratio(m) <= 1.0 + 1.0e-6:
-        return m, info
-    hi, m_hi, info_hi = lo, None, None
-    for _ in range(24):
-        hi *= 2.0
-        m_try, info_try, _ = attempt(hi, m)
-        if m_try is not None and true_ratio(m_try) <= 1.0:
-            m_hi, info_hi = m_try, info_try
+    # Without caps the cost scales like 1/ratio (V is homogeneous of degree -1); with caps that is only a guess, but a good one:
+    # B <- B * ratio until the tolerance is met (bracket), then a few bisection steps in log B.  Each step is one capped solve
+    # warm-started from the previous allocation.
+    lo, m_lo = None, None
+    B = float(unconstrained_cost)                        # without caps this budget gives ratio 1: a lower bound on the cost
+    m_hi = info_hi = hi = None
+    start = x0
+    for _ in range(8):
+        m_try, info_try, _ = attempt(B, start)
+        rho = np.inf if m_try is None else true_ratio(m_try)
+        if m_try is not None and rho <= 1.0 + 1.0e-6:
+            hi, m_hi, info_hi = B, m_try, info_try
             break
-        m = m_try if m_try is not None else m
+        lo = B
+        start = m_try if m_try is not None else start
+        B *= min(4.0, max(1.05, rho if np.isfinite(rho) else 4.0))
     if m_hi is None:
         return None, {"reason": "the sample caps make the error tolerance unreachable"}
-    for _ in range(14):
-        mid = 0.5 * (lo + hi)
-        m_try, info_try, _ = attempt(mid, m_hi)
-        if m_try is not None and true_ratio(m_try) <= 1.0:
-            hi, m_hi, info_hi = mid, m_try, info_try
-        else:
-            lo = mid
-        if hi / lo - 1.0 < 1.0e-3:
-            break
+    if lo is not None:
+        for _ in range(6):
+            if hi / lo - 1.0 < 2.0e-3:
+                break
+            mid = float(np.sqrt(lo * hi))
+            m_try, info_try, _ = attempt(mid, m_hi)
+            if m_try is not None and true_ratio(m_try) <= 1.0 + 1.0e-6:
+                hi, m_hi, info_hi = mid, m_try, info_try
+            else:
+                lo = mid
     return m_hi, info_hi

@@ -63,6 +63,7 @@ static int g_debug_solve = getenv("BLUEST_DEBUG_SOLVE") ? atoi(getenv("BLUEST_DE
 
 
 #include "plan.hpp"
+#include "spg_state.hpp"
 
 // ------------------------------------------------------------------------------------------------------
 // Part 2 -- plan kernels
@@ -158,13 +159,25 @@ __global__ __launch_bounds__(fold_threads(NT)) void k_solve_from_chunks(int N, i
                                                            const double2 *__restrict__ partial, int64_t n_chunks,
                                                            double delta, int want_v, double *__restrict__ var,
                                                            double *__restrict__ v, int32_t *__restrict__ status,
-                                                           const int32_t *__restrict__ gate)
+                                                           const int32_t *__restrict__ gate, const int64_t *__restrict__ ocb, int staged,
+                                                           double *__restrict__ spg_state, int last_slot, int32_t *__restrict__ spg_enable,
+                                                           unsigned int *__restrict__ ticket)
 {
     __shared__ SolveLds<NT> lds;
-    if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
+    __shared__ double spg_ls[SPG_STATE_DOUBLES];
+    extern __shared__ double2 stage[];   // staged != 0: room for the partials of one output
     const int o = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
-    if (N < NT) { clear_pads(lds, N, tid, fold_threads(NT)); __syncthreads(); }   // uniform; every real entry is written by the fold
-    fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, fold_threads(NT));
+    if (gate && *gate == 0) {   // device-side predication (SPG line-search slots)
+        // the line-search decision still has to close the slot (it sets the gate of the finishing launches on the last one)
+        if (spg_state && o == 0 && c == 0 && tid < WAVE) spg_decide_wave(spg_state, var, status, n_out, last_slot, spg_enable, spg_ls, tid);
+        return;
+    }
+    RowDesc rd0 = rows[o * nsym + (((tid >> 2) < nsym) ? (tid >> 2) : 0)];      // in flight together with the staging copy
+    if (staged) stage_partials(stage, partial + (int64_t)c * n_chunks, ocb[o], (int)(ocb[o + 1] - ocb[o]), tid, fold_threads(NT));
+    clear_pads(lds, N, tid, fold_threads(NT));          // only when N < NT (every real entry is written by the fold)
+    if (staged || N < NT) __syncthreads();
+    if (staged) fold_rows(lds, N, rows, o * nsym, nsym, stage, ocb[o], tid, fold_threads(NT), &rd0);
+    else fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, 0, tid, fold_threads(NT));
     __syncthreads();
     if (tid >= WAVE) return;   // single wavefront from here on
     const int lane = tid;
@@ -178,6 +191,26 @@ __global__ __launch_bounds__(fold_threads(NT)) void k_solve_from_chunks(int N, i
     const int reps = (want_v & 4) ? 2 : 1;   // diagnostics: run the solve twice
     for (int rep = 0; rep < reps; rep++)
         solve_wave<NT>(lds, N, delta, am > 1.0e-6, am > 0.0, big, (want_v & 1) != 0, var + e, v + e * N, status + e, lane);
+    if (spg_state) {
+        // line-search decision fused into the tail (single candidate): every output's workgroup publishes V and status, takes a
+        // ticket, and the LAST one to arrive evaluates the objective of the trial point and decides -- one launch and one kernel
+        // boundary less per slot.  Publication: stores drained, agent-scope release, then the ticket (relaxed agent atomic);
+        // the last arriver acquires before it reads the other outputs' values (MI355X_MICROARCH.md, inter-workgroup visibility).
+        int last = 0;
+        if (lane == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (t == (unsigned int)(n_out - 1)) ? 1 : 0;
+            if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+        }
+        last = __builtin_amdgcn_readfirstlane(last);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            spg_decide_wave(spg_state, var, status, n_out, last_slot, spg_enable, spg_ls, lane);
+        }
+    }
 }
 
 // multi-GPU path, phase A tail: fold chunk partials into an all-reduce-able record.
@@ -188,7 +221,7 @@ __global__ __launch_bounds__(fold_threads(NT)) void k_fold_to_record(int N, int 
 {
     __shared__ SolveLds<NT> lds;
     const int o = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
-    fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, fold_threads(NT));
+    fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, 0, tid, fold_threads(NT));
     __syncthreads();
     const int reclen = N * N + 2 * N + 1;
     double *r = rec + ((int64_t)c * n_out + o) * reclen;
@@ -259,8 +292,9 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
                                                     const double *__restrict__ tvals, const uint8_t *__restrict__ tidx,
                                                     double *__restrict__ var, double *__restrict__ v_ws,
                                                     int32_t *__restrict__ status, double *__restrict__ grad,
-                                                    const int32_t *__restrict__ gate)
+                                                    const int32_t *__restrict__ gate, const int64_t *__restrict__ ocb, int staged)
 {
+    extern __shared__ double2 stage[];   // staged != 0: room for the partials of one output
     constexpr int FUSED_TPB = fused_tpb(NT, KU);
     constexpr int NTHREADS = 64 * (FUSED_TPB + 1);
     constexpr int NE = KU * (KU + 1) / 2;
@@ -275,9 +309,13 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
     int o, first;
     if (bpo > 0) { o = blockIdx.x / bpo; first = (blockIdx.x % bpo) == 0; }
     else { const TileDesc td0 = tiles[t0]; o = td0.out; first = (td0.n_valid >> 30) & 1; }
-    if (N < NT) { clear_pads(lds, N, tid, NTHREADS); __syncthreads(); }   // uniform; every real entry is written by the fold
+    RowDesc rd0 = rows[o * nsym + (((tid >> 2) < nsym) ? (tid >> 2) : 0)];      // in flight together with the staging copy
+    if (staged) stage_partials(stage, partial, ocb[o], (int)(ocb[o + 1] - ocb[o]), tid, NTHREADS);
+    clear_pads(lds, N, tid, NTHREADS);                  // only when N < NT (every real entry is written by the fold)
+    if (staged || N < NT) __syncthreads();
     PHASE(1);
-    fold_rows<NT>(lds, N, rows, o * nsym, nsym, partial, tid, NTHREADS);
+    if (staged) fold_rows<NT>(lds, N, rows, o * nsym, nsym, stage, ocb[o], tid, NTHREADS, &rd0);
+    else fold_rows<NT>(lds, N, rows, o * nsym, nsym, partial, 0, tid, NTHREADS);
     // the list is padded to a multiple of FUSED_TPB tiles per output, so every tile of this workgroup belongs to output o
     // (loaded by the tile wavefronts only: the solving wavefront must not wait for a descriptor it does not use)
     TileDesc td;
@@ -933,9 +971,11 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     const size_t o_tidx = arena.reserve(n_tidx), o_invmap = arena.reserve(invmap.size() * sizeof(int32_t));
     const size_t o_goff = arena.reserve(plan->grad_off.size() * sizeof(int64_t));
     const size_t o_perm = arena.reserve(perm.size() * sizeof(int32_t));
+    const size_t o_ocb = arena.reserve(out_chunk_begin.size() * sizeof(int64_t));
     const size_t o_partial = arena.reserve((size_t)max_candidates * n_chunks * sizeof(double2));
     const size_t o_v = arena.reserve((size_t)max_candidates * n_out * N * sizeof(double));
     const size_t o_status = arena.reserve((size_t)max_candidates * n_out * sizeof(int32_t));
+    const size_t o_ticket = arena.reserve(256);
     HIP_TRY(pool_alloc(&plan->d_arena, arena.bytes));
     arena.base = (char *)plan->d_arena;
     plan->d_vals = reinterpret_cast<double *>(arena.base + o_vals);
@@ -958,6 +998,9 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     if ((rc = upload(arena, o_invmap, &plan->d_invmap, invmap))) return rc;
     if ((rc = upload(arena, o_goff, &plan->d_goff, plan->grad_off))) return rc;
     if ((rc = upload(arena, o_perm, &d_perm, perm))) return rc;
+    if ((rc = upload(arena, o_ocb, &plan->d_out_chunk_begin, out_chunk_begin))) return rc;
+    plan->max_chunks_per_output = 0;
+    for (int o = 0; o < n_out; o++) plan->max_chunks_per_output = std::max<int>(plan->max_chunks_per_output, (int)(out_chunk_begin[o + 1] - out_chunk_begin[o]));
     timer.lap("device arena + small uploads");
     // scatter the values on the device: one launch per (output, group size) and layout
     for (int o = 0; o < n_out; o++) {
@@ -981,6 +1024,8 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     plan->d_partial = reinterpret_cast<double2 *>(arena.base + o_partial);
     plan->d_v = reinterpret_cast<double *>(arena.base + o_v);
     plan->d_status = reinterpret_cast<int32_t *>(arena.base + o_status);
+    plan->d_ticket = reinterpret_cast<unsigned int *>(arena.base + o_ticket);
+    HIP_TRY(hipMemset(plan->d_ticket, 0, 256));
     plan->finalized = true;
     timer.lap("device scatter of the values");
     return BLUEST_OK;
@@ -1114,8 +1159,27 @@ extern "C" int bluest_plan_grad(bluest_plan_t plan, const double *v_dev, const i
     return BLUEST_OK;
 }
 
+static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, double delta,
+                     double *var_dev, double *grad_dev, int64_t grad_stride, int32_t *status_dev, void *stream,
+                     double *dec_state, int dec_last, int32_t *dec_enable);
+
 extern "C" int bluest_plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, double delta,
                                 double *var_dev, double *grad_dev, int64_t grad_stride, int32_t *status_dev, void *stream)
+{
+    return plan_eval(plan, m_dev, n_cand, m_stride, delta, var_dev, grad_dev, grad_stride, status_dev, stream, nullptr, 0, nullptr);
+}
+
+extern "C" int bluest_plan_eval_decide(bluest_plan_t plan, const double *m_dev, double delta, double *var_dev, int32_t *status_dev,
+                                       double *state_dev, int last_slot, int32_t *enable_dev, void *stream)
+{
+    if (!state_dev || !enable_dev || !status_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (plan && (int)plan->outs.size() > SPG_MAX_OUT) return fail(BLUEST_ERR_ARG, "more than %d outputs", SPG_MAX_OUT);
+    return plan_eval(plan, m_dev, 1, 0, delta, var_dev, nullptr, 0, status_dev, stream, state_dev, last_slot, enable_dev);
+}
+
+static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, double delta,
+                     double *var_dev, double *grad_dev, int64_t grad_stride, int32_t *status_dev, void *stream,
+                     double *dec_state, int dec_last, int32_t *dec_enable)
 {
     int rc = plan_ready(plan, n_cand); if (rc) return rc;
     if (!m_dev || !var_dev) return fail(BLUEST_ERR_ARG, "null pointer");
@@ -1127,11 +1191,18 @@ extern "C" int bluest_plan_eval(bluest_plan_t plan, const double *m_dev, int n_c
     launch_chunks(plan, m_dev, n_cand, m_stride, st);
     int kmax = 0;
     for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
+    // the folding kernels CAN stage one output's chunk partials in LDS when they fit next to the solver's own LDS (default limit
+    // of dynamic LDS per workgroup: 64 KB)
+    const size_t want_stage = (size_t)plan->max_chunks_per_output * sizeof(double2);
+    // (opt-in, BLUEST_STAGED_FOLD=1: measured SLOWER at the headline size -- step 15.7 vs 15.3 us, value-only solve 6.6 vs
+    //  6.1 us: the LDS round trip and the extra barrier cost more than the dependent HBM round trip they replace)
+    const size_t stage_bytes = (want_stage <= 56 * 1024 && getenv("BLUEST_STAGED_FOLD")) ? want_stage : 0;
     // fused solve + gradient pass (2 launches per evaluation); groups larger than 12 take the generic tile code inside it
     if (grad_dev && n_cand == 1 && !g_debug_solve) {
         const dim3 grid((unsigned)(plan->n_tiles / plan->fused_tpb));
-#define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, \
-                                        delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->d_tvals, plan->d_tidx, var_dev, plan->d_v, status, grad_dev, plan->gate)
+#define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), stage_bytes, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, \
+                                        delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->d_tvals, plan->d_tidx, var_dev, plan->d_v, status, grad_dev, plan->gate, \
+                                        plan->d_out_chunk_begin, stage_bytes ? 1 : 0)
 #define LSG(NT) do { if (kmax <= 5) LSG2(NT, 5); else if (kmax <= 6) LSG2(NT, 6); else if (kmax <= 8) LSG2(NT, 8); else LSG2(NT, 12); } while (0)
         NT_DISPATCH(plan->N, LSG);
 #undef LSG
@@ -1140,8 +1211,9 @@ extern "C" int bluest_plan_eval(bluest_plan_t plan, const double *m_dev, int n_c
         return BLUEST_OK;
     }
     const int want = ((grad_dev || plan->always_v) ? 1 : 0) | g_debug_solve;
-#define LSC(NT) hipLaunchKernelGGL((k_solve_from_chunks<NT>), dim3(n_out, n_cand), dim3(fold_threads(NT)), 0, st, plan->N, n_out, plan->d_rows, \
-                                   plan->nsym, plan->d_partial, plan->n_chunks, delta, want, var_dev, plan->d_v, status, plan->gate)
+#define LSC(NT) hipLaunchKernelGGL((k_solve_from_chunks<NT>), dim3(n_out, n_cand), dim3(fold_threads(NT)), stage_bytes, st, plan->N, n_out, plan->d_rows, \
+                                   plan->nsym, plan->d_partial, plan->n_chunks, delta, want, var_dev, plan->d_v, status, plan->gate, \
+                                   plan->d_out_chunk_begin, stage_bytes ? 1 : 0, dec_state, dec_last, dec_enable, plan->d_ticket)
     NT_DISPATCH(plan->N, LSC);
 #undef LSC
     if (grad_dev)

@@ -44,6 +44,8 @@ struct bluest_plan_s {
     int32_t *d_cols = nullptr;
     RowDesc *d_rows = nullptr;
     int32_t *d_out_row_begin = nullptr;
+    int64_t *d_out_chunk_begin = nullptr;   // n_out + 1: first chunk of every output (its partials are contiguous)
+    int max_chunks_per_output = 0;
     TileDesc *d_tiles = nullptr;
     double *d_tvals = nullptr;
     uint8_t *d_tidx = nullptr;
@@ -55,6 +57,7 @@ struct bluest_plan_s {
     void *d_scratch = nullptr;   // set-up scratch of bluest_plan_add_output_cov (C, groups, inverses), reused across outputs
     size_t scratch_bytes = 0;
     int32_t *d_status = nullptr; // workspace for eval when caller passes NULL
+    unsigned int *d_ticket = nullptr;   // arrival counter of the fused solve + line-search decision (bluest_plan_eval_decide)
 };
 
 

@@ -52,14 +52,21 @@ __device__ __forceinline__ double readlane_f64(double x, int l)
 // FOUR adjacent lanes share a row: lane q sums chunks q, q+4, q+8, ... (up to 8 independent loads in flight, so a row of
 // <= 32 chunks costs ONE memory round trip), then the quad combines as (s0+s1)+(s2+s3) -- a fixed order, so the result
 // is deterministic and identical in every kernel that folds.  nthreads must be a multiple of 4.
+// `partial` is indexed by GLOBAL chunk number minus `chunk_base`: either the partial array in HBM (chunk_base = 0) or a copy of
+// ONE output's partials staged in LDS by the caller (chunk_base = that output's first chunk) -- same values, same order of
+// additions, so both variants give identical bits; the staged one saves the second dependent HBM round trip (descriptor ->
+// partials) of every row.
+// `first`: the descriptor of this quad's first row (r = tid >> 2), loaded by the caller BEFORE its barrier so that the load
+// overlaps the staging copy; nullptr = load it here.
 template <int NT>
 __device__ __forceinline__ void fold_rows(SolveLds<NT> &lds, int N, const RowDesc *__restrict__ rows, int row_begin,
-                                          int n_rows, const double2 *__restrict__ partial, int tid, int nthreads)
+                                          int n_rows, const double2 *partial, int64_t chunk_base, int tid, int nthreads,
+                                          const RowDesc *first = nullptr)
 {
     const int q = tid & 3;
     for (int r = tid >> 2; r < n_rows; r += nthreads >> 2) {
-        const RowDesc rd = rows[row_begin + r];
-        const double2 *p = partial + rd.first_chunk;
+        const RowDesc rd = (first && r == (tid >> 2)) ? *first : rows[row_begin + r];
+        const double2 *p = partial + ((int64_t)rd.first_chunk - chunk_base);
         const int n = rd.n_chunks;
         double s = 0.0, am = 0.0;
         for (int c0 = q; c0 < n; c0 += 32) {
@@ -79,6 +86,12 @@ __device__ __forceinline__ void fold_rows(SolveLds<NT> &lds, int N, const RowDes
             if (rd.a == rd.b) lds.amax[rd.a] = am;
         }
     }
+}
+
+// copy the partials of one output (chunks [cb, cb + n)) into LDS, coalesced; the caller synchronises
+__device__ __forceinline__ void stage_partials(double2 *stage, const double2 *__restrict__ partial, int64_t cb, int n, int tid, int nthreads)
+{
+    for (int i = tid; i < n; i += nthreads) stage[i] = partial[cb + i];
 }
 
 // single-wavefront LDS ordering: LDS operations of one wave execute in order; this only stops the compiler from

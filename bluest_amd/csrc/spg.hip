@@ -2,40 +2,11 @@
 // tagged mailboxes / multi-launch fallback) and the kernels of the device-resident SPG iteration (state in HBM, control flow by
 // predication).  Algorithm: bluest/spg.py:3-132 with the projection onto the simplex.
 #include "plan.hpp"
+#include "spg_state.hpp"
 
 // ------------------------------------------------------------------------------------------------------
 // Part 3 -- simplex projection (single workgroup of 1024 threads)
 // ------------------------------------------------------------------------------------------------------
-// ---- device-resident SPG state (doubles in HBM; layout mirrored in bluest_amd/spg_device.py) -----------------------
-#define SPG_F        0    // objective at x (normalised)
-#define SPG_FNEW     1    // objective at the accepted trial point
-#define SPG_LAMBDA   2    // spectral step
-#define SPG_ALPHA    3    // line-search step of the NEXT trial
-#define SPG_GD       4    // g.d            } written by the direction kernel
-#define SPG_DMAX     5    // max|d|         }
-#define SPG_TAU      6    //                }
-#define SPG_NPOS     7    //                }
-#define SPG_ACCEPT   8    // 1 once a trial of this iteration satisfied the nonmonotone Armijo test
-#define SPG_FAIL     9    // 1 if all slots of an iteration were rejected (host continues the line search)
-#define SPG_DONE     10   // 1 = every kernel is a no-op
-#define SPG_IT       11
-#define SPG_COUNT    12   // objective evaluations
-#define SPG_NORM     13   // objective normalisation
-#define SPG_P        14   // smoothing exponent (inf = plain max)
-#define SPG_LMIN     15
-#define SPG_LMAX     16
-#define SPG_HLEN     17   // history length (<= 16)
-#define SPG_SDOTS    18
-#define SPG_SDOTY    19
-#define SPG_FTRIAL   20   // objective of the last evaluated trial
-#define SPG_EPS      21   // stop when max|P(x-g)-x| <= eps
-#define SPG_GPSTATS  24   // g.gp, max|gp| (= gpmax), tau, npos of the convergence projection
-#define SPG_HIST     32   // 16 slots
-#define SPG_COEF     64   // dF/dV_o of the accepted trial (n_out <= 64)
-#define SPG_S        128  // normalisers s_o (1 or eps_o^2)
-#define SPG_STATE_DOUBLES 256
-#define SPG_MAX_OUT  64
-
 // xnew = x + alpha*d, m = scale*xnew for the next line-search slot; sets the plan gate (bluest/spg.py:13,28)
 __global__ __launch_bounds__(1024) void k_spg_trial(const double *__restrict__ x, const double *__restrict__ d,
                                                     const double *__restrict__ scale, const double *__restrict__ st,
@@ -62,66 +33,7 @@ __global__ __launch_bounds__(64) void k_spg_decide(double *__restrict__ st, cons
                                                    int32_t *__restrict__ enable)
 {
     __shared__ double ls[SPG_STATE_DOUBLES];
-    const int lane = threadIdx.x;
-#pragma unroll
-    for (int t = 0; t < SPG_STATE_DOUBLES / 64; t++) ls[t * 64 + lane] = st[t * 64 + lane];
-    __syncthreads();
-    const bool idle = ls[SPG_DONE] != 0.0 || ls[SPG_FAIL] != 0.0;
-    if (idle || ls[SPG_ACCEPT] != 0.0) {
-        if (last_slot && lane == 0) *enable = (!idle && ls[SPG_ACCEPT] != 0.0) ? 1 : 0;
-        return;
-    }
-    // objective F = || (V_o/s_o) ||_p / norm, coefficients dF/dV_o
-    const bool mine = lane < n_out;
-    const double so = mine ? ls[SPG_S + lane] : 1.0;
-    const double r = mine ? var[lane] / so : 0.0;
-    const bool bad = mine && (status[lane] != BLUEST_EVAL_OK || !isfinite(r));
-    const bool ok = __ballot(bad) == 0ull;
-    const double rmax = wave_max(mine ? r : -INFINITY);
-    const double p = ls[SPG_P], norm = ls[SPG_NORM];
-    double F = INFINITY, coef = 0.0;
-    if (ok) {
-        if (isinf(p) || n_out == 1) {
-            const unsigned long long is_max = __ballot(mine && r == rmax);
-            const int omax = __ffsll((long long)is_max) - 1;
-            F = rmax;
-            coef = (lane == omax) ? 1.0 / so : 0.0;
-        } else {
-            const double q = mine ? r / rmax : 0.0;
-            const double tq = mine ? pow(q, p - 1.0) : 0.0;       // q^(p-1); q^p = tq*q
-            const double tsum = wave_sum(tq * q);
-            const double root = pow(tsum, 1.0 / p);
-            F = rmax * root;
-            coef = tq * (root / tsum) / so;
-        }
-        F /= norm;
-    }
-    const int H = (int)ls[SPG_HLEN];
-    double fmax = -INFINITY;
-    for (int h = 0; h < H; h++) fmax = fmax > ls[SPG_HIST + h] ? fmax : ls[SPG_HIST + h];
-    const double alpha = ls[SPG_ALPHA], gd = ls[SPG_GD], f = ls[SPG_F];
-    const bool accept = F <= fmax + 1.0e-4 * alpha * gd;
-    if (accept && mine) st[SPG_COEF + lane] = coef / norm;
-    if (lane == 0) {
-        st[SPG_COUNT] = ls[SPG_COUNT] + 1.0;
-        st[SPG_FTRIAL] = F;
-        if (accept) {
-            st[SPG_ACCEPT] = 1.0;
-            st[SPG_FNEW] = F;
-        } else {
-            double a = alpha;
-            if (a <= 0.1) {
-                a *= 0.5;
-            } else {
-                double at = -0.5 * (a * a) * gd / (F - f - a * gd);
-                if (!(at >= 0.1) || at > 0.9 * a) at = 0.5 * a;   // also catches F = inf (at = -0) and NaN
-                a = at;
-            }
-            st[SPG_ALPHA] = a;
-            if (last_slot) st[SPG_FAIL] = 1.0;
-        }
-        if (last_slot) *enable = accept ? 1 : 0;
-    }
+    spg_decide_wave(st, var, status, n_out, last_slot, enable, ls, threadIdx.x);
 }
 
 // Workgroup reductions for the projection / SPG kernels: wavefront butterflies, one LDS hand-off and ONE barrier per call.

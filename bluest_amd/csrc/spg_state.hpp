@@ -1,0 +1,114 @@
+// spg_state.hpp -- layout of the device-resident SPG state and the line-search decision, shared by spg.hip (stand-alone decision
+// kernel) and plan.hip (decision fused into the tail of the solve kernel: one launch less per line-search slot).
+#pragma once
+#include "common.hpp"
+
+// ---- device-resident SPG state (doubles in HBM; layout mirrored in bluest_amd/spg_device.py) -----------------------
+#define SPG_F        0    // objective at x (normalised)
+#define SPG_FNEW     1    // objective at the accepted trial point
+#define SPG_LAMBDA   2    // spectral step
+#define SPG_ALPHA    3    // line-search step of the NEXT trial
+#define SPG_GD       4    // g.d            } written by the direction kernel
+#define SPG_DMAX     5    // max|d|         }
+#define SPG_TAU      6    //                }
+#define SPG_NPOS     7    //                }
+#define SPG_ACCEPT   8    // 1 once a trial of this iteration satisfied the nonmonotone Armijo test
+#define SPG_FAIL     9    // 1 if all slots of an iteration were rejected (host continues the line search)
+#define SPG_DONE     10   // 1 = every kernel is a no-op
+#define SPG_IT       11
+#define SPG_COUNT    12   // objective evaluations
+#define SPG_NORM     13   // objective normalisation
+#define SPG_P        14   // smoothing exponent (inf = plain max)
+#define SPG_LMIN     15
+#define SPG_LMAX     16
+#define SPG_HLEN     17   // history length (<= 16)
+#define SPG_SDOTS    18
+#define SPG_SDOTY    19
+#define SPG_FTRIAL   20   // objective of the last evaluated trial
+#define SPG_EPS      21   // stop when max|P(x-g)-x| <= eps
+#define SPG_GPSTATS  24   // g.gp, max|gp| (= gpmax), tau, npos of the convergence projection
+#define SPG_HIST     32   // 16 slots
+#define SPG_COEF     64   // dF/dV_o of the accepted trial (n_out <= 64)
+#define SPG_S        128  // normalisers s_o (1 or eps_o^2)
+#define SPG_STATE_DOUBLES 256
+#define SPG_MAX_OUT  64
+
+
+__device__ __forceinline__ void spg_wave_lds_sync()
+{   // one wavefront: its LDS operations execute in order; keep the compiler from moving them and drain the counter
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// objective of the trial from the per-output variances, nonmonotone Armijo test, safeguarded quadratic interpolation
+// (bluest/spg.py:9-35).  ONE wavefront (lane = 0..63): the state is staged through `ls` (SPG_STATE_DOUBLES doubles of LDS) with
+// coalesced loads, lane o handles output o, lane 0 takes the decision.  On the last slot of an iteration it also sets the
+// gate of the finishing launches.
+__device__ __forceinline__ void spg_decide_wave(double *__restrict__ st, const double *var, const int32_t *status, int n_out,
+                                                int last_slot, int32_t *__restrict__ enable, double *ls, int lane)
+{
+#pragma unroll
+    for (int t = 0; t < SPG_STATE_DOUBLES / 64; t++) ls[t * 64 + lane] = st[t * 64 + lane];
+    spg_wave_lds_sync();
+    const bool idle = ls[SPG_DONE] != 0.0 || ls[SPG_FAIL] != 0.0;
+    if (idle || ls[SPG_ACCEPT] != 0.0) {
+        if (last_slot && lane == 0) *enable = (!idle && ls[SPG_ACCEPT] != 0.0) ? 1 : 0;
+        return;
+    }
+    // objective F = || (V_o/s_o) ||_p / norm, coefficients dF/dV_o
+    const bool mine = lane < n_out;
+    const double so = mine ? ls[SPG_S + lane] : 1.0;
+    // agent-scope loads: in the fused form these values were written a moment ago by OTHER workgroups of the same launch
+    const double vo = mine ? __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(var) + lane,
+                                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+    const int32_t so_status = mine ? __hip_atomic_load(status + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : BLUEST_EVAL_OK;
+    const double r = mine ? vo / so : 0.0;
+    const bool bad = mine && (so_status != BLUEST_EVAL_OK || !isfinite(r));
+    const bool ok = __ballot(bad) == 0ull;
+    const double rmax = wave_max(mine ? r : -INFINITY);
+    const double p = ls[SPG_P], norm = ls[SPG_NORM];
+    double F = INFINITY, coef = 0.0;
+    if (ok) {
+        if (isinf(p) || n_out == 1) {
+            const unsigned long long is_max = __ballot(mine && r == rmax);
+            const int omax = __ffsll((long long)is_max) - 1;
+            F = rmax;
+            coef = (lane == omax) ? 1.0 / so : 0.0;
+        } else {
+            const double q = mine ? r / rmax : 0.0;
+            const double tq = mine ? pow(q, p - 1.0) : 0.0;       // q^(p-1); q^p = tq*q
+            const double tsum = wave_sum(tq * q);
+            const double root = pow(tsum, 1.0 / p);
+            F = rmax * root;
+            coef = tq * (root / tsum) / so;
+        }
+        F /= norm;
+    }
+    const int H = (int)ls[SPG_HLEN];
+    double fmax = -INFINITY;
+    for (int h = 0; h < H; h++) fmax = fmax > ls[SPG_HIST + h] ? fmax : ls[SPG_HIST + h];
+    const double alpha = ls[SPG_ALPHA], gd = ls[SPG_GD], f = ls[SPG_F];
+    const bool accept = F <= fmax + 1.0e-4 * alpha * gd;
+    if (accept && mine) st[SPG_COEF + lane] = coef / norm;
+    if (lane == 0) {
+        st[SPG_COUNT] = ls[SPG_COUNT] + 1.0;
+        st[SPG_FTRIAL] = F;
+        if (accept) {
+            st[SPG_ACCEPT] = 1.0;
+            st[SPG_FNEW] = F;
+        } else {
+            double a = alpha;
+            if (a <= 0.1) {
+                a *= 0.5;
+            } else {
+                double at = -0.5 * (a * a) * gd / (F - f - a * gd);
+                if (!(at >= 0.1) || at > 0.9 * a) at = 0.5 * a;   // also catches F = inf (at = -0) and NaN
+                a = at;
+            }
+            st[SPG_ALPHA] = a;
+            if (last_slot) st[SPG_FAIL] = 1.0;
+        }
+        if (last_slot) *enable = accept ? 1 : 0;
+    }
+}

@@ -65,9 +65,9 @@ class DeviceSpg(object):
         if with_trial:
             check(self.lib.bluest_spg_trial(self.x.data_ptr(), self.d.data_ptr(), self.scale.data_ptr(), self.st.data_ptr(),
                                             self.xnew.data_ptr(), self.m.data_ptr(), self.enable.data_ptr(), self.L, _stream()))
-        self.plan.eval(self.m, want_grad=False, out=(self.var, None, self.status))
-        check(self.lib.bluest_spg_decide(self.st.data_ptr(), self.var.data_ptr(), self.status.data_ptr(), self.n_out,
-                                         1 if t == self.T - 1 else 0, self.enable.data_ptr(), _stream()))
+        # Phi pass, then solve with the line-search decision fused into its tail (csrc/plan.hip: k_solve_from_chunks)
+        check(self.lib.bluest_plan_eval_decide(self.plan._h, self.m.data_ptr(), 0.0, self.var.data_ptr(), self.status.data_ptr(),
+                                               self.st.data_ptr(), 1 if t == self.T - 1 else 0, self.enable.data_ptr(), _stream()))
 
     def _slots(self):
         """T more trial points (host continuation of a line search that overflowed the T slots of the iteration)"""

@@ -212,6 +212,10 @@ int bluest_simplex_project(const double *x_dev, const double *g_dev, double lamb
  */
 #define BLUEST_SPG_STATE_DOUBLES 256
 int bluest_plan_set_gate(bluest_plan_t plan, const int32_t *enable_dev, int always_v);
+/* One line-search slot in two launches instead of three: bluest_plan_eval (value only, single candidate) with
+ * bluest_spg_decide fused into the tail of the solve kernel -- the output workgroup that finishes last evaluates the decision. */
+int bluest_plan_eval_decide(bluest_plan_t plan, const double *m_dev, double delta, double *var_dev, int32_t *status_dev,
+                            double *state_dev, int last_slot, int32_t *enable_dev, void *stream);
 int bluest_plan_v_workspace(bluest_plan_t plan, const double **v_dev, const int32_t **status_dev);
 int bluest_spg_direction(const double *x_dev, const double *g_dev, double *state_dev, double z, double floor, int64_t L,
                          double *d_dev, const double *scale_dev, double *xnew_dev, double *m_dev, int32_t *enable_dev,

@@ -14,6 +14,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """no test may run away: a hung GPU test would stall the whole run (the GPU box kills silent commands after 7 minutes)"""
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(330))
+
+
 def golden(name):
     return dict(np.load(os.path.join(GOLDEN, name)))
 

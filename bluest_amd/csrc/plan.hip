@@ -23,7 +23,7 @@
 #ifdef BLUEST_PHASE_TIMING   // experiment builds only (tools/phase_timing.py): 100 MHz timestamps of one workgroup's phases
 __device__ long long g_phase[3][12];
 #define PHASE(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1)) \
-        g_phase[blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 2 : 1)][i] = wall_clock64(); } while (0)
+        g_phase[blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 2 : 1)][i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int bluest_debug_phase_times(long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(long long) * 36) == hipSuccess ? 0 : 1; }
 // kernel spans in a chain of evaluations: [step % 16][kernel][begin, end] (min / max over a sample of workgroups)
 __device__ unsigned long long g_span[16][2][2];
@@ -159,25 +159,19 @@ __global__ __launch_bounds__(fold_threads(NT)) void k_solve_from_chunks(int N, i
                                                            const double2 *__restrict__ partial, int64_t n_chunks,
                                                            double delta, int want_v, double *__restrict__ var,
                                                            double *__restrict__ v, int32_t *__restrict__ status,
-                                                           const int32_t *__restrict__ gate, const int64_t *__restrict__ ocb, int staged,
-                                                           double *__restrict__ spg_state, int last_slot, int32_t *__restrict__ spg_enable,
+                                                           const int32_t *__restrict__ gate, double *__restrict__ spg_state, int last_slot, int32_t *__restrict__ spg_enable,
                                                            unsigned int *__restrict__ ticket)
 {
     __shared__ SolveLds<NT> lds;
     __shared__ double spg_ls[SPG_STATE_DOUBLES];
-    extern __shared__ double2 stage[];   // staged != 0: room for the partials of one output
     const int o = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
     if (gate && *gate == 0) {   // device-side predication (SPG line-search slots)
         // the line-search decision still has to close the slot (it sets the gate of the finishing launches on the last one)
         if (spg_state && o == 0 && c == 0 && tid < WAVE) spg_decide_wave(spg_state, var, status, n_out, last_slot, spg_enable, spg_ls, tid);
         return;
     }
-    RowDesc rd0 = rows[o * nsym + (((tid >> 2) < nsym) ? (tid >> 2) : 0)];      // in flight together with the staging copy
-    if (staged) stage_partials(stage, partial + (int64_t)c * n_chunks, ocb[o], (int)(ocb[o + 1] - ocb[o]), tid, fold_threads(NT));
-    clear_pads(lds, N, tid, fold_threads(NT));          // only when N < NT (every real entry is written by the fold)
-    if (staged || N < NT) __syncthreads();
-    if (staged) fold_rows(lds, N, rows, o * nsym, nsym, stage, ocb[o], tid, fold_threads(NT), &rd0);
-    else fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, 0, tid, fold_threads(NT));
+    if (N < NT) { clear_pads(lds, N, tid, fold_threads(NT)); __syncthreads(); }   // uniform; every real entry is written by the fold
+    fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, fold_threads(NT));
     __syncthreads();
     if (tid >= WAVE) return;   // single wavefront from here on
     const int lane = tid;
@@ -221,7 +215,7 @@ __global__ __launch_bounds__(fold_threads(NT)) void k_fold_to_record(int N, int 
 {
     __shared__ SolveLds<NT> lds;
     const int o = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
-    fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, 0, tid, fold_threads(NT));
+    fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, fold_threads(NT));
     __syncthreads();
     const int reclen = N * N + 2 * N + 1;
     double *r = rec + ((int64_t)c * n_out + o) * reclen;
@@ -292,9 +286,8 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
                                                     const double *__restrict__ tvals, const uint8_t *__restrict__ tidx,
                                                     double *__restrict__ var, double *__restrict__ v_ws,
                                                     int32_t *__restrict__ status, double *__restrict__ grad,
-                                                    const int32_t *__restrict__ gate, const int64_t *__restrict__ ocb, int staged)
+                                                    const int32_t *__restrict__ gate)
 {
-    extern __shared__ double2 stage[];   // staged != 0: room for the partials of one output
     constexpr int FUSED_TPB = fused_tpb(NT, KU);
     constexpr int NTHREADS = 64 * (FUSED_TPB + 1);
     constexpr int NE = KU * (KU + 1) / 2;
@@ -309,13 +302,9 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
     int o, first;
     if (bpo > 0) { o = blockIdx.x / bpo; first = (blockIdx.x % bpo) == 0; }
     else { const TileDesc td0 = tiles[t0]; o = td0.out; first = (td0.n_valid >> 30) & 1; }
-    RowDesc rd0 = rows[o * nsym + (((tid >> 2) < nsym) ? (tid >> 2) : 0)];      // in flight together with the staging copy
-    if (staged) stage_partials(stage, partial, ocb[o], (int)(ocb[o + 1] - ocb[o]), tid, NTHREADS);
-    clear_pads(lds, N, tid, NTHREADS);                  // only when N < NT (every real entry is written by the fold)
-    if (staged || N < NT) __syncthreads();
+    if (N < NT) { clear_pads(lds, N, tid, NTHREADS); __syncthreads(); }   // uniform; every real entry is written by the fold
     PHASE(1);
-    if (staged) fold_rows<NT>(lds, N, rows, o * nsym, nsym, stage, ocb[o], tid, NTHREADS, &rd0);
-    else fold_rows<NT>(lds, N, rows, o * nsym, nsym, partial, 0, tid, NTHREADS);
+    fold_rows<NT>(lds, N, rows, o * nsym, nsym, partial, tid, NTHREADS);
     // the list is padded to a multiple of FUSED_TPB tiles per output, so every tile of this workgroup belongs to output o
     // (loaded by the tile wavefronts only: the solving wavefront must not wait for a descriptor it does not use)
     TileDesc td;
@@ -1191,18 +1180,11 @@ static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_
     launch_chunks(plan, m_dev, n_cand, m_stride, st);
     int kmax = 0;
     for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
-    // the folding kernels CAN stage one output's chunk partials in LDS when they fit next to the solver's own LDS (default limit
-    // of dynamic LDS per workgroup: 64 KB)
-    const size_t want_stage = (size_t)plan->max_chunks_per_output * sizeof(double2);
-    // (opt-in, BLUEST_STAGED_FOLD=1: measured SLOWER at the headline size -- step 15.7 vs 15.3 us, value-only solve 6.6 vs
-    //  6.1 us: the LDS round trip and the extra barrier cost more than the dependent HBM round trip they replace)
-    const size_t stage_bytes = (want_stage <= 56 * 1024 && getenv("BLUEST_STAGED_FOLD")) ? want_stage : 0;
     // fused solve + gradient pass (2 launches per evaluation); groups larger than 12 take the generic tile code inside it
     if (grad_dev && n_cand == 1 && !g_debug_solve) {
         const dim3 grid((unsigned)(plan->n_tiles / plan->fused_tpb));
-#define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), stage_bytes, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, \
-                                        delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->d_tvals, plan->d_tidx, var_dev, plan->d_v, status, grad_dev, plan->gate, \
-                                        plan->d_out_chunk_begin, stage_bytes ? 1 : 0)
+#define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, \
+                                        delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->d_tvals, plan->d_tidx, var_dev, plan->d_v, status, grad_dev, plan->gate)
 #define LSG(NT) do { if (kmax <= 5) LSG2(NT, 5); else if (kmax <= 6) LSG2(NT, 6); else if (kmax <= 8) LSG2(NT, 8); else LSG2(NT, 12); } while (0)
         NT_DISPATCH(plan->N, LSG);
 #undef LSG
@@ -1211,9 +1193,9 @@ static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_
         return BLUEST_OK;
     }
     const int want = ((grad_dev || plan->always_v) ? 1 : 0) | g_debug_solve;
-#define LSC(NT) hipLaunchKernelGGL((k_solve_from_chunks<NT>), dim3(n_out, n_cand), dim3(fold_threads(NT)), stage_bytes, st, plan->N, n_out, plan->d_rows, \
+#define LSC(NT) hipLaunchKernelGGL((k_solve_from_chunks<NT>), dim3(n_out, n_cand), dim3(fold_threads(NT)), 0, st, plan->N, n_out, plan->d_rows, \
                                    plan->nsym, plan->d_partial, plan->n_chunks, delta, want, var_dev, plan->d_v, status, plan->gate, \
-                                   plan->d_out_chunk_begin, stage_bytes ? 1 : 0, dec_state, dec_last, dec_enable, plan->d_ticket)
+                                   dec_state, dec_last, dec_enable, plan->d_ticket)
     NT_DISPATCH(plan->N, LSC);
 #undef LSC
     if (grad_dev)

@@ -52,21 +52,17 @@ __device__ __forceinline__ double readlane_f64(double x, int l)
 // FOUR adjacent lanes share a row: lane q sums chunks q, q+4, q+8, ... (up to 8 independent loads in flight, so a row of
 // <= 32 chunks costs ONE memory round trip), then the quad combines as (s0+s1)+(s2+s3) -- a fixed order, so the result
 // is deterministic and identical in every kernel that folds.  nthreads must be a multiple of 4.
-// `partial` is indexed by GLOBAL chunk number minus `chunk_base`: either the partial array in HBM (chunk_base = 0) or a copy of
-// ONE output's partials staged in LDS by the caller (chunk_base = that output's first chunk) -- same values, same order of
-// additions, so both variants give identical bits; the staged one saves the second dependent HBM round trip (descriptor ->
-// partials) of every row.
-// `first`: the descriptor of this quad's first row (r = tid >> 2), loaded by the caller BEFORE its barrier so that the load
-// overlaps the staging copy; nullptr = load it here.
+// (Staging one output's partials in LDS first -- one coalesced copy, then the fold out of LDS -- was measured and rejected:
+//  step 15.7 vs 15.3 us at the headline size; the LDS round trip and the extra barrier cost more than the dependent HBM
+//  round trip descriptor -> partials they replace.)
 template <int NT>
 __device__ __forceinline__ void fold_rows(SolveLds<NT> &lds, int N, const RowDesc *__restrict__ rows, int row_begin,
-                                          int n_rows, const double2 *partial, int64_t chunk_base, int tid, int nthreads,
-                                          const RowDesc *first = nullptr)
+                                          int n_rows, const double2 *__restrict__ partial, int tid, int nthreads)
 {
     const int q = tid & 3;
     for (int r = tid >> 2; r < n_rows; r += nthreads >> 2) {
-        const RowDesc rd = (first && r == (tid >> 2)) ? *first : rows[row_begin + r];
-        const double2 *p = partial + ((int64_t)rd.first_chunk - chunk_base);
+        const RowDesc rd = rows[row_begin + r];
+        const double2 *p = partial + rd.first_chunk;
         const int n = rd.n_chunks;
         double s = 0.0, am = 0.0;
         for (int c0 = q; c0 < n; c0 += 32) {
@@ -86,12 +82,6 @@ __device__ __forceinline__ void fold_rows(SolveLds<NT> &lds, int N, const RowDes
             if (rd.a == rd.b) lds.amax[rd.a] = am;
         }
     }
-}
-
-// copy the partials of one output (chunks [cb, cb + n)) into LDS, coalesced; the caller synchronises
-__device__ __forceinline__ void stage_partials(double2 *stage, const double2 *__restrict__ partial, int64_t cb, int n, int tid, int nthreads)
-{
-    for (int i = tid; i < n; i += nthreads) stage[i] = partial[cb + i];
 }
 
 // single-wavefront LDS ordering: LDS operations of one wave execute in order; this only stops the compiler from
@@ -171,23 +161,23 @@ __device__ __forceinline__ void solve_wave(SolveLds<NT> &lds, int N, double delt
     unsigned long long vmask = 0ull;        // models for which vmine is meaningful
     int vswap = 0;
     const int p = lane < NT ? lane : NT - 1;          // lanes beyond NT shadow the last row (results unused)
-    if (!big) {
+    if (__builtin_expect(!big, 0)) {
         status = BLUEST_EVAL_INF;
         V = INFINITY;
-    } else if (mask1 == 0ull) {
+    } else if (__builtin_expect(mask1 == 0ull, 0)) {
         status = BLUEST_EVAL_NO_MODEL0;
         V = NAN;
     } else {
-        if (!(mask1 & 1ull)) status = BLUEST_EVAL_NO_MODEL0;
+        if (__builtin_expect(!(mask1 & 1ull), 0)) status = BLUEST_EVAL_NO_MODEL0;
         const int npass = (mask1 == mask2 || !want_v) ? 1 : 2;
         for (int pass = 0; pass < npass; pass++) {
             unsigned long long mask = (pass == 0) ? mask1 : mask2;
-            if (pass == 1 && !(mask & 1ull)) break;                     // row 0 of pinv(Phi) is zero
+            if (__builtin_expect(pass == 1 && !(mask & 1ull), 0)) break;                     // row 0 of pinv(Phi) is zero
             // target = smallest sampled model (model 0 unless it is unsampled: pinv(PHI[idx])[0,0] of misc.py:490 then
             // picks the first row of the restricted matrix); it must sit at the last position: swap models 0 <-> t
             const int t = __ffsll((long long)mask) - 1;
             int mp = NT - 1 - p;                                        // ORIGINAL model whose row this position holds
-            if (t != 0) {
+            if (__builtin_expect(t != 0, 0)) {
                 mp = (mp == 0) ? t : (mp == t ? 0 : mp);
                 mask = (mask | 1ull) & ~(1ull << t);                    // membership by POSITION index: bits 0 and t exchanged
             }
@@ -200,13 +190,13 @@ __device__ __forceinline__ void solve_wave(SolveLds<NT> &lds, int N, double delt
                 const double2 x = *reinterpret_cast<const double2 *>(row + c);
                 a[c] = x.x; a[c + 1] = x.y;
             }
-            if (t != 0) {   // column swap: position NT-1 <-> position NT-1-t
+            if (__builtin_expect(t != 0, 0)) {   // column swap: position NT-1 <-> position NT-1-t
 #pragma unroll
                 for (int c = 0; c < NT - 1; c++)
                     if (c == NT - 1 - t) { const double tmp = a[c]; a[c] = a[NT - 1]; a[NT - 1] = tmp; }
             }
             const unsigned long long smask = mask;                      // bit i: model at position NT-1-i is in the system
-            if (smask != all) {
+            if (__builtin_expect(smask != all, 0)) {
 #pragma unroll
                 for (int c = 0; c < NT; c++) {
                     const bool colin = (NT - 1 - c) < N && ((smask >> (NT - 1 - c)) & 1ull);
@@ -225,7 +215,7 @@ __device__ __forceinline__ void solve_wave(SolveLds<NT> &lds, int N, double delt
             PHASE(5);
             gj_regs<NT>(a, lane, diag0, rinv_mine, last_pivot, bad);
             PHASE(6);
-            if (uniform_i(bad)) {
+            if (__builtin_expect(uniform_i(bad) != 0, 0)) {
                 if (status == BLUEST_EVAL_OK) status = BLUEST_EVAL_SINGULAR;
                 if (pass == 0) V = NAN;
                 vmine = NAN; vmask = all; vswap = 0;

@@ -231,8 +231,56 @@ static void run(const char *name, int reps)
     hipFree(dA); hipFree(dout); hipFree(dc);
 }
 
+
+// ---- the product's whole solve_wave (masks, loads, elimination, v) from LDS, as the kernels call it ----
+template <int NT>
+__global__ __launch_bounds__(64) void k_wave(const double *__restrict__ A, int N, int reps, double *__restrict__ out, long long *__restrict__ cycles)
+{
+    __shared__ SolveLds<NT> lds;
+    const int lane = threadIdx.x;
+    clear_pads(lds, N, lane, 64);
+    __syncthreads();
+    for (int t = lane; t < N * N; t += 64) lds.at(t / N, t % N) = A[t];
+    if (lane < N) lds.amax[lane] = 1.0 + lane;
+    __syncthreads();
+    double acc = 0.0;
+    long long t0 = 0;
+    for (int rep = 0; rep < reps + 1; rep++) {
+        if (rep == 1) t0 = __builtin_amdgcn_s_memtime();
+        const double am = (lane < N) ? lds.amax[lane] : 0.0;
+        const bool big = __ballot(am >= 0.05) != 0ull;
+        double V = 0.0;
+        int32_t st = 0;
+        solve_wave<NT>(lds, N, acc * 1e-300, am > 1.0e-6, am > 0.0, big, true, &V, lds.vout, &st, lane);
+        acc += V + lds.vout[lane % N] + st;
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    out[lane] = acc;
+    if (lane == 0) cycles[0] = t1 - t0;
+}
+template <int NT>
+static void run_wave(int N, int reps)
+{
+    std::vector<double> G(N * N), A(N * N, 0.0);
+    srand(1);
+    for (auto &g : G) g = rand() / (double)RAND_MAX - 0.5;
+    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) { double s = (i == j) ? 1.0 : 0.0; for (int k = 0; k < N; k++) s += G[i * N + k] * G[j * N + k]; A[i * N + j] = s; }
+    double *dA, *dout; long long *dc;
+    hipMalloc(&dA, sizeof(double) * N * N); hipMalloc(&dout, sizeof(double) * 64); hipMalloc(&dc, 64);
+    hipMemcpy(dA, A.data(), sizeof(double) * N * N, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL((k_wave<NT>), dim3(1), dim3(64), 0, 0, dA, N, reps, dout, dc);
+    hipDeviceSynchronize();
+    long long c[8];
+    hipMemcpy(c, dc, 64, hipMemcpyDeviceToHost);
+    printf("solve_wave<%d> (N = %d), whole call: %8.1f cycles = %7.1f ns at 2.4 GHz\n", NT, N, (double)c[0] / reps, (double)c[0] / reps / 2.4);
+    hipFree(dA); hipFree(dout); hipFree(dc);
+}
+
 int main()
 {
+    run_wave<20>(20, 2000);
+    run_wave<26>(25, 2000);
+    run_wave<12>(12, 2000);
     const int reps = 2000;
     run<20, 0>("readlane (product)", reps);
     run<20, 1>("readlane, pipelined rcp", reps);

@@ -1,7 +1,8 @@
 """
 Experiment: per-phase timestamps of k_solve_grad workgroups (first / middle / last of the grid).  Needs a library built with
     BLUEST_EXTRA_HIPCC_FLAGS=-DBLUEST_PHASE_TIMING python -m bluest_amd.build --force
-(never the shipped build).  Prints phase durations in microseconds (100 MHz wall clock, 10 ns resolution).
+(never the shipped build).  Prints phase durations in microseconds (s_memtime = shader cycles, converted at 2.4 GHz; every
+stamp costs a few tens of cycles itself, far less than the s_memrealtime stamps used before).
 """
 import ctypes
 import os
@@ -30,7 +31,7 @@ for rep in range(30):
     assert L.bluest_debug_phase_times(t.ctypes.data) == 0
     if rep >= 5:
         acc.append(t.astype(np.float64))
-a = np.median(np.array(acc), axis=0) * 0.01   # us
+a = np.median(np.array(acc), axis=0) / 2400.0   # us (s_memtime counts shader cycles; 2.4 GHz)
 names = ["zero+desc", "fold", "solve", "grad tile"]
 for b, who in enumerate(["first wg", "middle wg", "last wg"]):
     print(who, "start %+.2f us (rel. first wg)" % (a[b, 0] - a[0, 0]), {names[i]: round(a[b, i + 1] - a[b, i], 2) for i in range(4)},

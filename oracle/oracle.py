@@ -430,21 +430,25 @@ def optimality_certificate(saps, m, costs, s=None, tol=1.0e-7, max_rounds=60, ve
         return res * (B * F) / w[:, None]
 
     blocks = {}
+    kmax = max(k for k in range(1, K + 1) if sap0.sizes[k])
 
-    def dense_blocks(idx):
-        """Qd[j, c] = B F R_i^T C_{i,o}^-1 R_i / w_i as an n x n matrix, for the groups i = idx[j] and the active outputs"""
-        Qd = np.zeros((len(idx), nA, N, N))
+    def sparse_blocks(idx):
+        """for the groups i = idx[j]: their models (padded with N, which addresses a zero appended to y) and, per active
+        output, the k x k block B F C_{i,o}^-1 / w_i (zero-padded to kmax x kmax)"""
+        gi = np.full((len(idx), kmax), N, dtype=np.int64)
+        bl = np.zeros((len(idx), nA, kmax, kmax))
         for j, i in enumerate(idx):
             if i not in blocks:
                 k = int(np.searchsorted(sap0.cumsizes, i, side="right"))
                 li = i - sap0.cumsizes[k - 1]
-                g = sap0.groups[k - 1][li]
-                blk = np.zeros((nA, N, N))
+                g = np.full(kmax, N, dtype=np.int64)
+                g[:k] = sap0.groups[k - 1][li]
+                b = np.zeros((nA, kmax, kmax))
                 for c, o in enumerate(act):
-                    blk[c][np.ix_(g, g)] = saps[o].invcovs[k - 1][li * k * k:(li + 1) * k * k].reshape(k, k) * (B * F / w[i])
-                blocks[i] = blk
-            Qd[j] = blocks[i]
-        return Qd
+                    b[c, :k, :k] = saps[o].invcovs[k - 1][li * k * k:(li + 1) * k * k].reshape(k, k) * (B * F / w[i])
+                blocks[i] = (g, b)
+            gi[j], bl[j] = blocks[i]
+        return gi, bl
 
     nY = nA * N
     state = {"work": np.zeros(0, dtype=np.int64), "Y": Y0.copy(), "solves": 0, "best": (-np.inf, None, None)}
@@ -479,16 +483,24 @@ def optimality_certificate(saps, m, costs, s=None, tol=1.0e-7, max_rounds=60, ve
             work = np.unique(np.concatenate([work, add]))
             if deadline is not None and time.time() > deadline:      # out of time: the best bound so far stays valid
                 break
-            Qd = dense_blocks(work)
+            gi, bl = sparse_blocks(work)
+            rows_j = np.arange(len(work))
 
-            def cons(xv, Qd=Qd):
-                Yv = xv[:nY].reshape(nA, N)
-                return xv[-1] - np.einsum("c,jcnm,cn,cm->j", a, Qd, Yv, Yv)
+            def cons(xv, gi=gi, bl=bl):
+                Yv = np.concatenate([xv[:nY].reshape(nA, N), np.zeros((nA, 1))], axis=1)
+                Yg = Yv[:, gi]                                                     # (nA, j, kmax)
+                t = np.einsum("jckl,cjl->cjk", bl, Yg)
+                return xv[-1] - np.einsum("c,cjk,cjk->j", a, t, Yg)
 
-            def cons_jac(xv, Qd=Qd):
-                Yv = xv[:nY].reshape(nA, N)
-                J = np.empty((len(Qd), nY + 1))
-                J[:, :nY] = (-2.0 * np.einsum("c,jcnm,cm->jcn", a, Qd, Yv)).reshape(len(Qd), nY)
+            def cons_jac(xv, gi=gi, bl=bl, rows_j=rows_j):
+                Yv = np.concatenate([xv[:nY].reshape(nA, N), np.zeros((nA, 1))], axis=1)
+                Yg = Yv[:, gi]
+                t = np.einsum("jckl,cjl->cjk", bl, Yg)                              # (nA, j, kmax): C^-1 y_g
+                J3 = np.zeros((len(gi), nA, N + 1))
+                for kk in range(kmax):
+                    np.add.at(J3, (rows_j[:, None], np.arange(nA)[None, :], gi[:, kk][:, None]), (-2.0 * a[:, None] * t[:, :, kk]).T)
+                J = np.empty((len(gi), nY + 1))
+                J[:, :nY] = J3[:, :, :N].reshape(len(gi), nY)
                 J[:, -1] = 1.0
                 return J
 

@@ -60,6 +60,7 @@ SIGNATURES = {
     "bluest_spg_update_fused": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp],
     "bluest_spg_finish": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp],
     "bluest_spg_update": [c_vp, c_vp, c_vp, c_vp, c_vp, c_f64, c_i64, c_vp, c_vp],
+    "bluest_spg_window": [c_vp] + [c_vp] * 14 + [c_f64, c_int, c_int, c_int, c_vp],
     "bluest_intproj_eval": [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp],
     "bluest_xchg_create": [ctypes.POINTER(c_vp), c_int, c_int, c_i64, c_vp],
     "bluest_xchg_connect": [c_vp, c_vp],

@@ -18,6 +18,7 @@ from itertools import combinations
 import numpy as np
 
 from .mosap import MOSAP
+from .host import in_host_section
 from .sap import BLUESTError
 
 default_params = {"verbose": True, "comm": None, "remove_uncorrelated": True, "optimization_solver": "spg", "sample_batch_size": 1}
@@ -187,6 +188,7 @@ class BLUEProblem(object):
         return out
 
     # ---- the path -------------------------------------------------------------------------------------------------------------
+    @in_host_section
     def setup_solver(self, K=4, budget=None, eps=None, groups=None, multi_groups=None, solver=None, continuous_relaxation=False,
                      max_model_samples=None, optimization_solver_params=None):
         """bluest/blue_models.py:448-538: returns {"models", "samples", "errors", "total_cost"}"""

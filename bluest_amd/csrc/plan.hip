@@ -394,7 +394,12 @@ static const size_t CACHE_CAP = 3ull << 30;
 
 static hipError_t pool_alloc(void **p, size_t bytes)
 {
-    const size_t want = (std::max<size_t>(bytes, 1) + 0x3ffff) & ~(size_t)0x3ffff;      // 256 KiB granules
+    size_t want = (std::max<size_t>(bytes, 1) + 0x3ffff) & ~(size_t)0x3ffff;            // 256 KiB granules
+    if (want <= (8u << 20)) {                  // small requests (restricted plans of the solver): power-of-two size classes, so
+        size_t cls = 512u << 10;               // that the next plan of a slightly different size reuses the block
+        while (cls < want) cls <<= 1;
+        want = cls;
+    }
     {
         std::lock_guard<std::mutex> lock(g_cache_mutex);
         auto it = g_cache.lower_bound(want);
@@ -577,11 +582,15 @@ extern "C" int bluest_plan_add_output(bluest_plan_t plan, int K, const int64_t *
                                       const double *invcovs, const int64_t *mapping)
 {
     OutputDesc od;
+    PhaseTimer timer("plan_add_output");
     int rc = plan_add_common(plan, K, sizes, groups, mapping, od);
     if (rc) return rc;
     if (!invcovs) return fail(BLUEST_ERR_ARG, "invcovs is NULL");
+    timer.lap("copy groups / mapping");
     if ((rc = output_to_device(plan, od))) { output_release(od); return rc; }
+    timer.lap("device buffers + groups upload");
     hipError_t e = hipMemcpy(od.d_invcov, invcovs, (size_t)od.n_inv * sizeof(double), hipMemcpyHostToDevice);
+    timer.lap("H2D inverses");
     if (e != hipSuccess) { output_release(od); HIP_TRY(e); }
     plan->outs.push_back(std::move(od));
     return BLUEST_OK;

@@ -1017,3 +1017,32 @@ extern "C" int bluest_spg_update(double *x_dev, double *g_dev, const double *xne
     return BLUEST_OK;
 }
 
+
+// A whole window of SPG iterations enqueued by ONE host call: direction (+ fused first trial point), T line-search slots
+// (trial point, Phi pass, solve + decision), gradient + update; the last iteration optionally followed by the convergence
+// projection.  Plain stream launches -- measured against replaying a captured hipGraph of the same sequence: the graph saves
+// ~1 us of dispatch per kernel, but capturing 18 graphs costs 13-55 ms per solve and DESTROYING them 60-80 ms, which the
+// runtime processes asynchronously inside whatever synchronises next (the "teardown stall" that kept landing in the next
+// set-up or solve).  20 iterations x 6-7 launches x ~2.5 us of host time stay well below the ~0.7-1.4 ms the GPU needs for them.
+extern "C" int bluest_spg_window(bluest_plan_t plan, double *x_dev, double *g_dev, double *d_dev, double *xnew_dev, double *m_dev,
+                                 const double *scale_dev, double *state_dev, double *var_dev, int32_t *status_dev, double *grad_dev,
+                                 int32_t *enable_dev, double *work_dev, double *proj_work_dev, const double *v_ws_dev,
+                                 double floor, int slots, int n_iterations, int check_last, void *stream)
+{
+    int rc = plan_ready(plan, 1); if (rc) return rc;
+    if (!x_dev || !g_dev || !d_dev || !xnew_dev || !m_dev || !scale_dev || !state_dev || !var_dev || !status_dev || !grad_dev ||
+        !enable_dev || !work_dev || !v_ws_dev)
+        return fail(BLUEST_ERR_ARG, "null pointer");
+    if (slots < 1 || slots > 8 || n_iterations < 0) return fail(BLUEST_ERR_ARG, "slots=%d, n_iterations=%d out of range", slots, n_iterations);
+    const int64_t L = plan->L;
+    for (int it = 0; it < n_iterations; it++) {
+        if ((rc = bluest_spg_direction(x_dev, g_dev, state_dev, 1.0, floor, L, d_dev, scale_dev, xnew_dev, m_dev, enable_dev, proj_work_dev, stream))) return rc;
+        for (int t = 0; t < slots; t++) {
+            if (t > 0 && (rc = bluest_spg_trial(x_dev, d_dev, scale_dev, state_dev, xnew_dev, m_dev, enable_dev, L, stream))) return rc;
+            if ((rc = bluest_plan_eval_decide(plan, m_dev, 0.0, var_dev, status_dev, state_dev, t == slots - 1 ? 1 : 0, enable_dev, stream))) return rc;
+        }
+        if ((rc = bluest_spg_finish(plan, v_ws_dev, status_dev, x_dev, g_dev, xnew_dev, grad_dev, scale_dev, state_dev, floor, work_dev, stream))) return rc;
+    }
+    if (check_last && (rc = bluest_spg_converged(x_dev, g_dev, state_dev, 1.0, floor, L, proj_work_dev, stream))) return rc;
+    return BLUEST_OK;
+}

@@ -10,6 +10,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .host import in_host_section
+
 
 def shard_bounds(sizes, world):
     """contiguous cuts of the size-major global group list, balanced by sum k^2 (the streamed bytes).
@@ -211,6 +213,7 @@ class ShardedPlan(object):
         return g
 
 
+@in_host_section
 def sharded_spg(sharded, costs, budget=None, eps=None, x0=None, params=None):
     """solver="spg" over a group-sharded plan: the host-driven SPG driver (bluest_amd.spg.spg = bluest/spg.py:39-132) with the
     scaled metric, every rank running the SAME deterministic iteration on replicated vectors (x, g, d of length K_tot);

@@ -7,12 +7,14 @@ All outputs share ONE device plan: a call to variances()/variance_GH() is one Ph
 (+ one gradient launch) for every output together, instead of the reference's serial loop over SAPS
 (bluest/mosap.py:86-100).
 """
+import weakref
+
 import numpy as np
 import torch
 
 from . import misc
 from .plan import EVAL_INF, EVAL_SINGULAR, Plan
-from .sap import BLUESTError, LazyIndicators, SAP, SpgAllocator, enforce_sample_caps, no_gc_pause, normalise_groups, status_to_python
+from .sap import BLUESTError, LazyIndicators, SAP, SpgAllocator, enforce_sample_caps, host_section, in_host_section, normalise_groups, status_to_python
 
 
 def _group_keys(gk, N):
@@ -103,7 +105,7 @@ class _SapView(SAP):
     single-output plan only if somebody calls it directly."""
 
     def __init__(self, parent, n):
-        self._parent, self._n = parent, n
+        self._parent_ref, self._n = weakref.ref(parent), n      # weak: MOSAP.SAPS -> view -> MOSAP would be a reference cycle
         self.verbose = parent.verbose
         self.C = parent.C[n]
         self.N = parent.N
@@ -123,25 +125,29 @@ class _SapView(SAP):
         self._plan = None
 
     @property
+    def _parent(self):
+        parent = self._parent_ref()
+        if parent is None:
+            raise ReferenceError("the MOSAP this per-output view belongs to no longer exists")
+        return parent
+
+    @property
     def plan(self):
         if self._plan is None:
             self._plan = Plan(self.N, self.L, [{"K": self.K, "sizes": self.sizes[1:], "groups": self.groups,
                                                 "invcovs": self.invcovs, "mapping": None}],
                               max_candidates=1, device=self._parent.plan.device)
-            self.get_variance_functions()
         return self._plan
+
+    @plan.setter
+    def plan(self, value):
+        self._plan = value
 
     def _inverse_source(self):
         return self._parent.plan.invcovs[self._n]
 
     def _inverse_plan(self):
         return self._parent.plan, self._n
-
-    def __getattr__(self, name):
-        if name in ("get_phi", "variance", "variance_GH"):
-            self.plan  # builds the closures
-            return self.__dict__[name]
-        raise AttributeError(name)
 
 
 class MOSAP(object):
@@ -161,7 +167,7 @@ class MOSAP(object):
         self.budget = None
         self.eps = None
         self.tot_cost = None
-        with no_gc_pause():
+        with host_section():
             self._build(C, K, Ks, groups, multi_groups, device, max_candidates)
 
     def _build(self, C, K, Ks, groups, multi_groups, device, max_candidates):
@@ -382,6 +388,7 @@ class MOSAP(object):
                 rhs.append(int(np.round(max_model_samples[i])))
         return es, rhs
 
+    @in_host_section
     def solve(self, budget=None, eps=None, solver="spg", x0=None, continuous_relaxation=False, max_model_samples=None,
               solver_params=None):
         """bluest/mosap.py:291-324 with solver="spg" """
@@ -405,10 +412,9 @@ class MOSAP(object):
             es.append(ee)
         alloc = SpgAllocator(self.plan, self.costs, es, verbose=False, subplan=self._restricted_plan)
         try:
-            with no_gc_pause():
-                samples = alloc.solve(budget=budget, eps=eps, x0=x0, params=solver_params)
-                self.solver_info = alloc.info
-                samples = enforce_sample_caps(self.plan, self.costs, cap_rows, cap_rhs, samples, budget, eps, solver_params, self)
+            samples = alloc.solve(budget=budget, eps=eps, x0=x0, params=solver_params)
+            self.solver_info = alloc.info
+            samples = enforce_sample_caps(self.plan, self.costs, cap_rows, cap_rhs, samples, budget, eps, solver_params, self)
         except BLUESTError as err:
             if self.verbose: print(str(err))
             self.samples = None

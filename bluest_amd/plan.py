@@ -34,14 +34,15 @@ def require_cuda():
 
 class _LazyInverses(object):
     def __init__(self, plan):
-        self._plan, self._cache = plan, {}
+        import weakref
+        self._plan_ref, self._cache = weakref.ref(plan), {}      # weak: plan -> this -> plan would be a reference cycle
 
-    def __len__(self): return self._plan.n_out
+    def __len__(self): return self._plan_ref().n_out
 
     def __getitem__(self, o):
         o = int(o)
         if o not in self._cache:
-            pl = self._plan
+            pl = self._plan_ref()
             ic = np.empty(pl._n_inv[o], dtype=np.float64)
             with torch.cuda.device(pl.device):
                 check(pl.lib.bluest_plan_get_invcovs(pl._h, o, ptr(ic)))

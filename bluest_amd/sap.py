@@ -9,6 +9,7 @@ import torch
 
 from . import misc
 from .plan import EVAL_INF, EVAL_NO_MODEL0, EVAL_OK, EVAL_SINGULAR, Plan, simplex_project
+from .host import host_section, in_host_section
 from .spg import spg
 
 spg_sap_default_params = {
@@ -58,23 +59,6 @@ spg_sap_default_params = {
 
 class BLUESTError(RuntimeError):
     pass
-
-
-class no_gc_pause(object):
-    """the constructors and solve() create ~1e5 short-lived Python objects (group lists, views); that is enough to trigger a
-    FULL pass of the cyclic collector, which in a process that has torch imported walks ~1e6 objects (30-70 ms, i.e. as long
-    as the whole set-up).  Inside these short sections the automatic collector is paused and the previous state restored."""
-
-    def __enter__(self):
-        import gc
-        self._was = gc.isenabled()
-        gc.disable()
-
-    def __exit__(self, *exc):
-        if self._was:
-            import gc
-            gc.enable()
-        return False
 
 
 def normalise_groups(groups, K, flatten=True):
@@ -522,7 +506,7 @@ class SAP(object):
         self.budget = None
         self.eps = None
         self.tot_cost = None
-        with no_gc_pause():
+        with host_section():
             self._build(C, K, groups, device, max_candidates)
 
     def _build(self, C, K, groups, device, max_candidates):
@@ -539,7 +523,6 @@ class SAP(object):
         self.ES = LazyIndicators(groups, self.N)
         self.e = self.ES[0]
         self._psi = None
-        self.get_variance_functions()
 
     @property
     def invcovs(self):
@@ -579,42 +562,39 @@ class SAP(object):
         return self._psi
 
     def get_variance_functions(self):
-        """bluest/sap.py:121-143: the operator boundary solvers call"""
-        plan = self.plan
+        """bluest/sap.py:121-143 creates the closures get_phi / variance / variance_GH here; in this class they are ordinary
+        methods (same names, same call shapes): a closure stored on the instance that refers back to the instance is a reference
+        cycle, and then the plan's HBM and the solver's hipGraphs live until the cyclic collector happens to run.  With methods
+        everything is released the moment the last reference to the SAP goes away."""
+        return self.get_phi, self.variance, self.variance_GH
 
-        def host(m):
-            return not isinstance(m, torch.Tensor)
+    def get_phi(self, m, delta=0):
+        """bluest/sap.py:131-132, bluest/misc.py:459-461"""
+        PHI = self.plan.phi_matrix(m, delta=delta)[0, 0]
+        return PHI if isinstance(m, torch.Tensor) else PHI.cpu().numpy()
 
-        def get_phi(m, delta=0):
-            PHI = plan.phi_matrix(m, delta=delta)[0, 0]
-            return PHI.cpu().numpy() if host(m) else PHI
+    def variance(self, m, delta=0):
+        """bluest/sap.py:133-134, bluest/misc.py:463-477"""
+        var, _, status = self.plan.eval(m, delta=delta, want_grad=False)
+        st = int(status[0, 0])
+        if st == EVAL_INF:
+            return np.inf
+        status_to_python(st, "variance")
+        return float(var[0, 0])
 
-        def variance(m, delta=0):
-            """bluest/misc.py:463-477"""
-            var, _, status = plan.eval(m, delta=delta, want_grad=False)
-            st = int(status[0, 0])
-            if st == EVAL_INF:
-                return np.inf
-            status_to_python(st, "variance")
-            return float(var[0, 0])
-
-        def variance_GH(m, delta=0, nohess=False):
-            """bluest/misc.py:479-505"""
-            var, grad, status = plan.eval(m, delta=delta, want_grad=True)
-            st = int(status[0, 0])
-            g = grad[0].cpu().numpy() if host(m) else grad[0]
-            if st == EVAL_INF:
-                return np.inf, g      # the reference returns a 2-tuple here (misc.py:484)
-            if st == EVAL_SINGULAR:
-                status_to_python(st, "variance_GH")
-            V = float(var[0, 0])
-            if nohess:
-                return V, g, None
-            return V, g, self._hessian(m, delta)
-
-        self.get_phi = get_phi
-        self.variance = variance
-        self.variance_GH = variance_GH
+    def variance_GH(self, m, delta=0, nohess=False):
+        """bluest/sap.py:135-136, bluest/misc.py:479-505"""
+        var, grad, status = self.plan.eval(m, delta=delta, want_grad=True)
+        st = int(status[0, 0])
+        g = grad[0] if isinstance(m, torch.Tensor) else grad[0].cpu().numpy()
+        if st == EVAL_INF:
+            return np.inf, g      # the reference returns a 2-tuple here (misc.py:484)
+        if st == EVAL_SINGULAR:
+            status_to_python(st, "variance_GH")
+        V = float(var[0, 0])
+        if nohess:
+            return V, g, None
+        return V, g, self._hessian(m, delta)
 
     def _restricted_plan(self, keep):
         """plan of this problem restricted to the groups `keep` (sorted global indices); the stored pseudo-inverses are reused"""
@@ -700,6 +680,7 @@ class SAP(object):
                 rhs.append(int(np.round(max_model_samples[i])))
         return es, rhs
 
+    @in_host_section
     def solve(self, budget=None, eps=None, solver="spg", x0=None, continuous_relaxation=False, max_model_samples=None,
               solver_params=None):
         """bluest/sap.py:189-220 with solver="spg" (the reference's cvxpy/cvxopt/ipopt/scipy back-ends are
@@ -718,11 +699,10 @@ class SAP(object):
 
         alloc = SpgAllocator(self.plan, self.costs, [self.e], verbose=False, subplan=self._restricted_plan)
         try:
-            with no_gc_pause():
-                samples = alloc.solve(budget=budget, eps=None if eps is None else [eps], x0=x0, params=solver_params)
-                self.solver_info = alloc.info
-                samples = enforce_sample_caps(self.plan, self.costs, es, rhs, samples, budget, None if eps is None else [eps],
-                                              solver_params, self)
+            samples = alloc.solve(budget=budget, eps=None if eps is None else [eps], x0=x0, params=solver_params)
+            self.solver_info = alloc.info
+            samples = enforce_sample_caps(self.plan, self.costs, es, rhs, samples, budget, None if eps is None else [eps],
+                                          solver_params, self)
         except BLUESTError as err:
             if self.verbose: print(str(err))
             self.samples = None

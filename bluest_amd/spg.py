@@ -11,6 +11,8 @@ The default solver path is the device-resident loop in spg_device.py; this file 
 """
 import numpy as np
 
+from .host import in_host_section
+
 # constants of the line search (bluest/spg.py:5-7)
 STEP_SHRINK_BELOW = 0.1      # below this step the search simply halves
 STEP_KEEP_FRACTION = 0.9     # an interpolated step above this fraction of the old one is replaced by half of it
@@ -100,6 +102,7 @@ class _Run(object):
         return {"x": self.x, "f": self.f, "gpmax": self.gpmax, "it": self.it, "count": self.count, "solver_info": info}
 
 
+@in_host_section
 def spg(feval, geval, proj, x, eps=1.0e-4, maxit=200, max_fevals=10 ** 5, verbose=True, lmbda_min=10. ** -30,
         lmbda_max=10. ** 30, Hlength=10, proj_step=None, callback=None, metric_dot=None):
     """bluest/spg.py:39-132: minimise feval over the set proj projects onto.

@@ -9,6 +9,7 @@ Same algorithm as bluest_amd.spg.spg with SpgAllocator's callbacks (tests/test_g
 iteration by iteration); this is what `solve(..., solver="spg")` runs by default.
 """
 import ctypes
+import time
 
 import numpy as np
 import torch
@@ -52,6 +53,7 @@ class DeviceSpg(object):
         check(self.lib.bluest_plan_v_workspace(plan._h, ctypes.byref(v), None))
         self.v_ws = v.value
         self.graph_sets = {}          # hipGraphs per number of in-iteration line-search slots
+        self.window_seconds = []
         self.graphs = None
 
     # ---- launch sequences (captured into hipGraphs) -------------------------------------------------------------
@@ -93,6 +95,14 @@ class DeviceSpg(object):
     def _iteration_checked(self):
         self._iteration()
         self._converged()
+
+    def _window_direct(self, n_iterations, check_last):
+        """n whole iterations (+ the convergence projection) enqueued by ONE call into the library: plain stream launches"""
+        check(self.lib.bluest_spg_window(self.plan._h, self.x.data_ptr(), self.g.data_ptr(), self.d.data_ptr(), self.xnew.data_ptr(),
+                                         self.m.data_ptr(), self.scale.data_ptr(), self.st.data_ptr(), self.var.data_ptr(),
+                                         self.status.data_ptr(), self.grad.data_ptr(), self.enable.data_ptr(), self.work.data_ptr(),
+                                         self.pws.data_ptr(), self.v_ws, self.floor, self.T, int(n_iterations), 1 if check_last else 0,
+                                         _stream()))
 
     def _window(self):
         """check_every iterations, the last one with the convergence projection: ONE graph replay per host look
@@ -142,8 +152,13 @@ class DeviceSpg(object):
         t = (r / rmax) ** self.p
         return rmax * t.sum() ** (1.0 / self.p), (r / rmax) ** (self.p - 1) * t.sum() ** (1.0 / self.p - 1.0) / self.s_norm
 
-    def run(self, x0, eps=1e-7, maxit=2000, max_fevals=10 ** 6, use_graph=True, rel_tol=0.0, stall_window=100):
+    def run(self, x0, eps=1e-7, maxit=2000, max_fevals=10 ** 6, use_graph=None, rel_tol=0.0, stall_window=100):
+        """use_graph: None = the default (direct launches of a whole window by one library call; BLUEST_SPG_GRAPH=1 in the
+        environment selects hipGraph replay), True = captured hipGraphs, False = direct launches"""
         plan, lib, st = self.plan, self.lib, self.st
+        if use_graph is None:
+            import os
+            use_graph = bool(os.environ.get("BLUEST_SPG_GRAPH"))
         with torch.cuda.device(self.dev):
             check(lib.bluest_plan_set_gate(plan._h, None, 0))
             if not isinstance(x0, torch.Tensor):
@@ -175,8 +190,8 @@ class DeviceSpg(object):
                     """launchers for the current number of slots self.T; every hipGraph is captured when it is first needed
                     (the continuation graphs `slots` / `finish` only if a line search ever overflows its slots)"""
                     if not use_graph:
-                        self.run_window = self._window
-                        return self._iteration, self._slots, self._finish, self._iteration_checked
+                        return (lambda: self._window_direct(1, False), self._slots, self._finish, lambda: self._window_direct(1, True),
+                                lambda: self._window_direct(self.check_every, True))
                     gs = self.graph_sets.setdefault(self.T, {})
 
                     def lazy(name, fn):
@@ -186,11 +201,10 @@ class DeviceSpg(object):
                             gs[name].replay()
                         return replay
                     self.graphs = gs
-                    self.run_window = lazy("window", self._window)
                     return (lazy("iteration", self._iteration), lazy("slots", self._slots), lazy("finish", self._finish),
-                            lazy("iteration_checked", self._iteration_checked))
+                            lazy("iteration_checked", self._iteration_checked), lazy("window", self._window))
 
-                run_iter, run_slots, run_finish, run_iter_checked = bind()
+                run_iter, run_slots, run_finish, run_iter_checked, run_window = bind()
                 fail_windows = []                                   # did the host have to continue a line search, per window
                 info, it, count = 1, 0, 1
                 stalled = False
@@ -212,13 +226,15 @@ class DeviceSpg(object):
                         info = 1
                         break
                     nrun = min(self.check_every, maxit - it)
+                    t_window = time.perf_counter()
                     if nrun == self.check_every:
-                        self.run_window()                       # the whole window is one graph
+                        run_window()                            # the whole window is one graph
                     else:
                         for _ in range(nrun - 1):
                             run_iter()
                         run_iter_checked()                      # last one also measures gpmax (sets DONE when <= eps)
                     hs = st.cpu().numpy()
+                    self.window_seconds.append(time.perf_counter() - t_window)      # host-visible time of the window (diagnostics)
                     fail_windows.append(hs[FAIL] != 0.0)
                     while hs[FAIL] != 0.0:                       # rare: more than T trial points needed
                         if hs[ALPHA] < 1e-300 or hs[COUNT] >= max_fevals:
@@ -242,7 +258,7 @@ class DeviceSpg(object):
                     # (3 of 10 measured better than 6 of 10: 92 vs 125 us per iteration at the headline size)
                     if self.T == 1 and sum(fail_windows[-10:]) >= 3:
                         self.T = 2
-                        run_iter, run_slots, run_finish, run_iter_checked = bind()
+                        run_iter, run_slots, run_finish, run_iter_checked, run_window = bind()
                     # line search in trouble: >= 8 trial points per iteration over at least 5 iterations (not just the first
                     # iteration after a restart, whose re-initialised step is expected to backtrack) and nothing gained --
                     # the iterate is stationary to rounding (typical for a restart from an already converged point)

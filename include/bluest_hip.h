@@ -239,6 +239,15 @@ int bluest_spg_finish(bluest_plan_t plan, const double *v_dev, const int32_t *st
                       const double *xnew_dev, double *grad_dev, const double *scale_dev, double *state_dev, double floor,
                       double *work_dev, void *stream);
 
+/* n_iterations whole SPG iterations (bluest_spg_direction, `slots` x [bluest_spg_trial,] bluest_plan_eval_decide,
+ * bluest_spg_finish), then bluest_spg_converged if check_last: one host call enqueues the launch sequence of a whole window on
+ * `stream`.  Arguments as in the calls it is made of; v_ws_dev from bluest_plan_v_workspace; proj_work_dev as work_dev of
+ * bluest_simplex_project (may be NULL for L <= 4096). */
+int bluest_spg_window(bluest_plan_t plan, double *x_dev, double *g_dev, double *d_dev, double *xnew_dev, double *m_dev,
+                      const double *scale_dev, double *state_dev, double *var_dev, int32_t *status_dev, double *grad_dev,
+                      int32_t *enable_dev, double *work_dev, double *proj_work_dev, const double *v_ws_dev, double floor, int slots,
+                      int n_iterations, int check_last, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Part 4 -- integer projection batch (bluest/misc.py:228-311 multi, :313-382 single)
  *

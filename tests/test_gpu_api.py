@@ -480,3 +480,39 @@ def test_max_model_samples_under_spg(oracle):
     assert m_cap is not None and all(e @ m_cap <= r * (1 + 1e-9) for e, r in zip(es, rhs))
     assert (np.array(mos.variances(m_cap)) <= eps ** 2 * (1 + 1e-6)).all()
     assert m_free @ w * (1 - 1e-6) <= m_cap @ w <= m_free @ w * 3.0
+
+
+def test_dropping_a_problem_releases_everything_without_the_cyclic_collector():
+    """SAP / MOSAP / the solver objects hold no reference cycles: when the last reference goes, the plan's HBM and the captured
+    hipGraphs are released at once (reference counting), not whenever a full garbage collection happens to run"""
+    import ctypes
+    import gc
+    import weakref
+    from bluest_amd import spg_device
+    from bluest_amd.mosap import MOSAP
+    n, kmax, n_out = 10, 3, 3
+    prob = synth.problem(n, kmax, n_out)
+    groups = prob["groups"]
+    solvers = []
+    orig = spg_device.DeviceSpg.__init__
+
+    def spy(self, *a, **k):
+        orig(self, *a, **k)
+        solvers.append(weakref.ref(self))
+
+    gc.collect()
+    gc.disable()
+    spg_device.DeviceSpg.__init__ = spy
+    try:
+        mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in groups] for _ in range(n_out)],
+                    prob["costs"], [prob["costs"]] * n_out, verbose=False)
+        m = mos.solve(budget=prob["budget"], solver="spg", continuous_relaxation=True)
+        assert m is not None and len(solvers) >= 1
+        _ = mos.SAPS[1].variance(m[mos.mappings[1]]), mos.SAPS[0].invcovs       # per-output views with their own lazy plans
+        refs = [weakref.ref(mos), weakref.ref(mos.plan), weakref.ref(mos.SAPS[1]), weakref.ref(mos.SAPS[1].plan)]
+        del mos
+        assert all(r() is None for r in refs), [r() for r in refs]
+        assert all(r() is None for r in solvers)
+    finally:
+        spg_device.DeviceSpg.__init__ = orig
+        gc.enable()

@@ -24,7 +24,21 @@ def timed(cls, name, label):
     setattr(cls, name, wrap)
 
 
-timed(spg_device.DeviceSpg, "_capture", "graph capture")
+names = []
+_orig_capture = spg_device.DeviceSpg._capture
+
+
+def _cap(self, fn):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g = _orig_capture(self, fn)
+    torch.cuda.synchronize()
+    names.append((fn.__name__, self.T, self.L, round((time.perf_counter() - t0) * 1e3, 2)))
+    acc.setdefault("graph capture", []).append(time.perf_counter() - t0)
+    return g
+
+
+spg_device.DeviceSpg._capture = _cap
 timed(spg_device.DeviceSpg, "run", "DeviceSpg.run (incl. captures)")
 timed(spg_device.DeviceSpg, "__init__", "DeviceSpg.__init__")
 timed(MOSAP, "_restricted_plan", "restricted plan")
@@ -41,3 +55,11 @@ for rep in range(3):
           "; ".join("%s: %d calls %.1f ms" % (k, len(v), sum(v) * 1e3) for k, v in acc.items()), flush=True)
     runs = acc.get("DeviceSpg.run (incl. captures)", [])
     print("   runs (ms):", [round(x * 1e3, 1) for x in runs])
+    print("   captured:", names)
+    del names[:]
+    t0 = time.perf_counter()
+    mos = None
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    print("   release %.1f ms" % ((time.perf_counter() - t0) * 1e3))

@@ -42,7 +42,6 @@ for rep in range(4):
         for s in solvers:
             s.graph_sets = {}
             s.graphs = None
-            s.run_window = None
     del solvers[:]
     torch.cuda.synchronize()
     t3 = time.perf_counter()

@@ -7,6 +7,19 @@
 // ------------------------------------------------------------------------------------------------------
 // Part 3 -- simplex projection (single workgroup of 1024 threads)
 // ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool proj_idle(const double *spg_state) { return spg_state && (spg_state[SPG_DONE] != 0.0 || spg_state[SPG_FAIL] != 0.0); }
+// direction launches (spg_mode 1) while a line search is pending: no new direction, the next trial point instead
+__device__ __forceinline__ bool proj_pending(const double *spg_state, int spg_mode) { return spg_state && spg_mode == 1 && spg_state[SPG_PENDING] != 0.0; }
+
+// the next trial point of a pending line search, element i: xnew = x + alpha*d, m = scale*xnew (bluest/spg.py:13,28)
+__device__ __forceinline__ void spg_trial_point(int64_t i, double alpha, const double *__restrict__ x, const double *d,
+                                                const double *__restrict__ scale, double *__restrict__ xnew, double *__restrict__ m)
+{
+    const double xn = fma(alpha, d[i], x[i]);
+    xnew[i] = xn;
+    m[i] = scale[i] * xn;
+}
+
 // xnew = x + alpha*d, m = scale*xnew for the next line-search slot; sets the plan gate (bluest/spg.py:13,28)
 __global__ __launch_bounds__(1024) void k_spg_trial(const double *__restrict__ x, const double *__restrict__ d,
                                                     const double *__restrict__ scale, const double *__restrict__ st,
@@ -93,16 +106,64 @@ __device__ __forceinline__ void block_sum2_cnt(double &x, double &y, long long &
 }
 
 // accept the step (bluest/spg.py:85-106), two launches:
-//  A (multi-block): s = xnew - x, y = gnew - g, per-block partial sums of s^T D^-1 s (D = diag(max(x,floor))) and s.y,
-//                   x <- xnew, g <- gnew;
-//  B (one wavefront): fixed-order sum of the partials, Barzilai-Borwein lambda, history, reset of the line-search state.
+// Barzilai-Borwein bookkeeping after an accepted step, one wavefront: fixed-order sum of the per-workgroup partials of
+// s^T D^-1 s and s.y, the new spectral step, history, reset of the line-search state (bluest/spg.py:100-120).
+__device__ __forceinline__ void spg_update_tail(double *__restrict__ st, const double2 *partial, int nblocks, int lane)
+{
+    double a = 0.0, b = 0.0;
+    for (int t = lane; t < nblocks; t += 64) {
+        const unsigned long long *q = reinterpret_cast<const unsigned long long *>(partial + t);
+        a += __longlong_as_double((long long)__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        b += __longlong_as_double((long long)__hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    const double sdots = wave_sum(a), sdoty = wave_sum(b);
+    if (lane == 0) {
+        st[SPG_SDOTS] = sdots;
+        st[SPG_SDOTY] = sdoty;
+        const double lmin = st[SPG_LMIN], lmax = st[SPG_LMAX], fnew = st[SPG_FNEW];
+        st[SPG_LAMBDA] = (sdoty <= 0.0) ? lmax : fmin(lmax, fmax(lmin, sdots / sdoty));
+        const double it = st[SPG_IT] + 1.0;
+        st[SPG_IT] = it;
+        st[SPG_F] = fnew;
+        const int H = (int)st[SPG_HLEN];
+        st[SPG_HIST + ((long long)it % H)] = fnew;
+        st[SPG_ALPHA] = 1.0;
+        st[SPG_ACCEPT] = 0.0;
+    }
+}
+
+// The workgroups of an update launch publish their partial sums, take a ticket, and the LAST one to arrive runs the tail above:
+// no second launch (same publication protocol as the decision in the tail of k_solve_from_chunks, csrc/plan.hip).
+__device__ __forceinline__ void spg_update_publish(double *__restrict__ st, double2 *__restrict__ partial, double sdots, double sdoty,
+                                                   int tid, int *s_last)
+{
+    if (tid == 0) {
+        partial[blockIdx.x] = make_double2(sdots, sdoty);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned int *ticket = reinterpret_cast<unsigned int *>(st + SPG_TICKET);
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == gridDim.x - 1u) ? 1 : 0;
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+        *s_last = last;
+    }
+    __syncthreads();
+    if (!*s_last || tid >= 64) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    spg_update_tail(st, partial, (int)gridDim.x, tid);
+}
+
+//  update launch (multi-block): s = xnew - x, y = gnew - g, per-block partial sums of s^T D^-1 s (D = diag(max(x,floor))) and
+//  s.y, x <- xnew, g <- gnew; the last workgroup to finish runs spg_update_tail.
 #define SPG_UPD_BLOCKS_MAX 512
 __global__ __launch_bounds__(1024) void k_spg_update_a(double *__restrict__ x, double *__restrict__ g,
                                                        const double *__restrict__ xnew, const double *__restrict__ gnew,
-                                                       const double *__restrict__ st, double floor, int64_t L,
+                                                       double *__restrict__ st, double floor, int64_t L,
                                                        double2 *__restrict__ partial)
 {
     __shared__ ProjLds sm;
+    __shared__ int s_last;
     int ph = 0;
     const int tid = threadIdx.x;
     if (st[SPG_DONE] != 0.0 || st[SPG_FAIL] != 0.0 || st[SPG_ACCEPT] == 0.0) return;
@@ -117,7 +178,7 @@ __global__ __launch_bounds__(1024) void k_spg_update_a(double *__restrict__ x, d
         g[i] = gn;
     }
     block_sum2_cnt(sdots, sdoty, dummy, sm, tid, ph);
-    if (tid == 0) partial[blockIdx.x] = make_double2(sdots, sdoty);
+    spg_update_publish(st, partial, sdots, sdoty, tid, &s_last);
 }
 
 // A with the gradient fold fused in: gnew_j = scale_j * sum_o coef_o * grad_o[local_o(j)] is formed on the fly (no gnew
@@ -126,10 +187,11 @@ __global__ __launch_bounds__(1024) void k_spg_update_a_fused(double *__restrict_
                                                              const double *__restrict__ xnew, const double *__restrict__ grad,
                                                              const int64_t *__restrict__ goff, const int32_t *__restrict__ invmap,
                                                              int n_out, const double *__restrict__ scale,
-                                                             const double *__restrict__ st, double floor, int64_t L,
+                                                             double *__restrict__ st, double floor, int64_t L,
                                                              double2 *__restrict__ partial)
 {
     __shared__ ProjLds sm;
+    __shared__ int s_last;
     int ph = 0;
     const int tid = threadIdx.x;
     if (st[SPG_DONE] != 0.0 || st[SPG_FAIL] != 0.0 || st[SPG_ACCEPT] == 0.0) return;
@@ -150,37 +212,12 @@ __global__ __launch_bounds__(1024) void k_spg_update_a_fused(double *__restrict_
         g[i] = gn;
     }
     block_sum2_cnt(sdots, sdoty, dummy, sm, tid, ph);
-    if (tid == 0) partial[blockIdx.x] = make_double2(sdots, sdoty);
-}
-
-__global__ __launch_bounds__(64) void k_spg_update_b(double *__restrict__ st, const double2 *__restrict__ partial, int nblocks)
-{
-    __shared__ double ls[64];
-    const int lane = threadIdx.x;
-    ls[lane] = st[lane];          // scalars live in st[0..63]
-    __syncthreads();
-    if (ls[SPG_DONE] != 0.0 || ls[SPG_FAIL] != 0.0 || ls[SPG_ACCEPT] == 0.0) return;
-    double a = 0.0, b = 0.0;
-    for (int t = lane; t < nblocks; t += 64) { const double2 q = partial[t]; a += q.x; b += q.y; }
-    const double sdots = wave_sum(a), sdoty = wave_sum(b);
-    if (lane == 0) {
-        st[SPG_SDOTS] = sdots;
-        st[SPG_SDOTY] = sdoty;
-        const double lmin = ls[SPG_LMIN], lmax = ls[SPG_LMAX];
-        st[SPG_LAMBDA] = (sdoty <= 0.0) ? lmax : fmin(lmax, fmax(lmin, sdots / sdoty));
-        const double it = ls[SPG_IT] + 1.0;
-        st[SPG_IT] = it;
-        st[SPG_F] = ls[SPG_FNEW];
-        const int H = (int)ls[SPG_HLEN];
-        st[SPG_HIST + ((long long)it % H)] = ls[SPG_FNEW];
-        st[SPG_ALPHA] = 1.0;
-        st[SPG_ACCEPT] = 0.0;
-    }
+    spg_update_publish(st, partial, sdots, sdoty, tid, &s_last);
 }
 
 // Small plans (K_tot <= 4096, a few hundred gradient tiles: the working set of the solver): the accepted step's gradient tiles,
 // the fused gradient fold + update and the Barzilai-Borwein bookkeeping in ONE single-workgroup kernel instead of three launches
-// (k_grad_tiles, k_spg_update_a_fused, k_spg_update_b) -- at this size every launch is pure latency.
+// (k_grad_tiles, k_spg_update_a_fused) -- at this size every launch is pure latency.
 template <int KU>
 __global__ __launch_bounds__(1024) void k_spg_finish_small(const TileDesc *__restrict__ tiles, int64_t n_tiles,
                                                            const double *__restrict__ tvals, const uint8_t *__restrict__ tidx,
@@ -226,7 +263,7 @@ __global__ __launch_bounds__(1024) void k_spg_finish_small(const TileDesc *__res
         g[i] = gn;
     }
     block_sum2_cnt(sdots, sdoty, dummy, sm, tid, ph);
-    // (3) Barzilai-Borwein step, history, reset of the line-search state (as k_spg_update_b)
+    // (3) Barzilai-Borwein step, history, reset of the line-search state (as spg_update_tail)
     if (tid == 0) {
         const double lmin = st[SPG_LMIN], lmax = st[SPG_LMAX], fnew = st[SPG_FNEW];
         st[SPG_SDOTS] = sdots;
@@ -265,6 +302,13 @@ __global__ __launch_bounds__(SIMPLEX_BLOCK) void k_simplex(const double *__restr
     if (spg_state) {   // device-resident SPG: a finished / failed run is a no-op
         if (spg_state[SPG_DONE] != 0.0 || spg_state[SPG_FAIL] != 0.0) {
             if (enable && tid == 0) *enable = 0;
+            return;
+        }
+        if (proj_pending(spg_state, spg_mode)) {   // line search pending: the next trial point instead of a new direction
+            if (!xnew) return;                     // (without the fused trial outputs the caller launches bluest_spg_trial)
+            const double alpha = spg_state[SPG_ALPHA];
+            for (int64_t i = tid; i < L; i += SIMPLEX_BLOCK) spg_trial_point(i, alpha, x, d, scale, xnew, mtrial);
+            if (tid == 0) *enable = 1;
             return;
         }
         if (spg_mode == 1) lambda = spg_state[SPG_LAMBDA];   // direction: the step length lives in HBM
@@ -379,7 +423,6 @@ struct ProjWs {            // layout of the caller-provided workspace (doubles)
     static __host__ __device__ int64_t total(int64_t L, int nb) { return sync_off(L, nb) + FusedProj::DOUBLES; }
 };
 
-__device__ __forceinline__ bool proj_idle(const double *spg_state) { return spg_state && (spg_state[SPG_DONE] != 0.0 || spg_state[SPG_FAIL] != 0.0); }
 
 __global__ __launch_bounds__(1024) void k_proj_a(const double *__restrict__ x, const double *__restrict__ g, double lambda,
                                                  double floor, int64_t L, double *__restrict__ ws, int nb,
@@ -387,7 +430,7 @@ __global__ __launch_bounds__(1024) void k_proj_a(const double *__restrict__ x, c
 {
     __shared__ ProjLds sm;
     int ph = 0;
-    if (proj_idle(spg_state)) return;
+    if (proj_idle(spg_state) || proj_pending(spg_state, spg_mode)) return;
     if (spg_state && spg_mode == 1) lambda = spg_state[SPG_LAMBDA];
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
@@ -436,7 +479,7 @@ __global__ __launch_bounds__(1024) void k_proj_b(double z, double floor, int64_t
 {
     __shared__ ProjLds sm;
     int ph = 0;
-    if (proj_idle(spg_state)) return;
+    if (proj_idle(spg_state) || proj_pending(spg_state, mode)) return;
     const int tid = threadIdx.x;
     double rmax = -INFINITY;
     for (int b = tid; b < nb; b += 1024) rmax = fmax(rmax, ws[ProjWs::part_off(L) + 4LL * b]);
@@ -495,7 +538,7 @@ __global__ __launch_bounds__(1024) void k_proj_b(double z, double floor, int64_t
 __global__ __launch_bounds__(64) void k_proj_q0(double z, double floor, int64_t L, double *__restrict__ ws, int nb,
                                                 const double *__restrict__ spg_state, int mode)
 {
-    if (proj_idle(spg_state)) return;
+    if (proj_idle(spg_state) || proj_pending(spg_state, mode)) return;
     const int lane = threadIdx.x;
     double rmax = -INFINITY;
     for (int b = lane; b < nb; b += 64) rmax = fmax(rmax, ws[ProjWs::part_off(L) + 4LL * b]);
@@ -512,11 +555,12 @@ __global__ __launch_bounds__(64) void k_proj_q0(double z, double floor, int64_t 
     }
 }
 
-__global__ __launch_bounds__(1024) void k_proj_p(int64_t L, double *__restrict__ ws, int nb, const double *__restrict__ spg_state)
+__global__ __launch_bounds__(1024) void k_proj_p(int64_t L, double *__restrict__ ws, int nb, const double *__restrict__ spg_state,
+                                                 int mode)
 {
     __shared__ ProjLds sm;
     int ph = 0;
-    if (proj_idle(spg_state)) return;
+    if (proj_idle(spg_state) || proj_pending(spg_state, mode)) return;
     const double *t = ws + ProjWs::tau_off(L, nb);
     if (t[3] != 0.0) return;
     const double tau = t[0], rmax = t[1];
@@ -539,7 +583,7 @@ __global__ __launch_bounds__(1024) void k_proj_p(int64_t L, double *__restrict__
 __global__ __launch_bounds__(64) void k_proj_q(double z, int64_t L, double *__restrict__ ws, int nb, const double *__restrict__ spg_state,
                                                int mode)
 {
-    if (proj_idle(spg_state)) return;
+    if (proj_idle(spg_state) || proj_pending(spg_state, mode)) return;
     double *t = ws + ProjWs::tau_off(L, nb);
     if (t[3] != 0.0) return;
     const int lane = threadIdx.x;
@@ -564,7 +608,7 @@ __global__ __launch_bounds__(1024) void k_proj_b_finish(double z, int64_t L, dou
 {
     __shared__ ProjLds sm;
     int ph = 0;
-    if (proj_idle(spg_state)) return;
+    if (proj_idle(spg_state) || proj_pending(spg_state, mode)) return;
     double *t = ws + ProjWs::tau_off(L, nb);
     if (t[3] != 0.0) return;
     const int tid = threadIdx.x;
@@ -592,11 +636,16 @@ __global__ __launch_bounds__(1024) void k_proj_b_finish(double z, int64_t L, dou
 __global__ __launch_bounds__(1024) void k_proj_c(const double *__restrict__ x, const double *__restrict__ g, int64_t L,
                                                  double *__restrict__ ws, int nb, double *__restrict__ p, double *__restrict__ d,
                                                  const double *__restrict__ scale, double *__restrict__ xnew,
-                                                 double *__restrict__ mtrial, const double *__restrict__ spg_state)
+                                                 double *__restrict__ mtrial, const double *__restrict__ spg_state, int mode)
 {
     __shared__ ProjLds sm;
     int ph = 0;
     if (proj_idle(spg_state)) return;
+    if (proj_pending(spg_state, mode)) {   // line search pending: the next trial point instead of a new direction
+        const int64_t j = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+        if (xnew && j < L) spg_trial_point(j, spg_state[SPG_ALPHA], x, d, scale, xnew, mtrial);
+        return;
+    }
     const int tid = threadIdx.x;
     const double tau = ws[ProjWs::tau_off(L, nb)], rmax = ws[ProjWs::tau_off(L, nb) + 1];
     const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
@@ -626,6 +675,7 @@ __global__ __launch_bounds__(64) void k_proj_d(int64_t L, const double *__restri
 {
     const int lane = threadIdx.x;
     if (proj_idle(spg_state)) { if (enable && lane == 0) *enable = 0; return; }
+    if (proj_pending(spg_state, spg_mode)) { if (enable && lane == 0) *enable = 1; return; }
     double gd = 0.0, dm = 0.0, np = 0.0;
     for (int b = lane; b < nb; b += 64) {
         const double *pp = ws + ProjWs::part_off(L) + 4LL * b;
@@ -702,6 +752,17 @@ __global__ __launch_bounds__(1024) void k_proj_fused(const double *__restrict__ 
     double *sy = ws + ProjWs::sync_off(L, nb_ws);
     if (proj_idle(spg_state) || t[12] != 0.0) {   // t[12]: sticky "a wait timed out" flag
         if (enable && b == 0 && tid == 0) *enable = 0;
+        return;
+    }
+    if (proj_pending(spg_state, spg_mode)) {   // line search pending: the next trial point instead of a new direction
+        if (!xnew) return;
+        const double alpha = spg_state[SPG_ALPHA];
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const int64_t i = ((int64_t)k * nb + b) * 1024 + tid;
+            if (i < L) spg_trial_point(i, alpha, x, d, scale, xnew, mtrial);
+        }
+        if (b == 0 && tid == 0) *enable = 1;
         return;
     }
     const unsigned int epoch = (unsigned int)t[11];   // tags of this launch: epoch + 1 ... epoch + EPOCH_STEP
@@ -870,14 +931,14 @@ static int simplex_impl(const double *x_dev, const double *g_dev, double lambda,
         else {   // long vector: multi-block Newton passes, then the (normally idle) finishing search
             hipLaunchKernelGGL(k_proj_q0, dim3(1), dim3(64), 0, st, z, floor, L, ws, nb, spg_state, mode);
             for (int pass = 0; pass < PROJ_PASSES; pass++) {
-                hipLaunchKernelGGL(k_proj_p, dim3(nb), dim3(1024), 0, st, L, ws, nb, spg_state);
+                hipLaunchKernelGGL(k_proj_p, dim3(nb), dim3(1024), 0, st, L, ws, nb, spg_state, mode);
                 hipLaunchKernelGGL(k_proj_q, dim3(1), dim3(64), 0, st, z, L, ws, nb, spg_state, mode);
             }
             hipLaunchKernelGGL(k_proj_b_finish, dim3(1), dim3(1024), 0, st, z, L, ws, nb, spg_state, mode);
         }
 #undef PB
         hipLaunchKernelGGL(k_proj_c, dim3(nb), dim3(1024), 0, st, x_dev, g_dev, L, ws, nb, p_dev, d_dev, trial_scale, trial_xnew, trial_m,
-                           spg_state);
+                           spg_state, mode);
         hipLaunchKernelGGL(k_proj_d, dim3(1), dim3(64), 0, st, L, ws, nb, stats_dev, spg_state, spg_mode, trial_enable);
         HIP_TRY(hipGetLastError());
         return BLUEST_OK;
@@ -974,7 +1035,6 @@ extern "C" int bluest_spg_update_fused(bluest_plan_t plan, double *x_dev, double
     const int nblocks = (int)std::min<int64_t>((L + 255) / 256, SPG_UPD_BLOCKS_MAX);
     hipLaunchKernelGGL(k_spg_update_a_fused, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, x_dev, g_dev, xnew_dev, grad_dev, plan->d_goff,
                        plan->d_invmap, (int)plan->outs.size(), scale_dev, state_dev, floor, L, (double2 *)work_dev);
-    hipLaunchKernelGGL(k_spg_update_b, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, (const double2 *)work_dev, nblocks);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }
@@ -1012,7 +1072,6 @@ extern "C" int bluest_spg_update(double *x_dev, double *g_dev, const double *xne
     const int nblocks = (int)std::min<int64_t>((L + 1023) / 1024, SPG_UPD_BLOCKS_MAX);
     hipLaunchKernelGGL(k_spg_update_a, dim3(nblocks), dim3(1024), 0, (hipStream_t)stream, x_dev, g_dev, xnew_dev, gnew_dev, state_dev, floor, L,
                        (double2 *)work_dev);
-    hipLaunchKernelGGL(k_spg_update_b, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, (const double2 *)work_dev, nblocks);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }

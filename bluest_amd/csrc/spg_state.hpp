@@ -13,7 +13,7 @@
 #define SPG_TAU      6    //                }
 #define SPG_NPOS     7    //                }
 #define SPG_ACCEPT   8    // 1 once a trial of this iteration satisfied the nonmonotone Armijo test
-#define SPG_FAIL     9    // 1 if all slots of an iteration were rejected (host continues the line search)
+#define SPG_FAIL     9    // 1 = the line search failed (step length underflow / evaluation budget spent): every kernel is a no-op
 #define SPG_DONE     10   // 1 = every kernel is a no-op
 #define SPG_IT       11
 #define SPG_COUNT    12   // objective evaluations
@@ -26,7 +26,11 @@
 #define SPG_SDOTY    19
 #define SPG_FTRIAL   20   // objective of the last evaluated trial
 #define SPG_EPS      21   // stop when max|P(x-g)-x| <= eps
+#define SPG_PENDING  22   // 1 = the line search of the current iteration goes on: the NEXT direction launch forms the next trial
+                          //     point (alpha from the state) instead of a new direction, the finishing launches stay gated off
+#define SPG_MAXFEV   23   // evaluation budget (0 = none): a line search that exhausts it fails
 #define SPG_GPSTATS  24   // g.gp, max|gp| (= gpmax), tau, npos of the convergence projection
+#define SPG_TICKET   28   // (32-bit counter in this slot) arrival ticket of the update launch's workgroups
 #define SPG_HIST     32   // 16 slots
 #define SPG_COEF     64   // dF/dV_o of the accepted trial (n_out <= 64)
 #define SPG_S        128  // normalisers s_o (1 or eps_o^2)
@@ -44,7 +48,9 @@ __device__ __forceinline__ void spg_wave_lds_sync()
 // objective of the trial from the per-output variances, nonmonotone Armijo test, safeguarded quadratic interpolation
 // (bluest/spg.py:9-35).  ONE wavefront (lane = 0..63): the state is staged through `ls` (SPG_STATE_DOUBLES doubles of LDS) with
 // coalesced loads, lane o handles output o, lane 0 takes the decision.  On the last slot of an iteration it also sets the
-// gate of the finishing launches.
+// gate of the finishing launches; a trial rejected there leaves the line search PENDING (continued by the next direction launch,
+// so a window of the solver is a sequence of identical "steps" with no host round trip) unless the step length underflowed or
+// the evaluation budget is spent (FAIL).
 __device__ __forceinline__ void spg_decide_wave(double *__restrict__ st, const double *var, const int32_t *status, int n_out,
                                                 int last_slot, int32_t *__restrict__ enable, double *ls, int lane)
 {
@@ -107,8 +113,13 @@ __device__ __forceinline__ void spg_decide_wave(double *__restrict__ st, const d
                 a = at;
             }
             st[SPG_ALPHA] = a;
-            if (last_slot) st[SPG_FAIL] = 1.0;
+            if (last_slot) {
+                const double maxfev = ls[SPG_MAXFEV];
+                const bool dead = !(a >= 1.0e-300) || (maxfev > 0.0 && ls[SPG_COUNT] + 1.0 >= maxfev);
+                st[dead ? SPG_FAIL : SPG_PENDING] = 1.0;
+            }
         }
+        if (accept) st[SPG_PENDING] = 0.0;
         if (last_slot) *enable = accept ? 1 : 0;
     }
 }

@@ -76,6 +76,7 @@ class Plan(object):
             check(self.lib.bluest_plan_create(ctypes.byref(self._h), self.N, self.L))
             try:
                 self._sizes = []
+                self._mappings = [out.get("mapping") for out in outputs]      # host view of each output's local -> global map
                 for out in outputs:
                     K = int(out["K"])
                     sizes = _i64(out["sizes"])
@@ -215,6 +216,19 @@ class Plan(object):
                                                     None if scale is None else scale.data_ptr(), nc, res.data_ptr(),
                                                     res.stride(0), _stream()))
         return res
+
+    def output_gradients(self, grad):
+        """(n_out, L) host array: row o = gradient of V_o scattered to the global allocation vector (zero outside the
+        output's groups), from the concatenated per-output gradient of ONE candidate as eval() returns it"""
+        gh = np.asarray(grad.cpu().numpy() if isinstance(grad, torch.Tensor) else grad, dtype=np.float64).reshape(-1)
+        G = np.zeros((self.n_out, self.L))
+        for o in range(self.n_out):
+            mp = self._mappings[o]
+            if mp is None:
+                G[o] = gh[self.grad_off[o]:self.grad_off[o] + self.L]
+            else:
+                G[o, np.asarray(mp, dtype=np.int64)] = gh[self.grad_off[o]:self.grad_off[o] + len(mp)]
+        return G
 
     def phi_matrix(self, m, delta=0.0):
         """Phi(m) + delta*I for every output as an (n_cand, n_out, N, N) device tensor (misc.py:459-461)"""

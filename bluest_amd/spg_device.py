@@ -1,9 +1,10 @@
 """
 Device-resident SPG: the iteration of bluest/spg.py:68-106 (direction by projection, nonmonotone Armijo line search with
 safeguarded quadratic interpolation, Barzilai-Borwein step) with ALL control flow on the GPU.  The solver state is a
-256-double array in HBM; one iteration is a fixed sequence of kernels (direction, T predicated line-search slots each
-= trial point + Phi pass + solve + decision, gate, gradient, combine, update) captured once in a hipGraph and replayed.
-The host only looks at the state every `check_every` iterations (convergence test, rare line-search overflow).
+256-double array in HBM; the loop is a sequence of identical STEPS, each a fixed sequence of kernels: direction (or, while a
+line search is pending, the next trial point), T predicated line-search slots (Phi pass + solve + decision), gradient, update.
+A trial rejected in the last slot leaves the line search pending and the next step continues it, so nothing ever waits for
+the host, which only looks at the state every `check_every` steps (convergence test, failure).
 
 Same algorithm as bluest_amd.spg.spg with SpgAllocator's callbacks (tests/test_gpu_api.py compares the two
 iteration by iteration); this is what `solve(..., solver="spg")` runs by default.
@@ -19,7 +20,7 @@ from .plan import EVAL_OK, _stream, projection_workspace, simplex_project
 
 # state layout (csrc/spg.hip SPG_*)
 F, FNEW, LAMBDA, ALPHA, GD, DMAX, TAU, NPOS, ACCEPT, FAIL, DONE, IT, COUNT, NORM, P, LMIN, LMAX, HLEN, SDOTS, SDOTY, FTRIAL = range(21)
-EPS, GPSTATS = 21, 24
+EPS, PENDING, MAXFEV, GPSTATS = 21, 22, 23, 24
 HIST, COEF, S, STATE_DOUBLES = 32, 64, 128, 256
 
 
@@ -70,11 +71,6 @@ class DeviceSpg(object):
         # Phi pass, then solve with the line-search decision fused into its tail (csrc/plan.hip: k_solve_from_chunks)
         check(self.lib.bluest_plan_eval_decide(self.plan._h, self.m.data_ptr(), 0.0, self.var.data_ptr(), self.status.data_ptr(),
                                                self.st.data_ptr(), 1 if t == self.T - 1 else 0, self.enable.data_ptr(), _stream()))
-
-    def _slots(self):
-        """T more trial points (host continuation of a line search that overflowed the T slots of the iteration)"""
-        for t in range(self.T):
-            self._slot(t, True)
 
     def _finish(self):
         plan = self.plan
@@ -182,15 +178,16 @@ class DeviceSpg(object):
             h[HIST] = 1.0
             h[S:S + self.n_out] = self.s_norm
             h[EPS] = eps
+            h[MAXFEV] = float(max_fevals)
             h[GPSTATS + 1] = gpmax
             st.copy_(torch.from_numpy(h))
             check(lib.bluest_plan_set_gate(plan._h, self.enable.data_ptr(), 1))
             try:
                 def bind():
-                    """launchers for the current number of slots self.T; every hipGraph is captured when it is first needed
-                    (the continuation graphs `slots` / `finish` only if a line search ever overflows its slots)"""
+                    """launchers of one step, one step + convergence projection, and a whole window; every hipGraph is captured
+                    when it is first needed"""
                     if not use_graph:
-                        return (lambda: self._window_direct(1, False), self._slots, self._finish, lambda: self._window_direct(1, True),
+                        return (lambda: self._window_direct(1, False), lambda: self._window_direct(1, True),
                                 lambda: self._window_direct(self.check_every, True))
                     gs = self.graph_sets.setdefault(self.T, {})
 
@@ -201,11 +198,9 @@ class DeviceSpg(object):
                             gs[name].replay()
                         return replay
                     self.graphs = gs
-                    return (lazy("iteration", self._iteration), lazy("slots", self._slots), lazy("finish", self._finish),
-                            lazy("iteration_checked", self._iteration_checked), lazy("window", self._window))
+                    return lazy("iteration", self._iteration), lazy("iteration_checked", self._iteration_checked), lazy("window", self._window)
 
-                run_iter, run_slots, run_finish, run_iter_checked, run_window = bind()
-                fail_windows = []                                   # did the host have to continue a line search, per window
+                run_iter, run_iter_checked, run_window = bind()
                 info, it, count = 1, 0, 1
                 stalled = False
                 hs = h
@@ -235,30 +230,13 @@ class DeviceSpg(object):
                         run_iter_checked()                      # last one also measures gpmax (sets DONE when <= eps)
                     hs = st.cpu().numpy()
                     self.window_seconds.append(time.perf_counter() - t_window)      # host-visible time of the window (diagnostics)
-                    fail_windows.append(hs[FAIL] != 0.0)
-                    while hs[FAIL] != 0.0:                       # rare: more than T trial points needed
-                        if hs[ALPHA] < 1e-300 or hs[COUNT] >= max_fevals:
-                            info = 2
-                            break
-                        st[FAIL:FAIL + 1].copy_(self._zero)
-                        run_slots()
-                        hs = st.cpu().numpy()
-                        if hs[ACCEPT] != 0.0:
-                            run_finish()
-                            self._converged()
-                            hs = st.cpu().numpy()
-                    if info == 2:
+                    if hs[FAIL] != 0.0:                          # step length underflow or evaluation budget spent (decided on the GPU)
+                        info = 2
                         break
                     it, count = int(hs[IT]), int(hs[COUNT])
                     gpmax = float(hs[GPSTATS + 1])
                     trace.append((it, float(hs[F])))
                     checks.append((it, count, float(hs[F])))
-                    # backtracking is frequent on this problem: keep a second trial point inside the iteration graph (costs
-                    # three predicated-off launches when unused, saves the host round trip and the idle rest of the window)
-                    # (3 of 10 measured better than 6 of 10: 92 vs 125 us per iteration at the headline size)
-                    if self.T == 1 and sum(fail_windows[-10:]) >= 3:
-                        self.T = 2
-                        run_iter, run_slots, run_finish, run_iter_checked, run_window = bind()
                     # line search in trouble: >= 8 trial points per iteration over at least 5 iterations (not just the first
                     # iteration after a restart, whose re-initialised step is expected to backtrack) and nothing gained --
                     # the iterate is stationary to rounding (typical for a restart from an already converged point)

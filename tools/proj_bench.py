@@ -1,36 +1,37 @@
-"""Kernel time of the scaled simplex projection step (as the device SPG calls it) for a few vector lengths: 50 projections
-per hipGraph, inputs drifting slowly so the warm start is realistic.  BLUEST_PROJ_MULTI_LAUNCH=1 selects the multi-launch path."""
-import sys
-import time
+"""Micro-benchmark of the simplex projection alone: single-workgroup kernel (work=None) vs the multi-workgroup mailbox kernel,
+at SPG-like inputs (x on the simplex, a gradient step).  Usage: python tools/proj_bench.py [L ...]"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from bluest_amd import _lib
+from bluest_amd.plan import projection_workspace, check, _stream
 
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-from bluest_amd.plan import simplex_project  # noqa: E402
+lib = _lib.lib()
+for L in [int(a) for a in sys.argv[1:]] or [4096, 8192, 16384, 21699, 24576]:
+    rng = np.random.default_rng(L)
+    xh = rng.random(L) ** 8
+    xh /= xh.sum()
+    x = torch.from_numpy(xh).cuda()
+    g = torch.from_numpy(rng.standard_normal(L) * 1e-3).cuda()
+    p, d, stats = torch.empty_like(x), torch.empty_like(x), torch.empty(4, dtype=torch.float64, device="cuda")
+    res = {}
+    for name, work in (("single", None), ("multi", projection_workspace(L, x.device))):
+        if name == "single" and L > 512 * 48:
+            continue
 
-dev = torch.device("cuda")
-rng = np.random.RandomState(0)
-for L in [int(a) for a in sys.argv[1:]] or [21699, 245505]:
-    x = torch.from_numpy(rng.dirichlet(np.full(L, 0.05))).to(dev)
-    gs = [torch.from_numpy(rng.randn(L) * (1 + 0.01 * k)).to(dev) for k in range(5)]
-    for _ in range(3):
-        simplex_project(x, gs[0], 1e-3, floor=1e-8)
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, capture_error_mode="thread_local"):
-        for k in range(50):
-            out = simplex_project(x, gs[k % 5], 1e-3 * (1 + 0.1 * (k % 3)), floor=1e-8)
-    for _ in range(3):
-        g.replay()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    R = 20
-    for _ in range(R):
-        g.replay()
-    torch.cuda.synchronize()
-    from bluest_amd.plan import projection_workspace
-    ws = projection_workspace(L, x.device)
-    off = 2 * L + 4 * ((L + 1023) // 1024)
-    t = ws[off:off + 16].cpu().numpy()
-    print("L = %7d: %.2f us per projection  (sum p = %.15f)  passes per search %.2f" % (
-        L, (time.perf_counter() - t0) / (R * 50) * 1e6, float(out[0].sum()), t[9] / max(t[10], 1)))
+        def call():
+            check(lib.bluest_simplex_project(x.data_ptr(), g.data_ptr(), 0.5, 1.0, 1e-9, L, p.data_ptr(), d.data_ptr(), stats.data_ptr(),
+                                             None if work is None else work.data_ptr(), _stream()))
+        for _ in range(20):
+            call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(500):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = (e0.elapsed_time(e1) * 2.0, p.clone())
+    line = "L %6d: " % L + "  ".join("%s %.2f us" % (k, v[0]) for k, v in res.items())
+    if len(res) == 2:
+        line += "   max |p_single - p_multi| = %.2e" % float((res["single"][1] - res["multi"][1]).abs().max())
+    print(line, flush=True)

@@ -388,6 +388,7 @@ __global__ __launch_bounds__(SIMPLEX_BLOCK) void k_simplex(const double *__restr
     }
     block_sum_cnt(gd, npos, s, tid, ph);
     dmax = block_max(dmax, s, tid, ph);
+    if (tid == 0 && spg_state && spg_mode == 1) spg_state[SPG_GDPARTS_N] = 0.0;   // g.d below is the folded value
     if (tid == 0 && stats) {
         stats[0] = gd;
         stats[1] = dmax;
@@ -684,6 +685,7 @@ __global__ __launch_bounds__(64) void k_proj_d(int64_t L, const double *__restri
     gd = wave_sum(gd); dm = wave_max(dm); np = wave_sum(np);
     if (lane == 0) {
         if (stats) { stats[0] = gd; stats[1] = dm; stats[2] = ws[ProjWs::tau_off(L, nb)]; stats[3] = np; }
+        if (spg_state && spg_mode == 1) spg_state[SPG_GDPARTS_N] = 0.0;   // g.d above is the folded value
         if (enable) *enable = 1;
         if (spg_state && spg_mode == 2 && dm <= spg_state[SPG_EPS]) spg_state[SPG_DONE] = 1.0;
     }
@@ -859,6 +861,29 @@ __global__ __launch_bounds__(1024) void k_proj_fused(const double *__restrict__ 
             dm = fmax(dm, fabs(di));
             npos += pi > 0.0;
         }
+    }
+    if (spg_state && spg_mode == 1) {
+        // direction of the device-resident SPG: the only statistic anybody consumes is g.d (the Armijo test, two launches later),
+        // so no workgroup waits for the others here: each publishes its partial of g.d and spg_decide_wave folds them in fixed
+        // order -- one mailbox exchange (~4 us) less per iteration.  Every workgroup holds the same tau, so workgroup 0 does
+        // the bookkeeping alone; all others read epoch/hint/flag before the first exchange, i.e. before it can get here.
+        long long unused = 0;
+        block_sum_cnt(gd, unused, sm, tid, ph);
+        if (tid == 0) {
+            ws[ProjWs::part_off(L) + 4LL * b + 1] = ok ? gd : NAN;
+            if (!ok) t[12] = 1.0;                                      // sticky: a wait timed out
+            if (b == 0) {
+                spg_state[SPG_GDPARTS] = __longlong_as_double((long long)(uintptr_t)(ws + ProjWs::part_off(L)));
+                spg_state[SPG_GDPARTS_N] = (double)nb;
+                if (enable) *enable = 1;
+                t[0] = tau; t[1] = rmax;
+                if (ok) t[4 + mode] = use_theta ? (1.0 - (tau + rmax)) / lambda : tau + rmax;
+                t[9] += (double)passes;
+                t[10] += 1.0;
+                t[11] = (double)(epoch + (unsigned int)FusedProj::EPOCH_STEP);
+            }
+        }
+        return;
     }
     block_sum_cnt(gd, npos, sm, tid, ph);
     dm = block_max(dm, sm, tid, ph);

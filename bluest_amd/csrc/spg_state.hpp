@@ -31,6 +31,8 @@
 #define SPG_MAXFEV   23   // evaluation budget (0 = none): a line search that exhausts it fails
 #define SPG_GPSTATS  24   // g.gp, max|gp| (= gpmax), tau, npos of the convergence projection
 #define SPG_TICKET   28   // (32-bit counter in this slot) arrival ticket of the update launch's workgroups
+#define SPG_GDPARTS  29   // (pointer bits) per-workgroup partials of g.d left by the multi-workgroup direction kernel, stride 4
+#define SPG_GDPARTS_N 30  // how many (0: SPG_GD holds the folded value)
 #define SPG_HIST     32   // 16 slots
 #define SPG_COEF     64   // dF/dV_o of the accepted trial (n_out <= 64)
 #define SPG_S        128  // normalisers s_o (1 or eps_o^2)
@@ -94,7 +96,13 @@ __device__ __forceinline__ void spg_decide_wave(double *__restrict__ st, const d
     const int H = (int)ls[SPG_HLEN];
     double fmax = -INFINITY;
     for (int h = 0; h < H; h++) fmax = fmax > ls[SPG_HIST + h] ? fmax : ls[SPG_HIST + h];
-    const double alpha = ls[SPG_ALPHA], gd = ls[SPG_GD], f = ls[SPG_F];
+    double gd = ls[SPG_GD];
+    const int n_parts = (int)ls[SPG_GDPARTS_N];
+    if (n_parts > 0) {   // the direction kernel left per-workgroup partials (<= 64): fixed-order fold
+        const double *parts = reinterpret_cast<const double *>((uintptr_t)__double_as_longlong(ls[SPG_GDPARTS]));
+        gd = wave_sum(lane < n_parts ? parts[4 * lane + 1] : 0.0);
+    }
+    const double alpha = ls[SPG_ALPHA], f = ls[SPG_F];
     const bool accept = F <= fmax + 1.0e-4 * alpha * gd;
     if (accept && mine) st[SPG_COEF + lane] = coef / norm;
     if (lane == 0) {

@@ -375,6 +375,26 @@ def main():
         extra["single_gpu_value"] = n_out_all / float(solo[0])
         extra["single_gpu_ms_per_step"] = float(solo[0]) * 1e3
         del full
+        if sharded is not None and not args.no_sap:
+            # the solve of the same configuration over the sharded plan: device-resident loop, two all-reduces per step (records:
+            # peer-write or RCCL; gradient K_tot f64: RCCL); collective, so every rank runs it -- outside the timed region
+            try:
+                from bluest_amd.dist import sharded_spg
+                rows = []
+                for rep in range(2):
+                    barrier()
+                    t0 = time.perf_counter()
+                    m_sh, info = sharded_spg(sharded, prob["costs"], budget=prob["budget"])
+                    barrier()
+                    rows.append(time.perf_counter() - t0)
+                vs, _, _ = sharded.eval(torch.from_numpy(m_sh).to(dev), want_grad=False)
+                extra["sharded_solve"] = {"cold_s": rows[0], "warm_s": rows[1], "spg_iterations": int(info["it"]),
+                                          "objective_evaluations": int(info["count"]), "max_variance": float(vs.max()),
+                                          "loop": "device-resident SPG over the sharded plan (spg_device.ShardedDeviceSpg)",
+                                          "note": "set-up not included (the sharded plan is the one timed above); compare sap_wallclock of "
+                                                  "the single-GPU run of this configuration: profiles/*_bench_n25_k6_o1.json"}
+            except Exception as err:      # the headline line must not depend on this leg
+                extra["sharded_solve"] = {"error": repr(err)[:300]}
 
     # ---- per-kernel durations with HIP events on the launch stream (single GPU) -----------------------
     roofline = None

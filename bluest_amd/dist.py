@@ -183,11 +183,7 @@ class ShardedPlan(object):
         plan's concatenated per-output layout (plan.grad_off, local numbering).  out = (var, grad, status) preallocated
         device tensors (the v workspace is kept by this object)."""
         rec = self.plan.phi(m, out=rec)
-        if self.world > 1:
-            if self.exchange is not None:
-                self.exchange.all_reduce(rec)
-            else:
-                dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=self.group)
+        self.reduce_records(rec)
         if out is None:
             var, v, status = self.plan.solve(rec, delta)
             grad = self.plan.grad(v, status) if want_grad else None
@@ -199,6 +195,19 @@ class ShardedPlan(object):
         if want_grad:
             self.plan.grad(self._v, status, out=grad)
         return var, grad if want_grad else None, status
+
+    def reduce_records(self, rec):
+        """in-place all-reduce(SUM) of Phi records on the current stream: every rank ends with the same bits"""
+        if self.world > 1:
+            if self.exchange is not None:
+                self.exchange.all_reduce(rec)
+            else:
+                dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=self.group)
+        return rec
+
+    @property
+    def lib(self):
+        return self.plan.lib
 
     def combine_grad(self, grad_local, coef, scale=None, out=None):
         """plan.Plan.combine_grad for the whole group set (same signature): see global_gradient"""
@@ -215,17 +224,23 @@ class ShardedPlan(object):
 
 @in_host_section
 def sharded_spg(sharded, costs, budget=None, eps=None, x0=None, params=None):
-    """solver="spg" over a group-sharded plan: the host-driven SPG driver (bluest_amd.spg.spg = bluest/spg.py:39-132) with the
-    scaled metric, every rank running the SAME deterministic iteration on replicated vectors (x, g, d of length K_tot);
-    the callbacks are collective -- an objective evaluation is one all-reduce of the Phi records, a gradient evaluation one more
-    all-reduce of the gradient (every rank contributes the entries of its groups).  All ranks return the same allocation.
+    """solver="spg" over a group-sharded plan: every rank runs the SAME deterministic iteration on replicated vectors (x, g, d
+    of length K_tot); an objective evaluation is one all-reduce of the Phi records, a gradient evaluation one more all-reduce of
+    the gradient (every rank contributes the entries of its groups).  On GPUs the loop is device-resident
+    (spg_device.ShardedDeviceSpg: nothing waits for the host between the collectives); params={"device_loop": False} selects
+    the host-driven driver (bluest_amd.spg.spg = bluest/spg.py:39-132, what CPU stand-in plans always use).  All ranks return
+    the same allocation.
     The reference runs its optimiser on one MPI rank (bluest/blue_models.py:508-526); this is the N-GPU counterpart of
     SAP.solve / MOSAP.solve(..., continuous_relaxation=True).  Returns (samples, solver info)."""
     from .sap import SpgAllocator
-    prm = {"device_loop": False, "maxit": 600, "eps": 1.0e-7}
+    on_gpu = sharded.device is not None and type(sharded.plan).__name__ == "Plan"
+    prm = {"device_loop": on_gpu, "eps": 1.0e-7}
+    if not on_gpu:
+        prm["maxit"] = 600
     if params:
         prm.update(params)
-    prm["device_loop"] = False
+    if not on_gpu:
+        prm["device_loop"] = False                                 # CPU stand-in plans (tests): the host-driven driver
     alloc = SpgAllocator(sharded, costs, None, verbose=False, subplan=None)
     m = alloc.solve(budget=budget, eps=eps, x0=x0, params=prm)
     return m, alloc.info

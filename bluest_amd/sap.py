@@ -187,7 +187,7 @@ class SpgAllocator(object):
         """solve() with the device-resident loop.  All vector bookkeeping between the runs (pruning, support selection, pricing)
         is numpy on the host: the vectors are <= a few MB, and no torch compute operator is touched -- on ROCm the first use
         of each one loads its kernels (30-150 ms a piece), which used to triple the first solve of a process."""
-        from .spg_device import DeviceSpg
+        from .spg_device import DeviceSpg, ShardedDeviceSpg
         plan, dev = self.plan, self.dev
         n_out, L, N = plan.n_out, plan.L, plan.N
         s = np.ones(n_out) if budget is not None else np.asarray(eps, dtype=np.float64) ** 2
@@ -238,7 +238,8 @@ class SpgAllocator(object):
 
             # ONE solver object for all stages: the smoothing exponent lives in the device state, so the captured hipGraphs
             # are shared by the stages
-            dspg = DeviceSpg(pl, sc, s, stages[0], floor, lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"],
+            loop_cls = ShardedDeviceSpg if hasattr(pl, "reduce_records") else DeviceSpg     # dist.ShardedPlan: collective loop
+            dspg = loop_cls(pl, sc, s, stages[0], floor, lmbda_min=prm["lmbda_min"], lmbda_max=prm["lmbda_max"],
                              Hlength=prm["linesearch_history_length"], slots=prm["slots"] if slots is None else slots,
                              check_every=prm["check_every"])
             out = None

@@ -27,7 +27,10 @@ HIST, COEF, S, STATE_DOUBLES = 32, 64, 128, 256
 class DeviceSpg(object):
     def __init__(self, plan, scale, s_norm, p, floor, lmbda_min=1e-30, lmbda_max=1e30, Hlength=10, slots=2, check_every=20):
         assert 1 <= Hlength <= 16 and plan.n_out <= 64
-        self.plan, self.lib, self.dev = plan, plan.lib, plan.device
+        # self.plan answers eval()/combine_grad() for the WHOLE group set; self.hip is the HIP plan whose handle the launch
+        # sequences use (the same object, except for a group-sharded plan: its local shard)
+        self.hip = getattr(plan, "plan", plan)
+        self.plan, self.lib, self.dev = plan, self.hip.lib, self.hip.device
         self.L, self.n_out = plan.L, plan.n_out
         self.scale = scale.contiguous()
         self.scale_h = self.scale.cpu().numpy()
@@ -45,13 +48,13 @@ class DeviceSpg(object):
         self.xnew, self.gnew, self.m = torch.empty(L, **d), torch.empty(L, **d), torch.empty(L, **d)
         self.var = torch.empty((1, self.n_out), **d)
         self.status = torch.from_numpy(np.zeros((1, self.n_out), dtype=np.int32)).to(self.dev)
-        self.grad = torch.empty((1, plan.grad_len), **d)
+        self.grad = torch.empty((1, self.hip.grad_len), **d)
         self.enable = torch.from_numpy(np.ones(1, dtype=np.int32)).to(self.dev)
         self.st = torch.from_numpy(np.zeros(STATE_DOUBLES)).to(self.dev)
         self.work = torch.from_numpy(np.zeros(1024)).to(self.dev)
         self.pws = projection_workspace(L, self.dev)
         v = ctypes.c_void_p()
-        check(self.lib.bluest_plan_v_workspace(plan._h, ctypes.byref(v), None))
+        check(self.lib.bluest_plan_v_workspace(self.hip._h, ctypes.byref(v), None))
         self.v_ws = v.value
         self.graph_sets = {}          # hipGraphs per number of in-iteration line-search slots
         self.window_seconds = []
@@ -69,12 +72,11 @@ class DeviceSpg(object):
             check(self.lib.bluest_spg_trial(self.x.data_ptr(), self.d.data_ptr(), self.scale.data_ptr(), self.st.data_ptr(),
                                             self.xnew.data_ptr(), self.m.data_ptr(), self.enable.data_ptr(), self.L, _stream()))
         # Phi pass, then solve with the line-search decision fused into its tail (csrc/plan.hip: k_solve_from_chunks)
-        check(self.lib.bluest_plan_eval_decide(self.plan._h, self.m.data_ptr(), 0.0, self.var.data_ptr(), self.status.data_ptr(),
+        check(self.lib.bluest_plan_eval_decide(self.hip._h, self.m.data_ptr(), 0.0, self.var.data_ptr(), self.status.data_ptr(),
                                                self.st.data_ptr(), 1 if t == self.T - 1 else 0, self.enable.data_ptr(), _stream()))
 
     def _finish(self):
-        plan = self.plan
-        check(self.lib.bluest_spg_finish(plan._h, self.v_ws, self.status.data_ptr(), self.x.data_ptr(), self.g.data_ptr(),
+        check(self.lib.bluest_spg_finish(self.hip._h, self.v_ws, self.status.data_ptr(), self.x.data_ptr(), self.g.data_ptr(),
                                          self.xnew.data_ptr(), self.grad.data_ptr(), self.scale.data_ptr(), self.st.data_ptr(),
                                          self.floor, self.work.data_ptr(), _stream()))
 
@@ -94,7 +96,7 @@ class DeviceSpg(object):
 
     def _window_direct(self, n_iterations, check_last):
         """n whole iterations (+ the convergence projection) enqueued by ONE call into the library: plain stream launches"""
-        check(self.lib.bluest_spg_window(self.plan._h, self.x.data_ptr(), self.g.data_ptr(), self.d.data_ptr(), self.xnew.data_ptr(),
+        check(self.lib.bluest_spg_window(self.hip._h, self.x.data_ptr(), self.g.data_ptr(), self.d.data_ptr(), self.xnew.data_ptr(),
                                          self.m.data_ptr(), self.scale.data_ptr(), self.st.data_ptr(), self.var.data_ptr(),
                                          self.status.data_ptr(), self.grad.data_ptr(), self.enable.data_ptr(), self.work.data_ptr(),
                                          self.pws.data_ptr(), self.v_ws, self.floor, self.T, int(n_iterations), 1 if check_last else 0,
@@ -156,7 +158,7 @@ class DeviceSpg(object):
             import os
             use_graph = bool(os.environ.get("BLUEST_SPG_GRAPH"))
         with torch.cuda.device(self.dev):
-            check(lib.bluest_plan_set_gate(plan._h, None, 0))
+            check(lib.bluest_plan_set_gate(self.hip._h, None, 0))
             if not isinstance(x0, torch.Tensor):
                 x0 = torch.from_numpy(np.ascontiguousarray(x0, dtype=np.float64))
             self.x.copy_(simplex_project(x0.to(self.dev), want_d=False)[0])
@@ -181,7 +183,7 @@ class DeviceSpg(object):
             h[MAXFEV] = float(max_fevals)
             h[GPSTATS + 1] = gpmax
             st.copy_(torch.from_numpy(h))
-            check(lib.bluest_plan_set_gate(plan._h, self.enable.data_ptr(), 1))
+            check(lib.bluest_plan_set_gate(self.hip._h, self.enable.data_ptr(), 1))
             try:
                 def bind():
                     """launchers of one step, one step + convergence projection, and a whole window; every hipGraph is captured
@@ -249,7 +251,7 @@ class DeviceSpg(object):
                             break
                 hs = st.cpu().numpy()
             finally:
-                check(lib.bluest_plan_set_gate(plan._h, None, 0))
+                check(lib.bluest_plan_set_gate(self.hip._h, None, 0))
         if not np.isfinite(hs[F]) or info == 2:
             # a wait between the workgroups of the single-launch projection timed out (never observed; the kernel then returns
             # NaN and raises a sticky flag in its workspace): say so instead of handing back a NaN allocation
@@ -262,3 +264,48 @@ class DeviceSpg(object):
                                        "(BLUEST_PROJ_MULTI_LAUNCH=1 selects the multi-launch path)")
         return {"x": self.x.cpu().numpy(), "f": float(hs[F]) * norm, "gpmax": gpmax, "it": int(hs[IT]), "count": int(hs[COUNT]),
                 "solver_info": info, "norm": norm, "stalled": stalled}
+
+
+class ShardedDeviceSpg(DeviceSpg):
+    """The device-resident loop over a group-sharded plan (dist.ShardedPlan), one process per GPU: every rank runs the SAME
+    iteration on replicated vectors (x, g, d, state) and evaluates its shard of the groups.  One step =
+
+        direction (replicated projection + first trial point)
+        Phi records of the shard -> all-reduce(SUM) of the records (peer-write exchange or RCCL) -> redundant solve + decision
+        gradient of the shard -> scattered into the K_tot-vector -> all-reduce(SUM) (RCCL) -> update
+
+    enqueued on the stream with no host synchronisation in between; the records and the gradient come out of the all-reduces
+    bit-identical on every rank, so the replicated state never diverges and all ranks take the same host decisions."""
+
+    def __init__(self, sharded, *args, **kwargs):
+        super().__init__(sharded, *args, **kwargs)
+        d = dict(dtype=torch.float64, device=self.dev)
+        self.rec = torch.empty((1, self.n_out, self.hip.reclen), **d)
+        self.v = torch.empty((1, self.n_out, self.hip.N), **d)
+        self.gnew = torch.empty((1, self.L), **d)
+
+    def _window_direct(self, n_iterations, check_last):
+        import torch.distributed as dist
+        lib, h, sh, st = self.lib, self.hip._h, self.plan, self.st
+        coef = st.data_ptr() + 8 * COEF                           # dF/dV_o of the accepted trial, written by the decision
+        for _ in range(int(n_iterations)):
+            self._direction()
+            check(lib.bluest_plan_phi(h, self.m.data_ptr(), 1, self.L, self.rec.data_ptr(), _stream()))
+            sh.reduce_records(self.rec)
+            check(lib.bluest_plan_solve(h, self.rec.data_ptr(), 1, 0.0, self.var.data_ptr(), self.v.data_ptr(), self.status.data_ptr(),
+                                        _stream()))
+            check(lib.bluest_spg_decide(st.data_ptr(), self.var.data_ptr(), self.status.data_ptr(), self.n_out, 1, self.enable.data_ptr(),
+                                        _stream()))
+            check(lib.bluest_plan_grad(h, self.v.data_ptr(), self.status.data_ptr(), 1, self.grad.data_ptr(), self.grad.stride(0), _stream()))
+            check(lib.bluest_plan_combine_grad(h, self.grad.data_ptr(), self.grad.stride(0), coef, self.scale.data_ptr(), 1,
+                                               self.gnew.data_ptr(), self.gnew.stride(0), _stream()))
+            if sh.world > 1:
+                dist.all_reduce(self.gnew, op=dist.ReduceOp.SUM, group=sh.group)
+            check(lib.bluest_spg_update(self.x.data_ptr(), self.g.data_ptr(), self.xnew.data_ptr(), self.gnew.data_ptr(), st.data_ptr(),
+                                        self.floor, self.L, self.work.data_ptr(), _stream()))
+        if check_last:
+            self._converged()
+
+    def run(self, x0, **kwargs):
+        kwargs["use_graph"] = False                               # collectives are enqueued directly
+        return super().run(x0, **kwargs)

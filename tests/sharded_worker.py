@@ -60,7 +60,11 @@ def main(out_path):
         res[tag + "_status_equal"] = bool(torch.equal(status, st_full))
         res[tag + "_shard"] = [sp.lo, sp.hi]
         res[tag + "_exchange"] = sp.exchange_name
-        m_sh, info = sharded_spg(sp, prob["costs"], budget=prob["budget"], params={"smoothing_p": 512.0})
+        # host-driven driver (collective callbacks) and the device-resident collective loop (the default on GPUs)
+        m_host, info_h = sharded_spg(sp, prob["costs"], budget=prob["budget"], params={"smoothing_p": 512.0, "device_loop": False})
+        vh, _, _ = full.eval(torch.from_numpy(m_host).to(dev), want_grad=False)
+        res[tag + "_F_sharded_host_loop"] = float(vh.max())
+        m_sh, info = sharded_spg(sp, prob["costs"], budget=prob["budget"])
         all_m = [torch.empty(prob["K_tot"], dtype=torch.float64) for _ in range(world)]
         dist.all_gather(all_m, torch.from_numpy(np.ascontiguousarray(m_sh)))
         res[tag + "_ranks_agree"] = bool(all(torch.equal(all_m[0], q) for q in all_m))

@@ -36,11 +36,13 @@ def test_sharded_hip_plans_two_ranks(tmp_path):
         assert res[tag + "_ranks_agree"] and abs(res[tag + "_cost_ratio"] - 1) < 1e-9
         lo, hi = res[tag + "_shard"]
         assert lo == 0 and 0 < hi < synth.n_groups(n, kmax)
-        # the sharded solve (host-driven SPG, collective callbacks) reaches the single-GPU solver's optimum
+        # the sharded solves (device-resident collective loop; host-driven SPG with collective callbacks) reach the single-GPU
+        # solver's optimum
         prob = synth.problem(n, kmax, n_out)
         groups = prob["groups"]
         mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in groups] for _ in range(n_out)],
                     prob["costs"], [prob["costs"]] * n_out, verbose=False)
         m1 = mos.solve(budget=prob["budget"], solver="spg", continuous_relaxation=True)
         F1 = max(mos.variances(m1))
-        assert res[tag + "_F_sharded"] <= F1 * (1 + 5e-3), (tag, res[tag + "_F_sharded"], F1, res[tag + "_it"])
+        assert res[tag + "_F_sharded"] <= F1 * (1 + 1e-3), (tag, res[tag + "_F_sharded"], F1, res[tag + "_it"])
+        assert res[tag + "_F_sharded_host_loop"] <= F1 * (1 + 5e-3), (tag, res[tag + "_F_sharded_host_loop"], F1)

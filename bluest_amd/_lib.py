@@ -39,6 +39,8 @@ SIGNATURES = {
     "bluest_plan_add_output_cov": [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp],
     "bluest_plan_get_invcovs": [c_vp, c_int, c_vp],
     "bluest_plan_gather_invcovs": [c_vp, c_int, c_vp, c_i64, c_vp],
+    "bluest_plan_restrict": [c_vp, c_vp, c_i64, c_int, c_vp],
+    "bluest_plan_output_layout": [c_vp, c_int, c_vp, c_vp, c_vp],
     "bluest_plan_finalize": [c_vp, c_int],
     "bluest_plan_n_outputs": [c_vp, ctypes.POINTER(c_int)],
     "bluest_plan_grad_layout": [c_vp, c_i64p, c_i64p],

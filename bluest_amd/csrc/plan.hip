@@ -1037,6 +1037,100 @@ int plan_ready(bluest_plan_t plan, int n_cand)
     return BLUEST_OK;
 }
 
+extern "C" int bluest_plan_output_layout(bluest_plan_t plan, int output, int *K, int64_t *sizes, int64_t *mapping)
+{
+    if (!plan || !K) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (output < 0 || output >= (int)plan->outs.size()) return fail(BLUEST_ERR_ARG, "output %d out of range", output);
+    const OutputDesc &od = plan->outs[output];
+    *K = od.K;
+    if (sizes) std::copy(od.sizes.begin(), od.sizes.end(), sizes);
+    if (mapping) std::copy(od.mapping.begin(), od.mapping.end(), mapping);
+    return BLUEST_OK;
+}
+
+// The working set of the solver: a plan over a sub-list of the parent's groups, built natively -- group lists and mappings are
+// filtered on the host (they live there), the k x k pseudo-inverse blocks are gathered device to device.
+extern "C" int bluest_plan_restrict(bluest_plan_t parent, const int64_t *keep, int64_t n_keep, int max_candidates, bluest_plan_t *restricted)
+{
+    if (!parent || !keep || !restricted) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (!parent->finalized) return fail(BLUEST_ERR_STATE, "parent plan not finalized");
+    if (n_keep <= 0 || n_keep > parent->L) return fail(BLUEST_ERR_ARG, "n_keep=%lld out of range", (long long)n_keep);
+    PhaseTimer timer("plan_restrict");
+    std::vector<int32_t> pos((size_t)parent->L, -1);
+    for (int64_t i = 0; i < n_keep; i++) {
+        if (keep[i] < 0 || keep[i] >= parent->L || (i > 0 && keep[i] <= keep[i - 1]))
+            return fail(BLUEST_ERR_ARG, "keep must be strictly ascending indices in [0, L_global)");
+        pos[(size_t)keep[i]] = (int32_t)i;
+    }
+    bluest_plan_t sub = nullptr;
+    int rc = bluest_plan_create(&sub, parent->N, n_keep);
+    if (rc) return rc;
+    const int n_out = (int)parent->outs.size();
+    // selection per output (host), and ONE upload of all gather descriptors
+    std::vector<int64_t> src, dst;
+    std::vector<int32_t> kk;
+    std::vector<int64_t> first_of_output(n_out + 1, 0);
+    std::vector<OutputDesc> nods((size_t)n_out);
+    for (int o = 0; o < n_out; o++) {
+        const OutputDesc &od = parent->outs[o];
+        OutputDesc &nd = nods[o];
+        nd.K = od.K;
+        nd.sizes.assign(od.K, 0);
+        bool has0 = false;
+        int64_t t0 = 0, goff = 0, ioff = 0, dtot = 0;
+        for (int k = 1; k <= od.K; k++) {
+            const int64_t Lk = od.sizes[k - 1];
+            for (int64_t t = 0; t < Lk; t++) {
+                const int32_t q = pos[(size_t)od.mapping[t0 + t]];
+                if (q < 0) continue;
+                const int64_t *gp = od.groups.data() + goff + t * k;
+                for (int j = 0; j < k; j++) has0 = has0 || gp[j] == 0;
+                nd.groups.insert(nd.groups.end(), gp, gp + k);
+                nd.mapping.push_back(q);
+                nd.sizes[k - 1]++;
+                src.push_back(ioff + t * k * k);
+                dst.push_back(dtot);
+                kk.push_back(k);
+                dtot += (int64_t)k * k;
+            }
+            t0 += Lk; goff += Lk * k; ioff += Lk * k * k;
+        }
+        nd.L_o = (int64_t)nd.mapping.size();
+        first_of_output[o + 1] = (int64_t)src.size();
+        if (nd.L_o == 0 || !has0) {
+            bluest_plan_destroy(sub);
+            return fail(BLUEST_ERR_ARG, "restricted plan: output %d would not sample model 0", o);
+        }
+    }
+    timer.lap("select groups");
+    const int64_t n_all = (int64_t)src.size();
+    void *d = nullptr;
+    const size_t b64 = (size_t)n_all * sizeof(int64_t), b32 = ((size_t)n_all * sizeof(int32_t) + 7) / 8 * 8;
+    hipError_t e = pool_alloc(&d, 2 * b64 + b32);
+    if (e != hipSuccess) { bluest_plan_destroy(sub); HIP_TRY(e); }
+    int64_t *d_src = (int64_t *)d, *d_dst = d_src + n_all;
+    int32_t *d_k = (int32_t *)(d_dst + n_all);
+    e = hipMemcpy(d_src, src.data(), b64, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_dst, dst.data(), b64, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_k, kk.data(), (size_t)n_all * sizeof(int32_t), hipMemcpyHostToDevice);
+    for (int o = 0; o < n_out && e == hipSuccess; o++) {
+        OutputDesc &nd = nods[o];
+        if (output_to_device(sub, nd) != BLUEST_OK) { output_release(nd); e = hipErrorOutOfMemory; break; }
+        const int64_t f = first_of_output[o], n = first_of_output[o + 1] - f;
+        hipLaunchKernelGGL(k_gather_blocks, dim3((unsigned)n), dim3(64), 0, 0, parent->outs[o].d_invcov, d_src + f, d_dst + f, d_k + f, n,
+                           nd.d_invcov);
+        sub->outs.push_back(std::move(nd));
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();     // the descriptors are released below
+    (void)pool_free(d);
+    if (e != hipSuccess) { bluest_plan_destroy(sub); HIP_TRY(e); }
+    timer.lap("gather inverses (device)");
+    rc = bluest_plan_finalize(sub, max_candidates);
+    if (rc) { bluest_plan_destroy(sub); return rc; }
+    *restricted = sub;
+    return BLUEST_OK;
+}
+
 extern "C" int bluest_plan_n_outputs(bluest_plan_t plan, int *n)
 {
     if (!plan || !n) return fail(BLUEST_ERR_ARG, "null pointer");

@@ -14,7 +14,7 @@ import torch
 
 from . import misc
 from .plan import EVAL_INF, EVAL_SINGULAR, Plan
-from .sap import BLUESTError, LazyIndicators, SAP, SpgAllocator, enforce_sample_caps, host_section, in_host_section, normalise_groups, status_to_python
+from .sap import BLUESTError, LazyIndicators, SAP, SpgAllocator, restrict_plan, enforce_sample_caps, host_section, in_host_section, normalise_groups, status_to_python
 
 
 def _group_keys(gk, N):
@@ -247,24 +247,9 @@ class MOSAP(object):
         return variances, gradients, hessians
 
     def _restricted_plan(self, keep):
-        """shared plan of this problem restricted to the global groups `keep` (sorted indices); stored pseudo-inverses reused"""
-        keep = np.asarray(keep, dtype=np.int64)
-        outs = []
-        for n in range(self.n_outputs):
-            sap, mp = self.SAPS[n], np.asarray(self.mappings[n])
-            local = np.flatnonzero(np.isin(mp, keep))                        # positions inside output n, ascending
-            groups, invcovs, sizes = [], [], []
-            for k in range(1, sap.K + 1):
-                lo, hi = sap.cumsizes[k - 1], sap.cumsizes[k]
-                sel = local[(local >= lo) & (local < hi)]
-                groups.append(np.asarray(sap.groups[k - 1]).reshape(-1, k)[sel - lo])
-                invcovs.append(sap._gather_inverses(sel))
-                sizes.append(len(sel))
-            if not any(len(g) and (g == 0).any() for g in groups):
-                raise BLUESTError("restricted plan: output %d would not sample model 0" % n)
-            outs.append({"K": sap.K, "sizes": sizes, "groups": groups, "invcovs": invcovs,
-                         "mapping": np.searchsorted(keep, mp[local])})
-        return Plan(self.N, len(keep), outs, max_candidates=1, device=self.plan.device)
+        """shared plan of this problem restricted to the global groups `keep` (sorted indices): built natively from the shared
+        plan (bluest_plan_restrict: group lists filtered on the host, stored pseudo-inverses gathered on the device)"""
+        return restrict_plan(self.plan, np.asarray(keep, dtype=np.int64))
 
     def get_cleanup_matrices(self, m, delta=0, columns=None):
         """bluest/mosap.py:102-111: the per-output cleanup matrices stacked, (n_outputs*N, L).  Phi of every output comes

@@ -101,6 +101,9 @@ class Plan(object):
                 self.lib.bluest_plan_destroy(self._h)
                 self._h = None
                 raise
+        self._after_finalize()
+
+    def _after_finalize(self):
         glen = ctypes.c_int64(0)
         offs = (ctypes.c_int64 * self.n_out)()
         check(self.lib.bluest_plan_grad_layout(self._h, ctypes.byref(glen), offs))
@@ -110,6 +113,31 @@ class Plan(object):
         check(self.lib.bluest_plan_traffic(self._h, ctypes.byref(pb), ctypes.byref(gb)))
         self.phi_bytes, self.grad_bytes = pb.value, gb.value
         self.reclen = self.N * self.N + 2 * self.N + 1
+
+    def restrict(self, keep, max_candidates=1):
+        """a new Plan over the sub-list `keep` (sorted global group indices) of this plan's groups: allocation vectors of length
+        len(keep), every output keeps its groups inside `keep`, pseudo-inverses gathered on the device (bluest_plan_restrict).
+        Raises BLUESTError-compatible RuntimeError (via check) if an output would lose model 0."""
+        keep = _i64(keep)
+        sub = Plan.__new__(Plan)
+        sub.lib, sub.device, sub.N, sub.L, sub.n_out = self.lib, self.device, self.N, len(keep), self.n_out
+        sub.max_candidates = int(max_candidates)
+        sub._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.bluest_plan_restrict(self._h, ptr(keep), len(keep), sub.max_candidates, ctypes.byref(sub._h)))
+        sub._sizes, sub._mappings, sub._n_inv = [], [], []
+        for o in range(sub.n_out):
+            K = ctypes.c_int(0)
+            check(self.lib.bluest_plan_output_layout(sub._h, o, ctypes.byref(K), None, None))
+            sizes = np.zeros(K.value, dtype=np.int64)
+            check(self.lib.bluest_plan_output_layout(sub._h, o, ctypes.byref(K), ptr(sizes), None))
+            mapping = np.zeros(int(sizes.sum()), dtype=np.int64)
+            check(self.lib.bluest_plan_output_layout(sub._h, o, ctypes.byref(K), ptr(sizes), ptr(mapping)))
+            sub._sizes.append(sizes)
+            sub._mappings.append(mapping)
+            sub._n_inv.append(int(sum(int(sizes[k - 1]) * k * k for k in range(1, K.value + 1))))
+        sub._after_finalize()
+        return sub
 
     @property
     def invcovs(self):

@@ -149,6 +149,17 @@ def enforce_sample_caps(plan, costs, es, rhs, samples, budget, eps, solver_param
     return m
 
 
+def restrict_plan(plan, keep):
+    """plan.restrict(keep) with the library's "an output would lose model 0" turned into BLUESTError (what the solver expects)"""
+    from ._lib import BluestHipError
+    try:
+        return plan.restrict(keep)
+    except BluestHipError as err:
+        if "would not sample model 0" in str(err):
+            raise BLUESTError(str(err))
+        raise
+
+
 def support_multipliers(G, x):
     """mu >= 0, sum mu = 1 minimising the x-weighted variance over the support of sum_o mu_o G[o]: the multipliers of the active
     outputs in the KKT conditions of min_x max_o V_o(x) over the simplex (stationarity: the combined gradient is constant where
@@ -628,6 +639,8 @@ class SAP(object):
     def _restricted_plan(self, keep):
         """plan of this problem restricted to the groups `keep` (sorted global indices); the stored pseudo-inverses are reused"""
         keep = np.asarray(keep, dtype=np.int64)
+        if self.plan.n_out == 1 and self._plan_output == 0:
+            return restrict_plan(self.plan, keep)                        # native: bluest_plan_restrict
         groups, invcovs, sizes = [], [], []
         for k in range(1, self.K + 1):
             lo, hi = self.cumsizes[k - 1], self.cumsizes[k]

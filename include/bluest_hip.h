@@ -126,6 +126,16 @@ int bluest_plan_add_output_cov(bluest_plan_t plan, const double *C, int K, const
 int bluest_plan_get_invcovs(bluest_plan_t plan, int output, double *invcovs_out);
 int bluest_plan_gather_invcovs(bluest_plan_t plan, int output, const int64_t *local_idx, int64_t n, double *out);
 
+/* A NEW finalized plan over the sub-list `keep` (n_keep strictly ascending global group indices) of a finalized plan's groups:
+ * allocation vectors of the new plan have length n_keep (entry i = group keep[i]); every output keeps the groups whose global
+ * index is in `keep`, with the parent's pseudo-inverses gathered on the device (no host round trip).  This is the operator of
+ * bluest/sap.py:53-79 built on a subset of the groups -- the working set of the solver.  Fails with BLUEST_ERR_ARG if some
+ * output would be left without a group containing model 0 (its variance would be infinite whatever the allocation).
+ * bluest_plan_output_layout returns what the host mirror needs of one output: K, the sizes L_k (K entries) and, if `mapping`
+ * is non-NULL, the global indices of its groups (sum L_k entries); pass sizes = NULL to query K alone. */
+int bluest_plan_restrict(bluest_plan_t parent, const int64_t *keep, int64_t n_keep, int max_candidates, bluest_plan_t *restricted);
+int bluest_plan_output_layout(bluest_plan_t plan, int output, int *K, int64_t *sizes, int64_t *mapping);
+
 /* Build the HBM layouts.  max_candidates = largest number of allocation vectors evaluated per call. */
 int bluest_plan_finalize(bluest_plan_t plan, int max_candidates);
 

@@ -286,14 +286,20 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
                                                     const double *__restrict__ tvals, const uint8_t *__restrict__ tidx,
                                                     double *__restrict__ var, double *__restrict__ v_ws,
                                                     int32_t *__restrict__ status, double *__restrict__ grad,
-                                                    const int32_t *__restrict__ gate)
+                                                    const int32_t *__restrict__ gate, double *__restrict__ spg_state, int last_slot,
+                                                    int32_t *__restrict__ spg_enable, unsigned int *__restrict__ ticket)
 {
     constexpr int FUSED_TPB = fused_tpb(NT, KU);
     constexpr int NTHREADS = 64 * (FUSED_TPB + 1);
     constexpr int NE = KU * (KU + 1) / 2;
     __shared__ SolveLds<NT> lds;
-    if (gate && *gate == 0) return;
+    __shared__ double spg_ls[SPG_STATE_DOUBLES];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (gate && *gate == 0) {
+        // predicated off; the line-search decision still has to close the slot (see k_solve_from_chunks)
+        if (spg_state && blockIdx.x == 0 && wave == 0) spg_decide_wave(spg_state, var, status, n_out, last_slot, spg_enable, spg_ls, lane);
+        return;
+    }
     SPAN_BEGIN(1);
     PHASE(0);
     const int64_t t0 = (int64_t)blockIdx.x * FUSED_TPB;
@@ -339,7 +345,29 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
         for (int e = 0; e < NE; e++) if (e < ne) s[e] = vals[e * 64];
     }
     __syncthreads();
-    if (wave == 0) { SPAN_END(1, true); return; }
+    if (wave == 0) {
+        if (spg_state && first) {
+            // SPG line search: the first workgroup of every output has published V and status above; they take a ticket and the
+            // last one to arrive decides (same protocol as the tail of k_solve_from_chunks), while the tile wavefronts of all
+            // workgroups compute the gradient of this trial point -- it is the one the update needs if the trial is accepted
+            int last = 0;
+            if (lane == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = (t == (unsigned int)(n_out - 1)) ? 1 : 0;
+                if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            last = __builtin_amdgcn_readfirstlane(last);
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                spg_decide_wave(spg_state, var, status, n_out, last_slot, spg_enable, spg_ls, lane);
+            }
+        }
+        SPAN_END(1, true);
+        return;
+    }
     const bool valid = lane < (td.n_valid & 0xffff);
     const bool inf = lds.status == BLUEST_EVAL_INF;
     double *gout = grad + td.grad_off + lane;
@@ -947,6 +975,8 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     plan->grad_len = grad_len;
 
     // ---- inverse maps for combine_grad ------------------------------------------------------------
+    plan->identity = plan->shared && plan->outs[0].L_o == plan->L;
+    for (int64_t li = 0; plan->identity && li < plan->L; li++) plan->identity = plan->outs[0].mapping[li] == li;
     std::vector<int32_t> invmap((size_t)n_out * plan->L, -1);
     parallel_items(n_out, [&](int o) {
         for (int64_t li = 0; li < plan->outs[o].L_o; li++) invmap[(size_t)o * plan->L + plan->outs[o].mapping[li]] = (int32_t)li;
@@ -1269,6 +1299,14 @@ extern "C" int bluest_plan_eval_decide(bluest_plan_t plan, const double *m_dev, 
     return plan_eval(plan, m_dev, 1, 0, delta, var_dev, nullptr, 0, status_dev, stream, state_dev, last_slot, enable_dev);
 }
 
+extern "C" int bluest_plan_eval_grad_decide(bluest_plan_t plan, const double *m_dev, double delta, double *var_dev, double *grad_dev,
+                                            int32_t *status_dev, double *state_dev, int last_slot, int32_t *enable_dev, void *stream)
+{
+    if (!state_dev || !enable_dev || !status_dev || !grad_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (plan && (int)plan->outs.size() > SPG_MAX_OUT) return fail(BLUEST_ERR_ARG, "more than %d outputs", SPG_MAX_OUT);
+    return plan_eval(plan, m_dev, 1, 0, delta, var_dev, grad_dev, plan ? plan->grad_len : 0, status_dev, stream, state_dev, last_slot, enable_dev);
+}
+
 static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, double delta,
                      double *var_dev, double *grad_dev, int64_t grad_stride, int32_t *status_dev, void *stream,
                      double *dec_state, int dec_last, int32_t *dec_enable)
@@ -1287,7 +1325,8 @@ static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_
     if (grad_dev && n_cand == 1 && !g_debug_solve) {
         const dim3 grid((unsigned)(plan->n_tiles / plan->fused_tpb));
 #define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, \
-                                        delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->d_tvals, plan->d_tidx, var_dev, plan->d_v, status, grad_dev, plan->gate)
+                                        delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->d_tvals, plan->d_tidx, var_dev, plan->d_v, status, grad_dev, plan->gate, \
+                                        dec_state, dec_last, dec_enable, plan->d_ticket)
 #define LSG(NT) do { if (kmax <= 5) LSG2(NT, 5); else if (kmax <= 6) LSG2(NT, 6); else if (kmax <= 8) LSG2(NT, 8); else LSG2(NT, 12); } while (0)
         NT_DISPATCH(plan->N, LSG);
 #undef LSG

@@ -31,6 +31,7 @@ struct bluest_plan_s {
     int max_cand = 0;
     int iters = 1;  // chunk = 256*iters entries
     bool shared = false;  // all outputs have identical groups + mapping
+    bool identity = false; // ... and that mapping is the identity (local index = global index for every output)
     int fused_bpo = 0;    // workgroups of k_solve_grad per output when that is the same for every output, else 0
     int fused_tpb = 15;   // tiles per workgroup of k_solve_grad for this plan (tile list is padded to it per output)
     const int32_t *gate = nullptr;  // optional device word: 0 = skip the plan's kernels (bluest_plan_set_gate)

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(1024) void k_spg_update_a_fused(double *__restrict_
                                                              const int64_t *__restrict__ goff, const int32_t *__restrict__ invmap,
                                                              int n_out, const double *__restrict__ scale,
                                                              double *__restrict__ st, double floor, int64_t L,
-                                                             double2 *__restrict__ partial)
+                                                             double2 *__restrict__ partial, int identity)
 {
     __shared__ ProjLds sm;
     __shared__ int s_last;
@@ -199,9 +199,13 @@ __global__ __launch_bounds__(1024) void k_spg_update_a_fused(double *__restrict_
     long long dummy = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + tid; i < L; i += (int64_t)gridDim.x * blockDim.x) {
         double gn = 0.0;
-        for (int o = 0; o < n_out; o++) {
-            const int32_t li = invmap[(int64_t)o * L + i];
-            if (li >= 0) gn = fma(st[SPG_COEF + o], grad[goff[o] + li], gn);
+        if (identity) {   // every output over all groups in global order: coalesced streams, no index loads
+            for (int o = 0; o < n_out; o++) gn = fma(st[SPG_COEF + o], grad[(int64_t)o * L + i], gn);
+        } else {
+            for (int o = 0; o < n_out; o++) {
+                const int32_t li = invmap[(int64_t)o * L + i];
+                if (li >= 0) gn = fma(st[SPG_COEF + o], grad[goff[o] + li], gn);
+            }
         }
         gn *= scale[i];
         const double xi = x[i], gi = g[i], xn = xnew[i];
@@ -1059,7 +1063,7 @@ extern "C" int bluest_spg_update_fused(bluest_plan_t plan, double *x_dev, double
     // 256-thread workgroups: at K_tot = 21699 that is 85 compute units instead of 22 for a kernel made of dependent gathers
     const int nblocks = (int)std::min<int64_t>((L + 255) / 256, SPG_UPD_BLOCKS_MAX);
     hipLaunchKernelGGL(k_spg_update_a_fused, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, x_dev, g_dev, xnew_dev, grad_dev, plan->d_goff,
-                       plan->d_invmap, (int)plan->outs.size(), scale_dev, state_dev, floor, L, (double2 *)work_dev);
+                       plan->d_invmap, (int)plan->outs.size(), scale_dev, state_dev, floor, L, (double2 *)work_dev, plan->identity ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }
@@ -1119,13 +1123,21 @@ extern "C" int bluest_spg_window(bluest_plan_t plan, double *x_dev, double *g_de
         return fail(BLUEST_ERR_ARG, "null pointer");
     if (slots < 1 || slots > 8 || n_iterations < 0) return fail(BLUEST_ERR_ARG, "slots=%d, n_iterations=%d out of range", slots, n_iterations);
     const int64_t L = plan->L;
+    // small plans: the gradient tiles of the accepted point run inside the single-workgroup finishing kernel; large plans: every
+    // evaluation is the fused solve + gradient launch (decision in its tail), so the update follows the line search directly
+    const bool small = plan->L <= 4096 && plan->n_tiles <= 1024;
     for (int it = 0; it < n_iterations; it++) {
         if ((rc = bluest_spg_direction(x_dev, g_dev, state_dev, 1.0, floor, L, d_dev, scale_dev, xnew_dev, m_dev, enable_dev, proj_work_dev, stream))) return rc;
         for (int t = 0; t < slots; t++) {
+            const int last = t == slots - 1 ? 1 : 0;
             if (t > 0 && (rc = bluest_spg_trial(x_dev, d_dev, scale_dev, state_dev, xnew_dev, m_dev, enable_dev, L, stream))) return rc;
-            if ((rc = bluest_plan_eval_decide(plan, m_dev, 0.0, var_dev, status_dev, state_dev, t == slots - 1 ? 1 : 0, enable_dev, stream))) return rc;
+            if (small) rc = bluest_plan_eval_decide(plan, m_dev, 0.0, var_dev, status_dev, state_dev, last, enable_dev, stream);
+            else rc = bluest_plan_eval_grad_decide(plan, m_dev, 0.0, var_dev, grad_dev, status_dev, state_dev, last, enable_dev, stream);
+            if (rc) return rc;
         }
-        if ((rc = bluest_spg_finish(plan, v_ws_dev, status_dev, x_dev, g_dev, xnew_dev, grad_dev, scale_dev, state_dev, floor, work_dev, stream))) return rc;
+        if (small) rc = bluest_spg_finish(plan, v_ws_dev, status_dev, x_dev, g_dev, xnew_dev, grad_dev, scale_dev, state_dev, floor, work_dev, stream);
+        else rc = bluest_spg_update_fused(plan, x_dev, g_dev, xnew_dev, grad_dev, scale_dev, state_dev, floor, work_dev, stream);
+        if (rc) return rc;
     }
     if (check_last && (rc = bluest_spg_converged(x_dev, g_dev, state_dev, 1.0, floor, L, proj_work_dev, stream))) return rc;
     return BLUEST_OK;

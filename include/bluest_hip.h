@@ -226,6 +226,11 @@ int bluest_plan_set_gate(bluest_plan_t plan, const int32_t *enable_dev, int alwa
  * bluest_spg_decide fused into the tail of the solve kernel -- the output workgroup that finishes last evaluates the decision. */
 int bluest_plan_eval_decide(bluest_plan_t plan, const double *m_dev, double delta, double *var_dev, int32_t *status_dev,
                             double *state_dev, int last_slot, int32_t *enable_dev, void *stream);
+/* The same with the gradient of the trial point (bluest_plan_eval's fused solve + gradient launch, decision in its tail): the
+ * gradient of a rejected trial is wasted work (~2 us), the gradient of the accepted one is what the update needs -- no separate
+ * gradient launch after the line search.  grad_dev: grad_len doubles (bluest_plan_grad_layout). */
+int bluest_plan_eval_grad_decide(bluest_plan_t plan, const double *m_dev, double delta, double *var_dev, double *grad_dev,
+                                 int32_t *status_dev, double *state_dev, int last_slot, int32_t *enable_dev, void *stream);
 int bluest_plan_v_workspace(bluest_plan_t plan, const double **v_dev, const int32_t **status_dev);
 int bluest_spg_direction(const double *x_dev, const double *g_dev, double *state_dev, double z, double floor, int64_t L,
                          double *d_dev, const double *scale_dev, double *xnew_dev, double *m_dev, int32_t *enable_dev,

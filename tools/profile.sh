@@ -46,5 +46,10 @@ for r in list(csv.DictReader(open(f)))[:18]:
     print("%-60s %8s %10.2f us avg  %6.2f%%" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
 PY
 tail -3 $OUT/spg_out.json >> $SUM/${TAG}_spg_loop_kernel_stats.txt
+# (6) average kernel timeline of one SPG step (full problem: anchor k_proj_fused; working set: anchor k_simplex)
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_step -o t -- python tools/one_solve.py 20 5 8 2 > $OUT/one_solve.log 2> $OUT/one_solve.err
+F=$(find $OUT/trace_step -name "*kernel_trace.csv" | head -1)
+{ echo "# full-problem steps (K_tot = 21699)"; python tools/iter_timeline.py $F k_proj_fused; echo; echo "# working-set steps"; python tools/iter_timeline.py $F k_simplex; grep rep $OUT/one_solve.log; } > $SUM/${TAG}_spg_step_timeline.txt 2>&1
+echo "step timeline done"
 rm -rf $OUT
 ls -la $SUM

@@ -311,6 +311,7 @@ def _certify(oracle, Cs, kmax, groups, costs, m, eps=None):
     saps = [oracle.SparseOracleSAP(C, kmax, groups) for C in Cs]
     s = None if eps is None else np.asarray(eps, dtype=np.float64) ** 2
     gap, lb, mu, info = oracle.optimality_certificate(saps, m, costs, s=s, max_seconds=150)
+    print("certified gap (F - LB)/F = %.3e  [n=%d, K_tot=%d, n_out=%d]" % (gap, Cs[0].shape[0], len(m), len(Cs)))   # pytest -s / -rP
     return gap, np.array([q.variance(m) for q in saps]), (mu, info)
 
 

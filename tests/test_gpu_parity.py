@@ -750,3 +750,56 @@ def test_blue_estimator_vs_reference_fixture(gpu):
         assert abs(mu / float(G["mu%d" % case]) - 1) < TOL and abs(var / float(G["var%d" % case]) - 1) < TOL
         mus, Vars = mos.compute_BLUE_estimators([sums], samples)
         assert abs(mus[0] / float(G["mu%d" % case]) - 1) < TOL and abs(Vars[0] / float(G["var%d" % case]) - 1) < TOL
+
+
+def test_native_restricted_plan_equals_the_hand_built_one():
+    """bluest_plan_restrict (group lists filtered on the host, pseudo-inverses gathered device to device) against a plan built
+    from explicitly gathered inverses through bluest_plan_add_output: identical V, grad V and status bit for bit; an output that
+    would lose model 0 is refused"""
+    import torch
+    from bluest_amd import BLUESTError
+    from bluest_amd.mosap import MOSAP
+    from bluest_amd.plan import Plan
+    rng = np.random.RandomState(11)
+    n, kmax, n_out = 9, 4, 3
+    prob = synth.problem(n, kmax, n_out)
+    groups = prob["groups"]
+    # different group sets per output (ragged mappings)
+    multi = []
+    for o in range(n_out):
+        mg = []
+        for g in groups:
+            keep_rows = np.sort(rng.choice(len(g), max(2, (2 * len(g)) // 3), replace=False))
+            keep_rows = np.union1d(keep_rows, np.flatnonzero((g == 0).any(axis=1))[:2])
+            mg.append(g[keep_rows].copy())
+        multi.append(mg)
+    costs = prob["costs"]
+    multi_costs = [synth.group_costs(mg, prob["w"]) for mg in multi]
+    mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], multi, costs, multi_costs, verbose=False)
+    keep = np.unique(np.concatenate([np.flatnonzero(mos.e > 0), rng.choice(mos.L, 40, replace=False)]))
+    sub = mos._restricted_plan(keep)                                     # native
+    outs = []
+    for o in range(n_out):
+        sap, mp = mos.SAPS[o], np.asarray(mos.mappings[o])
+        local = np.flatnonzero(np.isin(mp, keep))
+        gs, ics, sizes = [], [], []
+        for k in range(1, sap.K + 1):
+            lo, hi = sap.cumsizes[k - 1], sap.cumsizes[k]
+            sel = local[(local >= lo) & (local < hi)]
+            gs.append(np.asarray(sap.groups[k - 1]).reshape(-1, k)[sel - lo])
+            ics.append(np.asarray(sap.invcovs[k - 1]).reshape(-1, k * k)[sel - lo].ravel())
+            sizes.append(len(sel))
+        outs.append({"K": sap.K, "sizes": sizes, "groups": gs, "invcovs": ics, "mapping": np.searchsorted(keep, mp[local])})
+    hand = Plan(n, len(keep), outs, max_candidates=1, device=sub.device)
+    assert sub.L == hand.L == len(keep) and sub.grad_len == hand.grad_len and sub.grad_off == hand.grad_off
+    for o in range(n_out):
+        assert np.array_equal(sub._sizes[o], np.asarray(outs[o]["sizes"])) and np.array_equal(sub._mappings[o], outs[o]["mapping"])
+    m = torch.from_numpy(0.5 + 5 * rng.rand(len(keep))).to(sub.device)
+    v1, g1, s1 = sub.eval(m)
+    v2, g2, s2 = hand.eval(m)
+    assert torch.equal(v1, v2) and torch.equal(g1, g2) and torch.equal(s1, s2)
+    with pytest.raises(BLUESTError):
+        mos._restricted_plan(np.flatnonzero(mos.e == 0)[:50])            # no group with model 0 left
+    from bluest_amd._lib import BluestHipError
+    with pytest.raises(BluestHipError):
+        mos.plan.restrict(np.array([5, 3, 9]))                           # not ascending

@@ -56,3 +56,50 @@ def test_spg_driver_on_numpy(oracle):
     # KKT: gradient constant on the support, larger off it
     g = geval(r1["x"]); sup = r1["x"] > 0
     assert np.ptp(g[sup]) < 1e-8 and (g[~sup] >= g[sup].max() - 1e-8).all()
+
+
+def test_host_section_limits_blas_and_pauses_the_collector():
+    """bluest_amd/host.py: inside the section the automatic cyclic collector is off and every BLAS pool runs on one thread (a
+    container whose CPU quota is below its visible core count gets throttled by OpenBLAS's spinning workers otherwise,
+    profiles/r02_host_stall.txt); both are restored on exit, also when the body raises, and sections nest"""
+    import gc
+    from bluest_amd.host import host_section, in_host_section
+    threadpoolctl = pytest.importorskip("threadpoolctl")
+
+    def blas_threads():
+        return [p["num_threads"] for p in threadpoolctl.threadpool_info() if p["user_api"] == "blas"]
+
+    before = blas_threads()
+    assert gc.isenabled() and before
+    with host_section():
+        assert not gc.isenabled() and all(n == 1 for n in blas_threads())
+        with host_section():
+            assert not gc.isenabled() and all(n == 1 for n in blas_threads())
+        assert not gc.isenabled() and all(n == 1 for n in blas_threads())
+    assert gc.isenabled() and blas_threads() == before
+
+    @in_host_section
+    def body(x):
+        assert not gc.isenabled()
+        raise KeyError(x)
+
+    with pytest.raises(KeyError):
+        body(3)
+    assert gc.isenabled() and blas_threads() == before
+    assert body.__name__ == "body"
+
+
+def test_support_multipliers_recover_the_kkt_weights():
+    """pricing of the working set: the multipliers of the active outputs are those that make the combined gradient constant on
+    the support (bluest_amd/sap.py: support_multipliers)"""
+    from bluest_amd.sap import support_multipliers
+    rng = np.random.RandomState(4)
+    n_act, S = 3, 40
+    mu_true = np.array([0.6, 0.3, 0.1])
+    G = rng.randn(n_act, S)
+    # make mu_true . G constant: fix the last row accordingly
+    G[2] = (1.7 - mu_true[0] * G[0] - mu_true[1] * G[1]) / mu_true[2]
+    x = rng.rand(S)
+    mu = support_multipliers(G, x)
+    assert mu.min() >= 0 and abs(mu.sum() - 1) < 1e-12 and np.abs(mu - mu_true).max() < 1e-6
+    assert np.array_equal(support_multipliers(G[:1], x), np.ones(1))

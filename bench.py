@@ -47,8 +47,8 @@ def build_outputs(prob):
 def sap_wallclock(prob, reps=4):
     """second half of BASELINE.json's metric: wall-clock from the covariances to the continuous optimum m* (MOSAP construction:
     group pseudo-inverses + HBM layouts, then solver="spg" on the GPU).  Nothing is hidden: repetition 0 is the cold one (first
-    launches, hipGraph captures), the others are warm; releasing a problem (plan memory + its captured graphs) is timed as
-    `release_s` of the repetition that created it, the garbage collector stays on."""
+    launches of every kernel), the others are warm; releasing a problem (its plans go back to the library's block cache) plus an
+    explicit full collection is timed as `release_s` of the repetition that created it, the garbage collector stays on."""
     import gc
     import torch
     from bluest_amd.mosap import MOSAP
@@ -66,6 +66,8 @@ def sap_wallclock(prob, reps=4):
         t2 = time.perf_counter()
         row = {"setup_s": t1 - t0, "solve_s": t2 - t1, "total_s": t2 - t0, "spg_iterations": int(mos.solver_info["it"]),
                "objective_evaluations": int(mos.solver_info["count"]), "max_variance": float(max(mos.variances(m)))}
+        # everything the solve does (full-problem and working-set steps, restricted plans, pricing, host checks) per trial point
+        row["solve_us_per_evaluation"] = row["solve_s"] / max(row["objective_evaluations"], 1) * 1e6
         t3 = time.perf_counter()
         mos = None
         gc.collect()
@@ -78,7 +80,8 @@ def sap_wallclock(prob, reps=4):
             "warm_all_total_s": [r["total_s"] for r in warm], "release_s_all": [r["release_s"] for r in rows],
             "budget": float(prob["budget"]), "solver": "spg (scaled metric, device-resident loop), continuous relaxation",
             "note": "total_s = set-up + solve; cold = first repetition of the process; warm = median of the following %d; release_s = "
-                    "dropping the problem afterwards (plan memory, captured hipGraphs, a full Python collection)" % len(warm)}
+                    "dropping the problem afterwards + a full Python collection; one solver step is 4 launches (direction, Phi "
+                    "pass, solve+gradient+decision, update), kernel timeline in profiles/*_spg_step_timeline.txt" % len(warm)}
 
 
 def pmc_traffic(kernel, cfg):

@@ -51,7 +51,7 @@ if os.environ.get("STACKWATCH"):
     sw = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro", "stackwatch.so"))
     sw.stackwatch_start(3000)
 keepers = []
-for rep in range(7):
+for rep in range(int(os.environ.get('REPS', '7'))):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in groups] for _ in range(n_out)],
@@ -90,4 +90,8 @@ for rep in range(7):
     del acc[:]
     print("    windows of the full-problem run (ms):", first_windows)
     del first_windows[:]
-    print("%s rep %d: setup %.1f ms, solve %.1f ms, release %.1f ms" % (mode, rep, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t4 - t3) * 1e3), flush=True)
+    try:
+        thr = [l.split()[1] for l in open("/sys/fs/cgroup/cpu.stat") if l.startswith("nr_throttled")][0]
+    except Exception:
+        thr = "?"
+    print("%s rep %d: setup %.1f ms, solve %.1f ms, release %.1f ms  (cgroup nr_throttled %s)" % (mode, rep, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t4 - t3) * 1e3, thr), flush=True)

@@ -33,6 +33,7 @@
 #define SPG_TICKET   28   // (32-bit counter in this slot) arrival ticket of the update launch's workgroups
 #define SPG_GDPARTS  29   // (pointer bits) per-workgroup partials of g.d left by the multi-workgroup direction kernel, stride 4
 #define SPG_GDPARTS_N 30  // how many (0: SPG_GD holds the folded value)
+#define SPG_THETA    31   // warm start of the single-workgroup direction search: (1 - tau_abs)/lambda of the previous one
 #define SPG_HIST     32   // 16 slots
 #define SPG_COEF     64   // dF/dV_o of the accepted trial (n_out <= 64)
 #define SPG_S        128  // normalisers s_o (1 or eps_o^2)

@@ -170,11 +170,14 @@ __global__ __launch_bounds__(fold_threads(NT)) void k_solve_from_chunks(int N, i
         if (spg_state && o == 0 && c == 0 && tid < WAVE) spg_decide_wave(spg_state, var, status, n_out, last_slot, spg_enable, spg_ls, tid);
         return;
     }
+    SpgPrefetch pf;
+    if (spg_state && tid < WAVE) spg_prefetch_state(spg_state, tid, pf);   // in flight during the fold (see spg_state.hpp)
     if (N < NT) { clear_pads(lds, N, tid, fold_threads(NT)); __syncthreads(); }   // uniform; every real entry is written by the fold
     fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, fold_threads(NT));
     __syncthreads();
     if (tid >= WAVE) return;   // single wavefront from here on
     const int lane = tid;
+    if (spg_state) spg_prefetch_parts(pf, lane);                           // in flight during the elimination
     const int64_t e = (int64_t)c * n_out + o;
     if (want_v & 2) {   // diagnostics: fold only (timing experiments)
         if (lane == 0) { var[e] = lds.at(0, 0); status[e] = 0; }
@@ -183,14 +186,21 @@ __global__ __launch_bounds__(fold_threads(NT)) void k_solve_from_chunks(int N, i
     const double am = (lane < N) ? lds.amax[lane] : 0.0;
     const bool big = __ballot(am >= 0.05) != 0ull;   // max |m| >= 0.05 (misc.py:464)
     const int reps = (want_v & 4) ? 2 : 1;   // diagnostics: run the solve twice
+    double V_mine = 0.0;
+    int32_t st_mine = 0;
     for (int rep = 0; rep < reps; rep++)
-        solve_wave<NT>(lds, N, delta, am > 1.0e-6, am > 0.0, big, (want_v & 1) != 0, var + e, v + e * N, status + e, lane);
+        solve_wave<NT>(lds, N, delta, am > 1.0e-6, am > 0.0, big, (want_v & 1) != 0, &V_mine, v + e * N, &st_mine, lane);
+    if (lane == 0) { var[e] = V_mine; status[e] = st_mine; }
     if (spg_state) {
         // line-search decision fused into the tail (single candidate): every output's workgroup publishes V and status, takes a
         // ticket, and the LAST one to arrive evaluates the objective of the trial point and decides -- one launch and one kernel
         // boundary less per slot.  Publication: stores drained, agent-scope release, then the ticket (relaxed agent atomic);
         // the last arriver acquires before it reads the other outputs' values (MI355X_MICROARCH.md, inter-workgroup visibility).
         int last = 0;
+        if (n_out == 1) {   // single output: nobody to wait for, V and status stay in lane 0's registers
+            spg_decide_wave(spg_state, var, status, n_out, last_slot, spg_enable, spg_ls, lane, pf, true, V_mine, st_mine);
+            return;
+        }
         if (lane == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -202,7 +212,7 @@ __global__ __launch_bounds__(fold_threads(NT)) void k_solve_from_chunks(int N, i
         last = __builtin_amdgcn_readfirstlane(last);
         if (last) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            spg_decide_wave(spg_state, var, status, n_out, last_slot, spg_enable, spg_ls, lane);
+            spg_decide_wave(spg_state, var, status, n_out, last_slot, spg_enable, spg_ls, lane, pf);
         }
     }
 }
@@ -308,6 +318,8 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
     int o, first;
     if (bpo > 0) { o = blockIdx.x / bpo; first = (blockIdx.x % bpo) == 0; }
     else { const TileDesc td0 = tiles[t0]; o = td0.out; first = (td0.n_valid >> 30) & 1; }
+    SpgPrefetch pf;
+    if (spg_state && first && wave == 0) spg_prefetch_state(spg_state, lane, pf);   // in flight during the fold (spg_state.hpp)
     if (N < NT) { clear_pads(lds, N, tid, NTHREADS); __syncthreads(); }   // uniform; every real entry is written by the fold
     PHASE(1);
     fold_rows<NT>(lds, N, rows, o * nsym, nsym, partial, tid, NTHREADS);
@@ -321,7 +333,10 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
     const int k = td.k;
     double s[NE];
     int gi[KU];
+    double V_pub = 0.0;      // wavefront 0: V and status of this workgroup's solve (for the single-output decision)
+    int32_t st_pub = 0;
     if (wave == 0) {
+        if (spg_state && first) spg_prefetch_parts(pf, lane);                       // in flight during the elimination
         const double am = (lane < N) ? lds.amax[lane] : 0.0;
         const bool big = __ballot(am >= 0.05) != 0ull;   // max |m| >= 0.05 (misc.py:464)
         double V = 0.0;
@@ -329,6 +344,7 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
         PHASE(8);
         solve_wave<NT>(lds, N, delta, am > 1.0e-6, am > 0.0, big, true, &V, lds.vout, &st, lane);
         if (lane == 0) lds.status = st;
+        V_pub = V; st_pub = st;
         if (first) {   // first workgroup of this output publishes V, status, v
             if (lane == 0) { var[o] = V; status[o] = st; }
             if (lane < N) v_ws[(int64_t)o * N + lane] = lds.vout[lane];
@@ -351,6 +367,11 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
             // last one to arrive decides (same protocol as the tail of k_solve_from_chunks), while the tile wavefronts of all
             // workgroups compute the gradient of this trial point -- it is the one the update needs if the trial is accepted
             int last = 0;
+            if (n_out == 1) {   // single output: nobody to wait for, V and status stay in lane 0's registers
+                spg_decide_wave(spg_state, var, status, n_out, last_slot, spg_enable, spg_ls, lane, pf, true, V_pub, st_pub);
+                SPAN_END(1, true);
+                return;
+            }
             if (lane == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -362,7 +383,7 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
             last = __builtin_amdgcn_readfirstlane(last);
             if (last) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                spg_decide_wave(spg_state, var, status, n_out, last_slot, spg_enable, spg_ls, lane);
+                spg_decide_wave(spg_state, var, status, n_out, last_slot, spg_enable, spg_ls, lane, pf);
             }
         }
         SPAN_END(1, true);

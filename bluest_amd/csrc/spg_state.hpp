@@ -54,11 +54,38 @@ __device__ __forceinline__ void spg_wave_lds_sync()
 // gate of the finishing launches; a trial rejected there leaves the line search PENDING (continued by the next direction launch,
 // so a window of the solver is a sequence of identical "steps" with no host round trip) unless the step length underflowed or
 // the evaluation budget is spent (FAIL).
-__device__ __forceinline__ void spg_decide_wave(double *__restrict__ st, const double *var, const int32_t *status, int n_out,
-                                                int last_slot, int32_t *__restrict__ enable, double *ls, int lane)
+// What the decision needs that no workgroup of the SAME launch changes: the state (written by earlier launches) and the
+// per-workgroup partials of g.d (written by the direction launch).  A kernel that ends with the decision issues these loads
+// early -- spg_prefetch_state before its own work, spg_prefetch_parts once the state has arrived -- so that the last arriver's
+// serial tail is ticket -> other outputs' values -> arithmetic, without two more dependent round trips to memory.
+struct SpgPrefetch {
+    double w[SPG_STATE_DOUBLES / 64];   // state words t*64 + lane
+    double gdpart;                      // this lane's partial of g.d (0 beyond the count)
+    int n_parts;
+};
+__device__ __forceinline__ void spg_prefetch_state(const double *st, int lane, SpgPrefetch &pf)
 {
 #pragma unroll
-    for (int t = 0; t < SPG_STATE_DOUBLES / 64; t++) ls[t * 64 + lane] = st[t * 64 + lane];
+    for (int t = 0; t < SPG_STATE_DOUBLES / 64; t++) pf.w[t] = st[t * 64 + lane];
+    pf.gdpart = 0.0;
+    pf.n_parts = 0;
+}
+__device__ __forceinline__ void spg_prefetch_parts(SpgPrefetch &pf, int lane)
+{
+    const double ptr_bits = __shfl(pf.w[0], SPG_GDPARTS);
+    pf.n_parts = (int)__shfl(pf.w[0], SPG_GDPARTS_N);
+    if (pf.n_parts > 0) {
+        const double *parts = reinterpret_cast<const double *>((uintptr_t)__double_as_longlong(ptr_bits));
+        pf.gdpart = lane < pf.n_parts ? parts[4 * lane + 1] : 0.0;
+    }
+}
+
+__device__ __forceinline__ void spg_decide_wave(double *__restrict__ st, const double *var, const int32_t *status, int n_out,
+                                                int last_slot, int32_t *__restrict__ enable, double *ls, int lane,
+                                                const SpgPrefetch &pf, bool own = false, double own_V = 0.0, int32_t own_status = 0)
+{   // own: single-output plan, lane 0 passes V and status of its own solve in registers (nothing is read back from memory)
+#pragma unroll
+    for (int t = 0; t < SPG_STATE_DOUBLES / 64; t++) ls[t * 64 + lane] = pf.w[t];
     spg_wave_lds_sync();
     const bool idle = ls[SPG_DONE] != 0.0 || ls[SPG_FAIL] != 0.0;
     if (idle || ls[SPG_ACCEPT] != 0.0) {
@@ -69,9 +96,16 @@ __device__ __forceinline__ void spg_decide_wave(double *__restrict__ st, const d
     const bool mine = lane < n_out;
     const double so = mine ? ls[SPG_S + lane] : 1.0;
     // agent-scope loads: in the fused form these values were written a moment ago by OTHER workgroups of the same launch
-    const double vo = mine ? __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(var) + lane,
-                                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
-    const int32_t so_status = mine ? __hip_atomic_load(status + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : BLUEST_EVAL_OK;
+    double vo = 0.0;
+    int32_t so_status = BLUEST_EVAL_OK;
+    if (own) {
+        vo = mine ? own_V : 0.0;
+        so_status = mine ? own_status : BLUEST_EVAL_OK;
+    } else if (mine) {
+        vo = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(var) + lane, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT));
+        so_status = __hip_atomic_load(status + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const double r = mine ? vo / so : 0.0;
     const bool bad = mine && (so_status != BLUEST_EVAL_OK || !isfinite(r));
     const bool ok = __ballot(bad) == 0ull;
@@ -98,11 +132,7 @@ __device__ __forceinline__ void spg_decide_wave(double *__restrict__ st, const d
     double fmax = -INFINITY;
     for (int h = 0; h < H; h++) fmax = fmax > ls[SPG_HIST + h] ? fmax : ls[SPG_HIST + h];
     double gd = ls[SPG_GD];
-    const int n_parts = (int)ls[SPG_GDPARTS_N];
-    if (n_parts > 0) {   // the direction kernel left per-workgroup partials (<= 64): fixed-order fold
-        const double *parts = reinterpret_cast<const double *>((uintptr_t)__double_as_longlong(ls[SPG_GDPARTS]));
-        gd = wave_sum(lane < n_parts ? parts[4 * lane + 1] : 0.0);
-    }
+    if (pf.n_parts > 0) gd = wave_sum(pf.gdpart);   // the direction kernel left per-workgroup partials (<= 64): fixed-order fold
     const double alpha = ls[SPG_ALPHA], f = ls[SPG_F];
     const bool accept = F <= fmax + 1.0e-4 * alpha * gd;
     if (accept && mine) st[SPG_COEF + lane] = coef / norm;
@@ -131,4 +161,14 @@ __device__ __forceinline__ void spg_decide_wave(double *__restrict__ st, const d
         if (accept) st[SPG_PENDING] = 0.0;
         if (last_slot) *enable = accept ? 1 : 0;
     }
+}
+
+// the decision without an early prefetch (stand-alone kernel, predicated-off launches)
+__device__ __forceinline__ void spg_decide_wave(double *__restrict__ st, const double *var, const int32_t *status, int n_out,
+                                                int last_slot, int32_t *__restrict__ enable, double *ls, int lane)
+{
+    SpgPrefetch pf;
+    spg_prefetch_state(st, lane, pf);
+    spg_prefetch_parts(pf, lane);
+    spg_decide_wave(st, var, status, n_out, last_slot, enable, ls, lane, pf);
 }

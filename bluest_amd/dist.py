@@ -209,6 +209,67 @@ class ShardedPlan(object):
     def lib(self):
         return self.plan.lib
 
+    def output_gradients(self, grad_local):
+        """plan.Plan.output_gradients for the whole group set: (n_out, K_tot) host array, every rank contributes the rows of its
+        groups and one all-reduce(SUM) assembles them (used by the working-set pricing of the solver)"""
+        G = torch.from_numpy(self.plan.output_gradients(grad_local))
+        if self.world > 1:
+            Gd = G.to(self.device) if (self.device is not None and dist.get_backend(self.group) == "nccl") else G
+            dist.all_reduce(Gd, op=dist.ReduceOp.SUM, group=self.group)
+            G = Gd.cpu()
+        return G.numpy()
+
+    def replicated_subplan(self, keep):
+        """the (small) plan of the WHOLE problem restricted to the global groups `keep`, built identically on every rank: each rank
+        gathers the k x k pseudo-inverse blocks of its own groups inside `keep` on its device, the pieces are all-gathered, and
+        every rank assembles the same plan.Plan -- the working set of the solver over a sharded group set (collective)"""
+        from .plan import Plan
+        from .sap import BLUESTError
+        keep = np.asarray(keep, dtype=np.int64)
+        mine = []
+        for o, out in enumerate(self.local_outputs):
+            mp = np.asarray(out["mapping"], dtype=np.int64)
+            local = np.flatnonzero(np.isin(mp, keep))
+            cum = np.cumsum([0] + [int(x) for x in out["sizes"]])
+            ks = np.searchsorted(cum, local, side="right")                       # group size of every kept local group
+            groups = [np.asarray(out["groups"][k - 1], dtype=np.int64).reshape(-1, k)[local[ks == k] - cum[k - 1]]
+                      for k in range(1, int(out["K"]) + 1)]
+            blocks = self.plan.gather_invcovs(o, local) if len(local) else np.zeros(0)   # concatenated in the order of `local`
+            mine.append((mp[local], ks, groups, blocks))
+        pieces = [mine]
+        if self.world > 1:
+            pieces = [None] * self.world
+            dist.all_gather_object(pieces, mine, group=self.group)
+        outs = []
+        for o in range(self.n_out):
+            K = int(self.local_outputs[o]["K"])
+            gidx = [[] for _ in range(K)]
+            grp = [[] for _ in range(K)]
+            blk = [[] for _ in range(K)]
+            for part in pieces:                                                   # rank order = ascending global index
+                idx, ks, groups, blocks = part[o]
+                off = 0
+                pos = [0] * K
+                for i in range(len(idx)):
+                    k = int(ks[i])
+                    gidx[k - 1].append(int(idx[i]))
+                    grp[k - 1].append(groups[k - 1][pos[k - 1]])
+                    blk[k - 1].append(blocks[off:off + k * k])
+                    pos[k - 1] += 1
+                    off += k * k
+            sizes, groups_k, inv_k, glob = [], [], [], []
+            for k in range(1, K + 1):
+                order = np.argsort(np.asarray(gidx[k - 1], dtype=np.int64), kind="stable")
+                sizes.append(len(order))
+                groups_k.append(np.asarray([grp[k - 1][j] for j in order], dtype=np.int64).reshape(-1, k))
+                inv_k.append(np.concatenate([blk[k - 1][j] for j in order]) if len(order) else np.zeros(0))
+                glob.extend(gidx[k - 1][j] for j in order)
+            if not any(len(g) and (g == 0).any() for g in groups_k):
+                raise BLUESTError("restricted plan: output %d would not sample model 0" % o)
+            outs.append({"K": K, "sizes": sizes, "groups": groups_k, "invcovs": inv_k,
+                         "mapping": np.searchsorted(keep, np.asarray(glob, dtype=np.int64))})
+        return Plan(self.N, len(keep), outs, max_candidates=1, device=self.device)
+
     def combine_grad(self, grad_local, coef, scale=None, out=None):
         """plan.Plan.combine_grad for the whole group set (same signature): see global_gradient"""
         return self.global_gradient(grad_local, coef, scale=scale)
@@ -241,6 +302,8 @@ def sharded_spg(sharded, costs, budget=None, eps=None, x0=None, params=None):
         prm.update(params)
     if not on_gpu:
         prm["device_loop"] = False                                 # CPU stand-in plans (tests): the host-driven driver
-    alloc = SpgAllocator(sharded, costs, None, verbose=False, subplan=None)
+    # the working set of the last stages is small: it is built identically on every rank and solved redundantly, the pricing of
+    # the excluded groups in between is collective
+    alloc = SpgAllocator(sharded, costs, None, verbose=False, subplan=sharded.replicated_subplan if on_gpu else None)
     m = alloc.solve(budget=budget, eps=eps, x0=x0, params=prm)
     return m, alloc.info

@@ -43,7 +43,9 @@ def main(out_path):
             dist.all_gather(gathered, a.cpu())
             same = same and all(torch.equal(gathered[0], q) for q in gathered)
         res["peer_exchange_err"], res["peer_exchange_identical_on_all_ranks"], res["peer_exchange_timed_out"] = worst, same, ex.timed_out()
-    for tag, (n, kmax, n_out) in (("n12_k4_o1", (12, 4, 1)), ("n10_k3_o3", (10, 3, 3))):
+    # (the third problem is long enough, K_tot = 6884 > 4096, for the solver's working set: replicated restricted plans,
+    # collective pricing)
+    for tag, (n, kmax, n_out) in (("n12_k4_o1", (12, 4, 1)), ("n10_k3_o3", (10, 3, 3)), ("n16_k5_o2", (16, 5, 2))):
         prob = synth.problem(n, kmax, n_out)
         sizes = [len(g) for g in prob["groups"]]
         outs = [{"K": kmax, "sizes": sizes, "groups": prob["groups"], "C": prob["C"][o], "mapping": None} for o in range(n_out)]
@@ -72,6 +74,7 @@ def main(out_path):
         res[tag + "_F_sharded"] = float(vs.max())
         res[tag + "_cost_ratio"] = float(m_sh @ prob["costs"] / prob["budget"])
         res[tag + "_it"] = int(info["it"])
+        res[tag + "_support"] = int((m_sh > 0).sum())
     if rank == 0:
         json.dump(res, open(out_path, "w"))
     dist.destroy_process_group()

@@ -31,7 +31,7 @@ def test_sharded_hip_plans_two_ranks(tmp_path):
     assert res["peer_exchange_err"] < 1e-13 and res["peer_exchange_identical_on_all_ranks"] and not res["peer_exchange_timed_out"]
     assert res["n12_k4_o1_exchange"].startswith("peer-write")
     from bluest_amd.mosap import MOSAP
-    for tag, (n, kmax, n_out) in (("n12_k4_o1", (12, 4, 1)), ("n10_k3_o3", (10, 3, 3))):
+    for tag, (n, kmax, n_out) in (("n12_k4_o1", (12, 4, 1)), ("n10_k3_o3", (10, 3, 3)), ("n16_k5_o2", (16, 5, 2))):
         assert res[tag + "_eval_err"] < 1e-12 and res[tag + "_grad_err"] < 1e-12 and res[tag + "_status_equal"]
         assert res[tag + "_ranks_agree"] and abs(res[tag + "_cost_ratio"] - 1) < 1e-9
         lo, hi = res[tag + "_shard"]
@@ -46,3 +46,6 @@ def test_sharded_hip_plans_two_ranks(tmp_path):
         F1 = max(mos.variances(m1))
         assert res[tag + "_F_sharded"] <= F1 * (1 + 1e-3), (tag, res[tag + "_F_sharded"], F1, res[tag + "_it"])
         assert res[tag + "_F_sharded_host_loop"] <= F1 * (1 + 5e-3), (tag, res[tag + "_F_sharded_host_loop"], F1)
+        if tag == "n16_k5_o2":
+            # the working set ran over the shards: the answer sits on a handful of groups and matches the single-GPU one closely
+            assert res[tag + "_support"] <= 8 * n and res[tag + "_F_sharded"] <= F1 * (1 + 2e-4), (res[tag + "_support"], res[tag + "_F_sharded"], F1)

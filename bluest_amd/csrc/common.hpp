@@ -31,6 +31,7 @@ int require_gpu();
 
 // per-group pseudo-inverse launcher (mirrors.hip), also used by the plan's set-up
 int launch_group_pinv(const double *dC, int N, int k, int64_t Lk, const int64_t *dg, double *dout, hipStream_t st);
+int launch_group_pinv_u8(const double *dC, int N, int k, int64_t Lk, const uint8_t *dg, double *dout, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------------
 // device helpers

@@ -221,19 +221,19 @@ __device__ __forceinline__ void sym_pinv_jacobi(double (&A)[K * K], double (&V)[
         }
 }
 
-template <int K>
-__global__ __launch_bounds__(64) void k_group_pinv(const double *__restrict__ C, int N, int64_t Lk, const int64_t *__restrict__ g,
+template <int K, typename G>   // G: element type of the group list (int64_t: the reference layout; uint8_t: the plan's device copy)
+__global__ __launch_bounds__(64) void k_group_pinv(const double *__restrict__ C, int N, int64_t Lk, const G *__restrict__ g,
                              double *__restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Lk) return;
     double A[K * K], V[K * K];
-    const int64_t *gi = g + i * K;
+    const G *gi = g + i * K;
 #pragma unroll
     for (int j = 0; j < K; j++)
 #pragma unroll
         for (int l = 0; l < K; l++) {
-            const int64_t a = gi[j], b = gi[l];
+            const int64_t a = (int64_t)gi[j], b = (int64_t)gi[l];
             A[j * K + l] = 0.5 * (C[a * N + b] + C[b * N + a]);
         }
     sym_pinv_jacobi<K>(A, V, out + i * (int64_t)K * K);
@@ -363,10 +363,11 @@ extern "C" int bluest_hessKQ(double *hess, int N, int k, int q, int64_t Lk, int6
     return s_h.finish(true);
 }
 
-int launch_group_pinv(const double *dC, int N, int k, int64_t Lk, const int64_t *dg, double *dout, hipStream_t st)
+template <typename G>
+static int launch_group_pinv_t(const double *dC, int N, int k, int64_t Lk, const G *dg, double *dout, hipStream_t st)
 {
     const dim3 grid((unsigned)((Lk + 63) / 64)), block(64);
-#define GP(KK) case KK: hipLaunchKernelGGL((k_group_pinv<KK>), grid, block, 0, st, dC, N, Lk, dg, dout); break;
+#define GP(KK) case KK: hipLaunchKernelGGL((k_group_pinv<KK, G>), grid, block, 0, st, dC, N, Lk, dg, dout); break;
     switch (k) {
         GP(1) GP(2) GP(3) GP(4) GP(5) GP(6) GP(7) GP(8) GP(9) GP(10) GP(11) GP(12) GP(13) GP(14) GP(15) GP(16)
         default: return fail(BLUEST_ERR_ARG, "group size k=%d > %d", k, BLUEST_MAX_GROUP);
@@ -374,6 +375,14 @@ int launch_group_pinv(const double *dC, int N, int k, int64_t Lk, const int64_t 
 #undef GP
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
+}
+int launch_group_pinv(const double *dC, int N, int k, int64_t Lk, const int64_t *dg, double *dout, hipStream_t st)
+{
+    return launch_group_pinv_t<int64_t>(dC, N, k, Lk, dg, dout, st);
+}
+int launch_group_pinv_u8(const double *dC, int N, int k, int64_t Lk, const uint8_t *dg, double *dout, hipStream_t st)
+{
+    return launch_group_pinv_t<uint8_t>(dC, N, k, Lk, dg, dout, st);
 }
 
 extern "C" int bluest_group_pinv(const double *C, int N, int k, int64_t Lk, const int64_t *g, double *out)

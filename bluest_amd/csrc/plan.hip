@@ -613,9 +613,11 @@ static int output_to_device(bluest_plan_t plan, OutputDesc &od)
         od.d_groups = plan->outs[0].d_groups;
         od.owns_groups = false;
     } else {
-        HIP_TRY(pool_alloc((void **)&od.d_groups, (size_t)std::max<int64_t>(ng, 1) * sizeof(int64_t)));
+        HIP_TRY(pool_alloc((void **)&od.d_groups, (size_t)std::max<int64_t>(ng, 1)));
         od.owns_groups = true;
-        HIP_TRY(hipMemcpy(od.d_groups, od.groups.data(), (size_t)ng * sizeof(int64_t), hipMemcpyHostToDevice));
+        std::vector<uint8_t> narrow((size_t)ng);
+        for (int64_t t = 0; t < ng; t++) narrow[(size_t)t] = (uint8_t)od.groups[(size_t)t];   // validated: 0 <= index < N <= 64
+        HIP_TRY(hipMemcpy(od.d_groups, narrow.data(), (size_t)ng, hipMemcpyHostToDevice));
     }
     return BLUEST_OK;
 }
@@ -673,7 +675,7 @@ extern "C" int bluest_plan_add_output_cov(bluest_plan_t plan, const double *C, i
         int64_t go = 0, io = 0;
         for (int k = 1; k <= K && rc == BLUEST_OK; k++) {
             const int64_t Lk = sizes[k - 1];
-            if (Lk > 0) rc = launch_group_pinv(dC, N, k, Lk, od.d_groups + go, od.d_invcov + io, 0);
+            if (Lk > 0) rc = launch_group_pinv_u8(dC, N, k, Lk, od.d_groups + go, od.d_invcov + io, 0);
             go += Lk * k; io += Lk * k * k;
         }
         // the next output's covariance upload overwrites dC: wait for the kernels (they take ~0.1 ms; the inverses stay on the device)
@@ -765,7 +767,7 @@ __global__ __launch_bounds__(256) void k_fill_csr(const double *__restrict__ ic,
     vals[perm[t]] = (j == l) ? b[j * k + j] : 0.5 * (b[j * k + l] + b[l * k + j]);
 }
 
-__global__ __launch_bounds__(256) void k_fill_tiles(const double *__restrict__ ic, const int64_t *__restrict__ groups, int k, int64_t Lk,
+__global__ __launch_bounds__(256) void k_fill_tiles(const double *__restrict__ ic, const uint8_t *__restrict__ groups, int k, int64_t Lk,
                                                     double *__restrict__ tvals, uint8_t *__restrict__ tidx)
 {
     const int ne = k * (k + 1) / 2;
@@ -783,7 +785,7 @@ __global__ __launch_bounds__(256) void k_fill_tiles(const double *__restrict__ i
         tvals[tile * ne * 64 + (int64_t)r * 64 + lane] = (j == l) ? b[j * k + j] : 0.5 * (b[j * k + l] + b[l * k + j]);
     } else {
         const int j = r - ne;
-        tidx[tile * k * 64 + (int64_t)j * 64 + lane] = (uint8_t)groups[gi * k + j];
+        tidx[tile * k * 64 + (int64_t)j * 64 + lane] = groups[gi * k + j];
     }
 }
 

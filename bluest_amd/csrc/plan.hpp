@@ -19,7 +19,8 @@ struct OutputDesc {
     int64_t L_o = 0;
     int64_t n_inv = 0;             // doubles of the reference-layout inverses: sum L_k k^2
     double *d_invcov = nullptr;    // DEVICE, reference layout concat (L_k * k * k): pinv output or uploaded; lives as long as the plan
-    int64_t *d_groups = nullptr;   // DEVICE copy of `groups` (shared with output 0 when the lists are identical)
+    uint8_t *d_groups = nullptr;   // DEVICE copy of `groups`, one byte per model index (n <= 64): 8x less to push over PCIe
+                                   // than the int64 list (11 MB at K_tot = 245 505); shared with output 0 when the lists are identical
     bool owns_groups = false;
 };
 

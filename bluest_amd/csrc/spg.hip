@@ -1136,8 +1136,7 @@ extern "C" int bluest_spg_window(bluest_plan_t plan, double *x_dev, double *g_de
     const int64_t L = plan->L;
     // small plans: the gradient tiles of the accepted point run inside the single-workgroup finishing kernel; large plans: every
     // evaluation is the fused solve + gradient launch (decision in its tail), so the update follows the line search directly
-    static int no_small = getenv("BLUEST_SPG_NO_SMALL") ? 1 : 0;   // timing experiments
-    const bool small = plan->L <= 4096 && plan->n_tiles <= 1024 && !no_small;
+    const bool small = plan->L <= 4096 && plan->n_tiles <= 1024;
     for (int it = 0; it < n_iterations; it++) {
         if ((rc = bluest_spg_direction(x_dev, g_dev, state_dev, 1.0, floor, L, d_dev, scale_dev, xnew_dev, m_dev, enable_dev, proj_work_dev, stream))) return rc;
         for (int t = 0; t < slots; t++) {

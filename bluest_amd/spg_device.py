@@ -154,6 +154,7 @@ class DeviceSpg(object):
         """use_graph: None = the default (direct launches of a whole window by one library call; BLUEST_SPG_GRAPH=1 in the
         environment selects hipGraph replay), True = captured hipGraphs, False = direct launches"""
         plan, lib, st = self.plan, self.lib, self.st
+        del self.window_seconds[:]                                  # diagnostics of THIS run only
         if use_graph is None:
             import os
             use_graph = bool(os.environ.get("BLUEST_SPG_GRAPH"))

@@ -226,6 +226,18 @@ class ShardedPlan(object):
         from .plan import Plan
         from .sap import BLUESTError
         keep = np.asarray(keep, dtype=np.int64)
+        if self.world > 1:
+            # every rank must ask for the same set (it does, by construction): checked collectively so that a disagreement is an
+            # error on ALL ranks rather than a hang in the gather below
+            import zlib
+            h = float(zlib.crc32(keep.tobytes()))
+            t = torch.tensor([h, -h, float(len(keep)), -float(len(keep))], dtype=torch.float64)
+            if self.device is not None and dist.get_backend(self.group) == "nccl":
+                t = t.to(self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            t = t.cpu().numpy()
+            if t[0] != -t[1] or t[2] != -t[3]:
+                raise BLUESTError("sharded working set: the ranks ask for different group sets")
         mine = []
         for o, out in enumerate(self.local_outputs):
             mp = np.asarray(out["mapping"], dtype=np.int64)

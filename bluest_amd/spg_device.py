@@ -137,6 +137,10 @@ class DeviceSpg(object):
         except Exception:
             pass
 
+    def _check_replicas(self, hs):
+        """hook of the collective variant: all ranks must have seen the same state (no-op on one GPU)"""
+        return None
+
     # ---- host-side objective (initialisation only) ---------------------------------------------------------------
     def _objective(self, var):
         r = var / self.s_norm
@@ -233,6 +237,7 @@ class DeviceSpg(object):
                         run_iter_checked()                      # last one also measures gpmax (sets DONE when <= eps)
                     hs = st.cpu().numpy()
                     self.window_seconds.append(time.perf_counter() - t_window)      # host-visible time of the window (diagnostics)
+                    self._check_replicas(hs)
                     if hs[FAIL] != 0.0:                          # step length underflow or evaluation budget spent (decided on the GPU)
                         info = 2
                         break
@@ -306,6 +311,26 @@ class ShardedDeviceSpg(DeviceSpg):
                                         self.floor, self.L, self.work.data_ptr(), _stream()))
         if check_last:
             self._converged()
+
+    def _check_replicas(self, hs):
+        """every rank takes its host decisions from its own copy of the state; the copies are identical by construction
+        (deterministic kernels, bit-identical all-reduces).  Should they ever differ, the ranks would leave the loop at different
+        windows and the next collective would hang -- so each window ends with ONE tiny all-reduce that makes every rank see
+        the disagreement and raise together instead"""
+        import torch.distributed as dist
+        sh = self.plan
+        if sh.world <= 1:
+            return
+        v = np.array([hs[IT], hs[COUNT], hs[DONE], hs[FAIL], hs[PENDING], hs[F]], dtype=np.float64)
+        v = np.where(np.isfinite(v), v, -1.0)
+        t = torch.from_numpy(np.concatenate([v, -v]))
+        on_dev = dist.get_backend(sh.group) == "nccl"
+        if on_dev:
+            t = t.to(self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=sh.group)
+        t = t.cpu().numpy()
+        if not np.array_equal(t[:len(v)], -t[len(v):]):
+            raise RuntimeError("sharded SPG: the replicated solver states of the ranks differ (max %s, min %s)" % (t[:len(v)], -t[len(v):]))
 
     def run(self, x0, **kwargs):
         kwargs["use_graph"] = False                               # collectives are enqueued directly

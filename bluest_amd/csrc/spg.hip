@@ -57,6 +57,8 @@ struct ProjLds {
     double d0[2][16];
     double d1[2][16];
     long long c[2][16];
+    double d2[2][16];
+    double d3[2][16];
 };
 
 __device__ __forceinline__ double block_max(double x, ProjLds &s, int tid, int &ph)
@@ -103,6 +105,35 @@ __device__ __forceinline__ void block_sum2_cnt(double &x, double &y, long long &
     x = __shfl(r, 0, WAVE);
     y = __shfl(q, 0, WAVE);
     n = __shfl(c, 0, WAVE);
+}
+
+// sums of x, y, n together with max of lo and min of hi: ONE barrier for the five values of a Newton pass of the projection
+__device__ __forceinline__ void block_pass5(double &x, double &y, long long &n, double &lo, double &hi, ProjLds &s, int tid, int &ph)
+{
+    x = wave_sum(x);
+    y = wave_sum(y);
+    n = wave_sum_ll(n);
+    lo = wave_max(lo);
+    hi = -wave_max(-hi);
+    const int lane = tid & 63, nw = blockDim.x >> 6;
+    if (lane == 0) { s.d0[ph][tid >> 6] = x; s.d1[ph][tid >> 6] = y; s.c[ph][tid >> 6] = n; s.d2[ph][tid >> 6] = lo; s.d3[ph][tid >> 6] = hi; }
+    __syncthreads();
+    double r = (lane < nw) ? s.d0[ph][lane] : 0.0;
+    double q = (lane < nw) ? s.d1[ph][lane] : 0.0;
+    long long c = (lane < nw) ? s.c[ph][lane] : 0;
+    double l = (lane < nw) ? s.d2[ph][lane] : -INFINITY;
+    double h = (lane < nw) ? s.d3[ph][lane] : INFINITY;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        r += __shfl_xor(r, off, WAVE); q += __shfl_xor(q, off, WAVE); c += __shfl_xor(c, off, WAVE);
+        l = fmax(l, __shfl_xor(l, off, WAVE)); h = fmin(h, __shfl_xor(h, off, WAVE));
+    }
+    ph ^= 1;
+    x = __shfl(r, 0, WAVE);
+    y = __shfl(q, 0, WAVE);
+    n = __shfl(c, 0, WAVE);
+    lo = __shfl(l, 0, WAVE);
+    hi = __shfl(h, 0, WAVE);
 }
 
 // accept the step (bluest/spg.py:85-106), two launches:
@@ -427,9 +458,11 @@ struct FusedProj {
     static constexpr int MAXB = 256;      // workgroups (<= compute units: all of them are resident at once)
     static constexpr int MAXP = 60;       // Newton passes per search
     static constexpr int EPOCH_STEP = 64; // tags used per launch (passes + final statistics)
-    // a mailbox = 8 x 64-bit words = four doubles, each split into two (tag << 32 | 32 payload bits) words
-    // doubles: [0, 2*MAXB*8) double-buffered pass mailboxes   [.., +MAXB*8) final-statistics mailboxes
-    static constexpr int PART = 0, FIN = 2 * MAXB * 8, DOUBLES = FIN + MAXB * 8;
+    // a mailbox holds doubles split into two (tag << 32 | 32 payload bits) 64-bit words each: six doubles = 12 words (stride
+    // PASS_WORDS) for a Newton pass, four doubles = 8 words for the final statistics
+    // words: [0, 2*MAXB*PASS_WORDS) double-buffered pass mailboxes   [.., +MAXB*8) final-statistics mailboxes
+    static constexpr int PASS_WORDS = 16;
+    static constexpr int PART = 0, FIN = 2 * MAXB * PASS_WORDS, DOUBLES = FIN + MAXB * 8;
 };
 struct ProjWs {            // layout of the caller-provided workspace (doubles)
     // [0, 2L): interleaved (r_i, s_i) pairs
@@ -754,6 +787,43 @@ __device__ __forceinline__ bool mailbox_recv(const double *box, unsigned int tag
     return __syncthreads_and(ok) != 0;
 }
 
+// the six doubles of a Newton pass (lanes 0..11 of one wavefront store, every polling thread reads its own mailbox)
+__device__ __forceinline__ void mailbox_send6(double *box, unsigned int tag, double v0, double v1, double v2, double v3, double v4, double v5)
+{
+    const int l = threadIdx.x & 15;
+    const double v = (l < 2) ? v0 : (l < 4) ? v1 : (l < 6) ? v2 : (l < 8) ? v3 : (l < 10) ? v4 : v5;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const unsigned long long half = (l & 1) ? (bits >> 32) : (bits & 0xffffffffull);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(box) + l, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool mailbox_recv6(const double *box, unsigned int tag, bool active, double (&v)[6])
+{
+    int ok = 1;
+#pragma unroll
+    for (int i = 0; i < 6; i++) v[i] = 0.0;
+    if (active) {
+        const unsigned long long *w = reinterpret_cast<const unsigned long long *>(box);
+        unsigned int spins = 0;
+        for (;;) {
+            unsigned long long q[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) q[i] = __hip_atomic_load(w + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool all = true;
+#pragma unroll
+            for (int i = 0; i < 12; i++) all = all && (unsigned int)(q[i] >> 32) == tag;
+            if (all) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) v[i] = __longlong_as_double((long long)((q[2 * i] & 0xffffffffull) | (q[2 * i + 1] << 32)));
+                break;
+            }
+            if (++spins > PROJ_SPIN_LIMIT) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return __syncthreads_and(ok) != 0;
+}
+
 template <int ITEMS>
 __global__ __launch_bounds__(1024) void k_proj_fused(const double *__restrict__ x, const double *__restrict__ g, double lambda,
                                                      double z, double floor, int64_t L, double *__restrict__ ws, int nb_ws,
@@ -819,6 +889,7 @@ __global__ __launch_bounds__(1024) void k_proj_fused(const double *__restrict__ 
     for (int iter = 0; iter < maxp; iter++) {
         double s1 = 0.0, s0 = 0.0;
         long long cnt = 0;
+        double lo = -INFINITY, hi = INFINITY;                // largest inactive / smallest active ratio (coordinates of tau)
         passes++;
         const double ref = first ? mb : 0.0;                 // later passes: r[] is already shifted
 #pragma unroll
@@ -827,20 +898,26 @@ __global__ __launch_bounds__(1024) void k_proj_fused(const double *__restrict__ 
             s1 = act ? fma(sc[k], r[k] - ref, s1) : s1;
             s0 = act ? s0 + sc[k] : s0;
             cnt += act ? 1 : 0;
+            hi = act ? fmin(hi, r[k]) : hi;
+            lo = act ? lo : fmax(lo, r[k]);
         }
-        block_sum2_cnt(s1, s0, cnt, sm, tid, ph);
+        block_pass5(s1, s0, cnt, lo, hi, sm, tid, ph);
         const unsigned int tag = epoch + 1u + (unsigned int)iter;
-        if (tid < 8) mailbox_send(sy + FusedProj::PART + ((iter & 1) * FusedProj::MAXB + b) * 8, tag, s1, s0, (double)cnt, mb);
-        double msg[4];
-        ok = mailbox_recv(sy + FusedProj::PART + ((iter & 1) * FusedProj::MAXB + (tid < nb ? tid : 0)) * 8, tag, tid < nb, msg);
+        if (tid < 12)
+            mailbox_send6(sy + FusedProj::PART + ((iter & 1) * FusedProj::MAXB + b) * FusedProj::PASS_WORDS, tag, s1, s0, (double)cnt, mb, lo, hi);
+        double msg[6];
+        ok = mailbox_recv6(sy + FusedProj::PART + ((iter & 1) * FusedProj::MAXB + (tid < nb ? tid : 0)) * FusedProj::PASS_WORDS, tag, tid < nb, msg);
         if (!ok) break;
         s1 = msg[0]; s0 = msg[1]; cnt = (long long)msg[2];
+        lo = (tid < nb) ? msg[4] : -INFINITY;
+        hi = (tid < nb) ? msg[5] : INFINITY;
         if (first) {
             const double m = (tid < nb) ? msg[3] : -INFINITY;
             rmax = block_max(m, sm, tid, ph);
             if (cnt > 0) s1 = fma(s0, m - rmax, s1);         // re-base this workgroup's partial to the grid-wide max
+            lo -= rmax; hi -= rmax;                          // pass 0 compared in absolute coordinates
         }
-        block_sum2_cnt(s1, s0, cnt, sm, tid, ph);
+        block_pass5(s1, s0, cnt, lo, hi, sm, tid, ph);
         if (first) {
 #pragma unroll
             for (int k = 0; k < ITEMS; k++) r[k] -= rmax;
@@ -857,6 +934,9 @@ __global__ __launch_bounds__(1024) void k_proj_fused(const double *__restrict__ 
         }
         prev = cnt;
         tau = (s1 - z) / s0;
+        // the new threshold separates the same entries as the one these sums were taken at (no ratio in between): it IS the
+        // fixed point -- the confirming pass (one more device-wide exchange, ~4 us) would reproduce it bit for bit
+        if (lo <= tau && tau < hi) break;
     }
     if (!ok) tau = NAN;
 

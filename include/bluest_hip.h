@@ -206,12 +206,17 @@ int bluest_simplex_project(const double *x_dev, const double *g_dev, double lamb
 /* Device-resident SPG iteration (bluest/spg.py:68-106 with the control flow on the GPU).  The solver state is an
  * array of BLUEST_SPG_STATE_DOUBLES doubles in HBM (layout: csrc/spg.hip SPG_*, bluest_amd/spg_device.py);
  * every kernel below reads its scalars (lambda, alpha, f, history ...) from it and is a no-op once state[DONE] or
- * state[FAIL] is set, so a whole iteration -- direction, T predicated line-search slots, gradient, Barzilai-Borwein
- * update -- is a fixed launch sequence that can be captured in one hipGraph and replayed without host round trips.
+ * state[FAIL] is set, so the loop is a fixed launch sequence of identical STEPS -- direction, T predicated line-search slots,
+ * (gradient,) Barzilai-Borwein update -- that needs no host round trip (plain stream launches, or captured in a hipGraph).
+ * A trial rejected in the last slot of a step sets state[PENDING]: the next direction launch then forms the next trial point
+ * x + alpha*d instead of a new direction and the update stays gated off, i.e. the line search of spg.py:9-35 simply continues
+ * in the next step; a step length below 1e-300 or state[MAXFEV] evaluations set state[FAIL].
  *   bluest_plan_set_gate   : the plan's kernels (Phi chunks, solve, gradient, combine) skip when *enable_dev == 0;
  *                            always_v != 0 makes every solve also produce v (kept in the plan workspace)
- *   bluest_spg_direction   : d = P_s(x - lambda*s*g) - x with lambda = state[LAMBDA]; g.d, max|d|, tau, npos -> state;
- *                            optionally also the first trial point (alpha = 1): xnew = x + d, m = scale*xnew, *enable = 1
+ *   bluest_spg_direction   : d = P_s(x - lambda*s*g) - x with lambda = state[LAMBDA]; g.d -> state (the multi-workgroup kernel
+ *                            leaves per-workgroup partials that bluest_spg_decide folds); optionally also the first trial
+ *                            point (alpha = 1): xnew = x + d, m = scale*xnew, *enable = 1.  While state[PENDING]: no new
+ *                            direction, xnew = x + alpha*d, m = scale*xnew instead
  *   bluest_spg_trial       : xnew = x + alpha*d, m = scale*xnew, *enable = 1 -- unless the iteration already accepted
  *   bluest_spg_decide      : F(trial) from the per-output variances (p-norm / max), nonmonotone Armijo test
  *                            (spg.py:17,32), safeguarded quadratic interpolation of alpha (spg.py:18-26)
@@ -254,9 +259,9 @@ int bluest_spg_finish(bluest_plan_t plan, const double *v_dev, const int32_t *st
                       const double *xnew_dev, double *grad_dev, const double *scale_dev, double *state_dev, double floor,
                       double *work_dev, void *stream);
 
-/* n_iterations whole SPG iterations (bluest_spg_direction, `slots` x [bluest_spg_trial,] bluest_plan_eval_decide,
- * bluest_spg_finish), then bluest_spg_converged if check_last: one host call enqueues the launch sequence of a whole window on
- * `stream`.  Arguments as in the calls it is made of; v_ws_dev from bluest_plan_v_workspace; proj_work_dev as work_dev of
+/* n_iterations steps of the loop (bluest_spg_direction, `slots` x [bluest_spg_trial,] bluest_plan_eval_grad_decide,
+ * bluest_spg_update_fused; on plans with K_tot <= 4096: bluest_plan_eval_decide and bluest_spg_finish), then
+ * bluest_spg_converged if check_last: one host call enqueues the launch sequence of a whole window on `stream`.  Arguments as in the calls it is made of; v_ws_dev from bluest_plan_v_workspace; proj_work_dev as work_dev of
  * bluest_simplex_project (may be NULL for L <= 4096). */
 int bluest_spg_window(bluest_plan_t plan, double *x_dev, double *g_dev, double *d_dev, double *xnew_dev, double *m_dev,
                       const double *scale_dev, double *state_dev, double *var_dev, int32_t *status_dev, double *grad_dev,

@@ -107,31 +107,28 @@ __device__ __forceinline__ void block_sum2_cnt(double &x, double &y, long long &
     n = __shfl(c, 0, WAVE);
 }
 
-// sums of x, y, n together with max of lo and min of hi: ONE barrier for the five values of a Newton pass of the projection
-__device__ __forceinline__ void block_pass5(double &x, double &y, long long &n, double &lo, double &hi, ProjLds &s, int tid, int &ph)
+// sums of x and y together with max of lo and min of hi: ONE barrier for the four values of a Newton pass of the projection
+__device__ __forceinline__ void block_pass4(double &x, double &y, double &lo, double &hi, ProjLds &s, int tid, int &ph)
 {
     x = wave_sum(x);
     y = wave_sum(y);
-    n = wave_sum_ll(n);
     lo = wave_max(lo);
     hi = -wave_max(-hi);
     const int lane = tid & 63, nw = blockDim.x >> 6;
-    if (lane == 0) { s.d0[ph][tid >> 6] = x; s.d1[ph][tid >> 6] = y; s.c[ph][tid >> 6] = n; s.d2[ph][tid >> 6] = lo; s.d3[ph][tid >> 6] = hi; }
+    if (lane == 0) { s.d0[ph][tid >> 6] = x; s.d1[ph][tid >> 6] = y; s.d2[ph][tid >> 6] = lo; s.d3[ph][tid >> 6] = hi; }
     __syncthreads();
     double r = (lane < nw) ? s.d0[ph][lane] : 0.0;
     double q = (lane < nw) ? s.d1[ph][lane] : 0.0;
-    long long c = (lane < nw) ? s.c[ph][lane] : 0;
     double l = (lane < nw) ? s.d2[ph][lane] : -INFINITY;
     double h = (lane < nw) ? s.d3[ph][lane] : INFINITY;
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) {
-        r += __shfl_xor(r, off, WAVE); q += __shfl_xor(q, off, WAVE); c += __shfl_xor(c, off, WAVE);
+        r += __shfl_xor(r, off, WAVE); q += __shfl_xor(q, off, WAVE);
         l = fmax(l, __shfl_xor(l, off, WAVE)); h = fmin(h, __shfl_xor(h, off, WAVE));
     }
     ph ^= 1;
     x = __shfl(r, 0, WAVE);
     y = __shfl(q, 0, WAVE);
-    n = __shfl(c, 0, WAVE);
     lo = __shfl(l, 0, WAVE);
     hi = __shfl(h, 0, WAVE);
 }
@@ -458,11 +455,10 @@ struct FusedProj {
     static constexpr int MAXB = 256;      // workgroups (<= compute units: all of them are resident at once)
     static constexpr int MAXP = 60;       // Newton passes per search
     static constexpr int EPOCH_STEP = 64; // tags used per launch (passes + final statistics)
-    // a mailbox holds doubles split into two (tag << 32 | 32 payload bits) 64-bit words each: six doubles = 12 words (stride
-    // PASS_WORDS) for a Newton pass, four doubles = 8 words for the final statistics
-    // words: [0, 2*MAXB*PASS_WORDS) double-buffered pass mailboxes   [.., +MAXB*8) final-statistics mailboxes
-    static constexpr int PASS_WORDS = 16;
-    static constexpr int PART = 0, FIN = 2 * MAXB * PASS_WORDS, DOUBLES = FIN + MAXB * 8;
+    // a mailbox = 8 x 64-bit words = four doubles, each split into two (tag << 32 | 32 payload bits) words: ONE 64-byte store
+    // (a 12-word message for the pass data was tried: every pass cost ~10 us instead of ~5, two lines to become visible)
+    // doubles: [0, 2*MAXB*8) double-buffered pass mailboxes   [.., +MAXB*8) final-statistics mailboxes
+    static constexpr int PART = 0, FIN = 2 * MAXB * 8, DOUBLES = FIN + MAXB * 8;
 };
 struct ProjWs {            // layout of the caller-provided workspace (doubles)
     // [0, 2L): interleaved (r_i, s_i) pairs
@@ -787,50 +783,13 @@ __device__ __forceinline__ bool mailbox_recv(const double *box, unsigned int tag
     return __syncthreads_and(ok) != 0;
 }
 
-// the six doubles of a Newton pass (lanes 0..11 of one wavefront store, every polling thread reads its own mailbox)
-__device__ __forceinline__ void mailbox_send6(double *box, unsigned int tag, double v0, double v1, double v2, double v3, double v4, double v5)
-{
-    const int l = threadIdx.x & 15;
-    const double v = (l < 2) ? v0 : (l < 4) ? v1 : (l < 6) ? v2 : (l < 8) ? v3 : (l < 10) ? v4 : v5;
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-    const unsigned long long half = (l & 1) ? (bits >> 32) : (bits & 0xffffffffull);
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(box) + l, ((unsigned long long)tag << 32) | half, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ bool mailbox_recv6(const double *box, unsigned int tag, bool active, double (&v)[6])
-{
-    int ok = 1;
-#pragma unroll
-    for (int i = 0; i < 6; i++) v[i] = 0.0;
-    if (active) {
-        const unsigned long long *w = reinterpret_cast<const unsigned long long *>(box);
-        unsigned int spins = 0;
-        for (;;) {
-            unsigned long long q[12];
-#pragma unroll
-            for (int i = 0; i < 12; i++) q[i] = __hip_atomic_load(w + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bool all = true;
-#pragma unroll
-            for (int i = 0; i < 12; i++) all = all && (unsigned int)(q[i] >> 32) == tag;
-            if (all) {
-#pragma unroll
-                for (int i = 0; i < 6; i++) v[i] = __longlong_as_double((long long)((q[2 * i] & 0xffffffffull) | (q[2 * i + 1] << 32)));
-                break;
-            }
-            if (++spins > PROJ_SPIN_LIMIT) { ok = 0; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    return __syncthreads_and(ok) != 0;
-}
-
 template <int ITEMS>
 __global__ __launch_bounds__(1024) void k_proj_fused(const double *__restrict__ x, const double *__restrict__ g, double lambda,
                                                      double z, double floor, int64_t L, double *__restrict__ ws, int nb_ws,
                                                      double *__restrict__ p, double *__restrict__ d,
                                                      double *__restrict__ stats, double *__restrict__ spg_state, int spg_mode,
                                                      const double *__restrict__ scale, double *__restrict__ xnew,
-                                                     double *__restrict__ mtrial, int32_t *__restrict__ enable, int maxp)
+                                                     double *__restrict__ mtrial, int32_t *__restrict__ enable, int maxp, int bracket)
 {
     __shared__ ProjLds sm;
     int ph = 0;
@@ -883,12 +842,16 @@ __global__ __launch_bounds__(1024) void k_proj_fused(const double *__restrict__ 
     const double mb = block_max(rmax, sm, tid, ph);          // this workgroup's max r
     bool ok = true, first = true;
     double tau = isfinite(hint) ? hint : -INFINITY;          // pass 0: absolute; later passes: relative to rmax
-    long long prev = -1;
     int passes = 0;
     rmax = mb;
+    // Every message is (s1_b, s0_b, m_b, bracket_b) in ONE 64-byte mailbox: bracket_b = the largest ratio NOT in the active set and
+    // the smallest one in it, as two floats rounded outwards from the threshold (conservative).  After the exchange every
+    // workgroup knows the new threshold AND whether it separates the same entries as the one the sums were taken at -- then it IS
+    // the fixed point, and the confirming pass (one more device-wide exchange, ~5 us) is skipped; otherwise the search goes on
+    // and ends when a pass reproduces the threshold bit for bit.  (No counts in the message: the weights are positive, so an
+    // empty active set is s0 == 0.)
     for (int iter = 0; iter < maxp; iter++) {
         double s1 = 0.0, s0 = 0.0;
-        long long cnt = 0;
         double lo = -INFINITY, hi = INFINITY;                // largest inactive / smallest active ratio (coordinates of tau)
         passes++;
         const double ref = first ? mb : 0.0;                 // later passes: r[] is already shifted
@@ -897,46 +860,43 @@ __global__ __launch_bounds__(1024) void k_proj_fused(const double *__restrict__ 
             const bool act = r[k] > tau;
             s1 = act ? fma(sc[k], r[k] - ref, s1) : s1;
             s0 = act ? s0 + sc[k] : s0;
-            cnt += act ? 1 : 0;
             hi = act ? fmin(hi, r[k]) : hi;
             lo = act ? lo : fmax(lo, r[k]);
         }
-        block_pass5(s1, s0, cnt, lo, hi, sm, tid, ph);
+        block_pass4(s1, s0, lo, hi, sm, tid, ph);
         const unsigned int tag = epoch + 1u + (unsigned int)iter;
-        if (tid < 12)
-            mailbox_send6(sy + FusedProj::PART + ((iter & 1) * FusedProj::MAXB + b) * FusedProj::PASS_WORDS, tag, s1, s0, (double)cnt, mb, lo, hi);
-        double msg[6];
-        ok = mailbox_recv6(sy + FusedProj::PART + ((iter & 1) * FusedProj::MAXB + (tid < nb ? tid : 0)) * FusedProj::PASS_WORDS, tag, tid < nb, msg);
+        const double bracket_bits = __hiloint2double(__float_as_int(__double2float_rd(hi)), __float_as_int(__double2float_ru(lo)));
+        if (tid < 8) mailbox_send(sy + FusedProj::PART + ((iter & 1) * FusedProj::MAXB + b) * 8, tag, s1, s0, mb, bracket_bits);
+        double msg[4];
+        ok = mailbox_recv(sy + FusedProj::PART + ((iter & 1) * FusedProj::MAXB + (tid < nb ? tid : 0)) * 8, tag, tid < nb, msg);
         if (!ok) break;
-        s1 = msg[0]; s0 = msg[1]; cnt = (long long)msg[2];
-        lo = (tid < nb) ? msg[4] : -INFINITY;
-        hi = (tid < nb) ? msg[5] : INFINITY;
+        s1 = msg[0]; s0 = msg[1];
+        lo = (tid < nb) ? (double)__int_as_float(__double2loint(msg[3])) : -INFINITY;
+        hi = (tid < nb) ? (double)__int_as_float(__double2hiint(msg[3])) : INFINITY;
+        const bool was_first = first;
         if (first) {
-            const double m = (tid < nb) ? msg[3] : -INFINITY;
+            const double m = (tid < nb) ? msg[2] : -INFINITY;
             rmax = block_max(m, sm, tid, ph);
-            if (cnt > 0) s1 = fma(s0, m - rmax, s1);         // re-base this workgroup's partial to the grid-wide max
+            if (s0 > 0.0) s1 = fma(s0, m - rmax, s1);        // re-base this workgroup's partial to the grid-wide max
             lo -= rmax; hi -= rmax;                          // pass 0 compared in absolute coordinates
         }
-        block_pass5(s1, s0, cnt, lo, hi, sm, tid, ph);
+        block_pass4(s1, s0, lo, hi, sm, tid, ph);
         if (first) {
 #pragma unroll
             for (int k = 0; k < ITEMS; k++) r[k] -= rmax;
-            if (cnt == 0) {                                  // hint right of every r_i (or no entries): all-active restart
+            first = false;
+            if (s0 == 0.0) {                                 // hint right of every r_i (or no entries): all-active restart
                 if (tau == -INFINITY) break;
-                tau = -INFINITY;
-                // r[] is shifted now, so the restart is an ordinary later pass
-                first = false;
+                tau = -INFINITY;                             // r[] is shifted now, so the restart is an ordinary later pass
                 continue;
             }
-            first = false;
-        } else if (cnt == prev || cnt == 0) {
+        } else if (s0 == 0.0) {
             break;
         }
-        prev = cnt;
-        tau = (s1 - z) / s0;
-        // the new threshold separates the same entries as the one these sums were taken at (no ratio in between): it IS the
-        // fixed point -- the confirming pass (one more device-wide exchange, ~4 us) would reproduce it bit for bit
-        if (lo <= tau && tau < hi) break;
+        const double tau_new = (s1 - z) / s0;
+        if (!was_first && tau_new == tau) break;             // this pass reproduced the threshold: fixed point
+        tau = tau_new;
+        if (bracket && lo <= tau && tau < hi) break;         // same active set on both sides of the update: fixed point
     }
     if (!ok) tau = NAN;
 
@@ -1031,12 +991,13 @@ static int simplex_impl(const double *x_dev, const double *g_dev, double lambda,
                 ncu = prop.multiProcessorCount;
             }
             static int maxp = getenv("BLUEST_PROJ_MAXP") ? atoi(getenv("BLUEST_PROJ_MAXP")) : (int)FusedProj::MAXP;   // timing experiments
+            static int bracket = getenv("BLUEST_PROJ_NO_BRACKET") ? 0 : 1;   // timing experiments
             static int maxb = getenv("BLUEST_PROJ_MAXB") ? atoi(getenv("BLUEST_PROJ_MAXB")) : 64;   // 64 measured best at L = 245505 (61 -> 42 us)
             const int nbf = std::max(1, std::min(std::min(nb, ncu), std::min(maxb, (int)FusedProj::MAXB)));
             const int64_t items = (L + 1024LL * nbf - 1) / (1024LL * nbf);
             if (items <= 16 && !getenv("BLUEST_PROJ_MULTI_LAUNCH")) {
 #define PF(IT) hipLaunchKernelGGL((k_proj_fused<IT>), dim3(nbf), dim3(1024), 0, st, x_dev, g_dev, lambda, z, floor, L, ws, nb, p_dev, d_dev, \
-                                  stats_dev, spg_state, spg_mode, trial_scale, trial_xnew, trial_m, trial_enable, maxp)
+                                  stats_dev, spg_state, spg_mode, trial_scale, trial_xnew, trial_m, trial_enable, maxp, bracket)
                 if (items <= 1) PF(1); else if (items <= 2) PF(2); else if (items <= 4) PF(4); else if (items <= 8) PF(8); else PF(16);
 #undef PF
                 HIP_TRY(hipGetLastError());

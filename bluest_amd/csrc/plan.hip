@@ -795,6 +795,24 @@ struct Arena {
     char *base = nullptr;
     size_t reserve(size_t n) { const size_t off = bytes; bytes += (std::max<size_t>(n, 1) + 255) / 256 * 256; return off; }
 };
+// a host array that is NOT value-initialised (std::vector zero-fills on one thread and touches every page before the worker
+// threads do: 4-5 ms for the 64 MB of slots and columns at K_tot = 245 505); every element is written by the layout passes
+template <typename T>
+struct RawArray {
+    std::unique_ptr<T[]> p;
+    size_t n;
+    explicit RawArray(size_t n_) : p(new T[std::max<size_t>(n_, 1)]), n(n_) {}
+    T *data() { return p.get(); }
+    const T *data() const { return p.get(); }
+    size_t size() const { return n; }
+};
+template <typename T>
+static int upload(Arena &arena, size_t off, T **dst, const RawArray<T> &src)
+{
+    *dst = reinterpret_cast<T *>(arena.base + off);
+    if (src.size()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return BLUEST_OK;
+}
 template <typename T>
 static int upload(Arena &arena, size_t off, T **dst, const std::vector<T> &src)
 {
@@ -914,8 +932,8 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
         struct_slots[o + 1] = struct_slots[o] + (out_chunk_begin[o + 1] - out_chunk_begin[o]) * CH;
     }
     if (struct_slots[n_struct] > 0x7fffffffLL) return fail(BLUEST_ERR_ARG, "problem too large for one plan (%lld slots per structure set)", (long long)struct_slots[n_struct]);
-    std::vector<int32_t> perm((size_t)struct_entries[n_struct]);
-    std::vector<int32_t> cols((size_t)struct_slots[n_struct], 0);
+    RawArray<int32_t> perm((size_t)struct_entries[n_struct]);
+    RawArray<int32_t> cols((size_t)struct_slots[n_struct]);
     parallel_items(n_struct * S, [&](int item) {
         const int o = item / S;
         std::vector<int64_t> &next = slice_cnt[item];     // start offsets, advanced as the slice writes

@@ -120,9 +120,12 @@ class _SapView(SAP):
         self.L = int(self.cumsizes[-1])
         self._plan_output = n
         self.ES = LazyIndicators(groups, self.N)
-        self.e = self.ES[0]
         self._psi = None
         self._plan = None
+
+    @property
+    def e(self):
+        return self.ES[0]
 
     @property
     def _parent(self):

@@ -79,16 +79,22 @@ class LazyIndicators(object):
     constraint) is needed on the path; the N x L table (49 MB at K_tot = 245505) is built when somebody asks for another row."""
 
     def __init__(self, groups, N, dtype=np.int64):
-        self._groups, self._N, self._dtype, self._all = groups, N, dtype, None
-        L = sum(len(g) for g in groups)
-        e = np.zeros(L, dtype=dtype)
-        off = 0
-        for gk in groups:
-            gk = np.asarray(gk)
-            if len(gk):
-                e[off:off + len(gk)] = (gk == 0).any(axis=1)
-            off += len(gk)
-        self.e = e
+        self._groups, self._N, self._dtype, self._all, self._e = groups, N, dtype, None, None
+
+    @property
+    def e(self):
+        """row 0, built on first use (a MOSAP creates one of these per output and normally reads only its own)"""
+        if self._e is None:
+            L = sum(len(g) for g in self._groups)
+            e = np.zeros(L, dtype=self._dtype)
+            off = 0
+            for gk in self._groups:
+                gk = np.asarray(gk)
+                if len(gk):
+                    e[off:off + len(gk)] = (gk == 0).any(axis=1)
+                off += len(gk)
+            self._e = e
+        return self._e
 
     def _table(self):
         if self._all is None:

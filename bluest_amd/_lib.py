@@ -55,6 +55,7 @@ SIGNATURES = {
     "bluest_plan_set_gate": [c_vp, c_vp, c_int],
     "bluest_plan_eval_decide": [c_vp, c_vp, c_f64, c_vp, c_vp, c_vp, c_int, c_vp, c_vp],
     "bluest_plan_eval_grad_decide": [c_vp, c_vp, c_f64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp],
+    "bluest_plan_solve_grad": [c_vp, c_vp, c_f64, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp],
     "bluest_plan_v_workspace": [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp)],
     "bluest_spg_direction": [c_vp, c_vp, c_vp, c_f64, c_f64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "bluest_spg_converged": [c_vp, c_vp, c_vp, c_f64, c_f64, c_i64, c_vp, c_vp],

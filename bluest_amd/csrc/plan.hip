@@ -291,7 +291,7 @@ __host__ __device__ constexpr int fused_tpb(int NT, int KU) { return (NT <= 26 &
 static int pick_ku(int kmax) { return kmax <= 5 ? 5 : kmax <= 6 ? 6 : kmax <= 8 ? 8 : 12; }
 template <int NT, int KU>
 __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
-                                                    const double2 *__restrict__ partial, double delta,
+                                                    const double2 *__restrict__ partial, const double *__restrict__ rec, double delta,
                                                     const TileDesc *__restrict__ tiles, int64_t n_tiles, int bpo,
                                                     const double *__restrict__ tvals, const uint8_t *__restrict__ tidx,
                                                     double *__restrict__ var, double *__restrict__ v_ws,
@@ -322,7 +322,14 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
     if (spg_state && first && wave == 0) spg_prefetch_state(spg_state, lane, pf);   // in flight during the fold (spg_state.hpp)
     if (N < NT) { clear_pads(lds, N, tid, NTHREADS); __syncthreads(); }   // uniform; every real entry is written by the fold
     PHASE(1);
-    fold_rows<NT>(lds, N, rows, o * nsym, nsym, partial, tid, NTHREADS);
+    // Phi either folded from this GPU's chunk partials, or (group-sharded plans) taken from the all-reduced record of output o:
+    // N*N sums, then the per-model flags "touched with |m| > 1e-6" / "touched at all" and the flag "max|m| >= 0.05" as counts
+    const double *rec_o = rec ? rec + (int64_t)o * (N * N + 2 * N + 1) : nullptr;
+    if (rec_o) {
+        for (int t = tid; t < N * N; t += NTHREADS) lds.at(t / N, t % N) = rec_o[t];
+    } else {
+        fold_rows<NT>(lds, N, rows, o * nsym, nsym, partial, tid, NTHREADS);
+    }
     // the list is padded to a multiple of FUSED_TPB tiles per output, so every tile of this workgroup belongs to output o
     // (loaded by the tile wavefronts only: the solving wavefront must not wait for a descriptor it does not use)
     TileDesc td;
@@ -337,12 +344,21 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
     int32_t st_pub = 0;
     if (wave == 0) {
         if (spg_state && first) spg_prefetch_parts(pf, lane);                       // in flight during the elimination
-        const double am = (lane < N) ? lds.amax[lane] : 0.0;
-        const bool big = __ballot(am >= 0.05) != 0ull;   // max |m| >= 0.05 (misc.py:464)
+        bool s1, s2, big;
+        if (rec_o) {
+            s1 = lane < N && rec_o[N * N + lane] > 0.0;
+            s2 = lane < N && rec_o[N * N + N + lane] > 0.0;
+            big = rec_o[N * N + 2 * N] > 0.0;
+        } else {
+            const double am = (lane < N) ? lds.amax[lane] : 0.0;
+            s1 = am > 1.0e-6;
+            s2 = am > 0.0;
+            big = __ballot(am >= 0.05) != 0ull;          // max |m| >= 0.05 (misc.py:464)
+        }
         double V = 0.0;
         int32_t st = 0;
         PHASE(8);
-        solve_wave<NT>(lds, N, delta, am > 1.0e-6, am > 0.0, big, true, &V, lds.vout, &st, lane);
+        solve_wave<NT>(lds, N, delta, s1, s2, big, true, &V, lds.vout, &st, lane);
         if (lane == 0) lds.status = st;
         V_pub = V; st_pub = st;
         if (first) {   // first workgroup of this output publishes V, status, v
@@ -1332,6 +1348,31 @@ extern "C" int bluest_plan_eval(bluest_plan_t plan, const double *m_dev, int n_c
     return plan_eval(plan, m_dev, n_cand, m_stride, delta, var_dev, grad_dev, grad_stride, status_dev, stream, nullptr, 0, nullptr);
 }
 
+// group-sharded plans: the second half of an evaluation FROM the all-reduced Phi record in one launch -- redundant solve in
+// every workgroup, gradient tiles of this GPU's shard, optionally the SPG line-search decision in the tail
+extern "C" int bluest_plan_solve_grad(bluest_plan_t plan, const double *rec_dev, double delta, double *var_dev, double *grad_dev,
+                                      int32_t *status_dev, double *state_dev, int last_slot, int32_t *enable_dev, void *stream)
+{
+    int rc = plan_ready(plan, 1); if (rc) return rc;
+    if (!rec_dev || !var_dev || !grad_dev || !status_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (state_dev && !enable_dev) return fail(BLUEST_ERR_ARG, "the decision needs enable_dev");
+    const int n_out = (int)plan->outs.size();
+    if (state_dev && n_out > SPG_MAX_OUT) return fail(BLUEST_ERR_ARG, "more than %d outputs", SPG_MAX_OUT);
+    hipStream_t st = (hipStream_t)stream;
+    int kmax = 0;
+    for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
+    const dim3 grid((unsigned)(plan->n_tiles / plan->fused_tpb));
+#define LSR2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, \
+                                        rec_dev, delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->d_tvals, plan->d_tidx, var_dev, plan->d_v, status_dev,  \
+                                        grad_dev, plan->gate, state_dev, last_slot, enable_dev, plan->d_ticket)
+#define LSR(NT) do { if (kmax <= 5) LSR2(NT, 5); else if (kmax <= 6) LSR2(NT, 6); else if (kmax <= 8) LSR2(NT, 8); else LSR2(NT, 12); } while (0)
+    NT_DISPATCH(plan->N, LSR);
+#undef LSR
+#undef LSR2
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
 extern "C" int bluest_plan_eval_decide(bluest_plan_t plan, const double *m_dev, double delta, double *var_dev, int32_t *status_dev,
                                        double *state_dev, int last_slot, int32_t *enable_dev, void *stream)
 {
@@ -1365,7 +1406,7 @@ static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_
     // fused solve + gradient pass (2 launches per evaluation); groups larger than 12 take the generic tile code inside it
     if (grad_dev && n_cand == 1 && !g_debug_solve) {
         const dim3 grid((unsigned)(plan->n_tiles / plan->fused_tpb));
-#define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, \
+#define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, nullptr, \
                                         delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->d_tvals, plan->d_tidx, var_dev, plan->d_v, status, grad_dev, plan->gate, \
                                         dec_state, dec_last, dec_enable, plan->d_ticket)
 #define LSG(NT) do { if (kmax <= 5) LSG2(NT, 5); else if (kmax <= 6) LSG2(NT, 6); else if (kmax <= 8) LSG2(NT, 8); else LSG2(NT, 12); } while (0)

@@ -184,6 +184,8 @@ class ShardedPlan(object):
         device tensors (the v workspace is kept by this object)."""
         rec = self.plan.phi(m, out=rec)
         self.reduce_records(rec)
+        if want_grad and rec.shape[0] == 1 and hasattr(self.plan, "solve_grad"):
+            return self.plan.solve_grad(rec, delta, out=out)          # solve + gradient of the shard: one launch
         if out is None:
             var, v, status = self.plan.solve(rec, delta)
             grad = self.plan.grad(v, status) if want_grad else None

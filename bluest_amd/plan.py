@@ -227,6 +227,20 @@ class Plan(object):
                                              status.data_ptr(), _stream()))
         return var, v, status
 
+    def solve_grad(self, rec, delta=0.0, out=None):
+        """solve + gradient from an (all-reduced) Phi record of ONE candidate in one launch: (var, grad, status)"""
+        assert rec.shape[0] == 1
+        if out is None:
+            var = torch.empty((1, self.n_out), dtype=torch.float64, device=self.device)
+            grad = torch.empty((1, self.grad_len), dtype=torch.float64, device=self.device)
+            status = torch.empty((1, self.n_out), dtype=torch.int32, device=self.device)
+        else:
+            var, grad, status = out
+        with torch.cuda.device(self.device):
+            check(self.lib.bluest_plan_solve_grad(self._h, rec.data_ptr(), float(delta), var.data_ptr(), grad.data_ptr(),
+                                                  status.data_ptr(), None, 0, None, _stream()))
+        return var, grad, status
+
     def grad(self, v, status, out=None):
         nc = v.shape[0]
         grad = out if out is not None else torch.empty((nc, self.grad_len), dtype=torch.float64, device=self.device)

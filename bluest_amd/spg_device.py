@@ -277,8 +277,9 @@ class ShardedDeviceSpg(DeviceSpg):
     iteration on replicated vectors (x, g, d, state) and evaluates its shard of the groups.  One step =
 
         direction (replicated projection + first trial point)
-        Phi records of the shard -> all-reduce(SUM) of the records (peer-write exchange or RCCL) -> redundant solve + decision
-        gradient of the shard -> scattered into the K_tot-vector -> all-reduce(SUM) (RCCL) -> update
+        Phi records of the shard -> all-reduce(SUM) of the records (peer-write exchange or RCCL)
+        -> redundant solve + gradient of the shard + decision (one launch)
+        -> gradient scattered into the K_tot-vector -> all-reduce(SUM) (RCCL) -> update
 
     enqueued on the stream with no host synchronisation in between; the records and the gradient come out of the all-reduces
     bit-identical on every rank, so the replicated state never diverges and all ranks take the same host decisions."""
@@ -287,7 +288,6 @@ class ShardedDeviceSpg(DeviceSpg):
         super().__init__(sharded, *args, **kwargs)
         d = dict(dtype=torch.float64, device=self.dev)
         self.rec = torch.empty((1, self.n_out, self.hip.reclen), **d)
-        self.v = torch.empty((1, self.n_out, self.hip.N), **d)
         self.gnew = torch.empty((1, self.L), **d)
 
     def _window_direct(self, n_iterations, check_last):
@@ -298,11 +298,9 @@ class ShardedDeviceSpg(DeviceSpg):
             self._direction()
             check(lib.bluest_plan_phi(h, self.m.data_ptr(), 1, self.L, self.rec.data_ptr(), _stream()))
             sh.reduce_records(self.rec)
-            check(lib.bluest_plan_solve(h, self.rec.data_ptr(), 1, 0.0, self.var.data_ptr(), self.v.data_ptr(), self.status.data_ptr(),
-                                        _stream()))
-            check(lib.bluest_spg_decide(st.data_ptr(), self.var.data_ptr(), self.status.data_ptr(), self.n_out, 1, self.enable.data_ptr(),
-                                        _stream()))
-            check(lib.bluest_plan_grad(h, self.v.data_ptr(), self.status.data_ptr(), 1, self.grad.data_ptr(), self.grad.stride(0), _stream()))
+            # redundant solve + gradient tiles of the shard + the line-search decision: one launch
+            check(lib.bluest_plan_solve_grad(h, self.rec.data_ptr(), 0.0, self.var.data_ptr(), self.grad.data_ptr(), self.status.data_ptr(),
+                                             st.data_ptr(), 1, self.enable.data_ptr(), _stream()))
             check(lib.bluest_plan_combine_grad(h, self.grad.data_ptr(), self.grad.stride(0), coef, self.scale.data_ptr(), 1,
                                                self.gnew.data_ptr(), self.gnew.stride(0), _stream()))
             if sh.world > 1:

@@ -236,6 +236,10 @@ int bluest_plan_eval_decide(bluest_plan_t plan, const double *m_dev, double delt
  * gradient launch after the line search.  grad_dev: grad_len doubles (bluest_plan_grad_layout). */
 int bluest_plan_eval_grad_decide(bluest_plan_t plan, const double *m_dev, double delta, double *var_dev, double *grad_dev,
                                  int32_t *status_dev, double *state_dev, int last_slot, int32_t *enable_dev, void *stream);
+/* Group-sharded plans: solve + gradient of this GPU's shard FROM the all-reduced Phi record (bluest_plan_phi, summed over the
+ * ranks) in one launch; state_dev != NULL adds the line-search decision in its tail (as bluest_plan_eval_grad_decide). */
+int bluest_plan_solve_grad(bluest_plan_t plan, const double *rec_dev, double delta, double *var_dev, double *grad_dev,
+                           int32_t *status_dev, double *state_dev, int last_slot, int32_t *enable_dev, void *stream);
 int bluest_plan_v_workspace(bluest_plan_t plan, const double **v_dev, const int32_t **status_dev);
 int bluest_spg_direction(const double *x_dev, const double *g_dev, double *state_dev, double z, double floor, int64_t L,
                          double *d_dev, const double *scale_dev, double *xnew_dev, double *m_dev, int32_t *enable_dev,

@@ -31,14 +31,20 @@ def build_mappings(groups, multi_groups, cumsizes, N=None):
     located with a sorted search (vectorised), with a tuple dictionary as the fall-back for very large groups."""
     if N is None:
         N = 1 + max([int(g.max()) for g in groups if len(g)] + [0])
-    gkeys = []
-    for gk in groups:
-        keys = _group_keys(np.asarray(gk, dtype=np.int64).reshape(len(gk), -1), N) if len(gk) else None
-        if keys is None:
-            gkeys.append(None)
-        else:
-            order = np.argsort(keys, kind="stable")
-            gkeys.append((keys[order], order))
+    key_cache = {}
+
+    def sorted_keys(k):
+        """(sorted keys, order) of the global groups of size k, built when an output really needs the search (outputs that use
+        the global list itself take the identity map below: nothing is sorted at all in the usual case)"""
+        if k not in key_cache:
+            gk = groups[k - 1]
+            keys = _group_keys(np.asarray(gk, dtype=np.int64).reshape(len(gk), -1), N) if len(gk) else None
+            if keys is None:
+                key_cache[k] = None
+            else:
+                order = np.argsort(keys, kind="stable")
+                key_cache[k] = (keys[order], order)
+        return key_cache[k]
     tuple_pos = None
     mappings = []
     for mg in multi_groups:
@@ -52,7 +58,7 @@ def build_mappings(groups, multi_groups, cumsizes, N=None):
             if k <= len(groups) and len(gk) == len(groups[k - 1]) and np.array_equal(gk, groups[k - 1]):
                 idx.append(base + np.arange(len(gk), dtype=np.int64))          # identical list: identity map
                 continue
-            entry = gkeys[k - 1] if k <= len(groups) else None
+            entry = sorted_keys(k) if k <= len(groups) else None
             keys = _group_keys(gk, N)
             if entry is not None and keys is not None:
                 sk, order = entry

@@ -844,8 +844,8 @@ __global__ __launch_bounds__(1024) void k_proj_fused(const double *__restrict__ 
     double tau = isfinite(hint) ? hint : -INFINITY;          // pass 0: absolute; later passes: relative to rmax
     int passes = 0;
     rmax = mb;
-    // Every message is (s1_b, s0_b, m_b, bracket_b) in ONE 64-byte mailbox: bracket_b = the largest ratio NOT in the active set and
-    // the smallest one in it, as two floats rounded outwards from the threshold (conservative).  After the exchange every
+    // Every message is four doubles in ONE 64-byte mailbox: (s1_b, s0_b, m_b, bracket_b) in pass 0, (s1_b, s0_b, lo_b, hi_b) later;
+    // the bracket = the largest ratio NOT in the active set and the smallest one in it (pass 0: as two floats rounded outwards).  After the exchange every
     // workgroup knows the new threshold AND whether it separates the same entries as the one the sums were taken at -- then it IS
     // the fixed point, and the confirming pass (one more device-wide exchange, ~5 us) is skipped; otherwise the search goes on
     // and ends when a pass reproduces the threshold bit for bit.  (No counts in the message: the weights are positive, so an
@@ -865,14 +865,21 @@ __global__ __launch_bounds__(1024) void k_proj_fused(const double *__restrict__ 
         }
         block_pass4(s1, s0, lo, hi, sm, tid, ph);
         const unsigned int tag = epoch + 1u + (unsigned int)iter;
+        // pass 0 needs the slot of the third double for m_b, so its bracket travels as two floats; later passes send it exactly
         const double bracket_bits = __hiloint2double(__float_as_int(__double2float_rd(hi)), __float_as_int(__double2float_ru(lo)));
-        if (tid < 8) mailbox_send(sy + FusedProj::PART + ((iter & 1) * FusedProj::MAXB + b) * 8, tag, s1, s0, mb, bracket_bits);
+        if (tid < 8)
+            mailbox_send(sy + FusedProj::PART + ((iter & 1) * FusedProj::MAXB + b) * 8, tag, s1, s0, first ? mb : lo, first ? bracket_bits : hi);
         double msg[4];
         ok = mailbox_recv(sy + FusedProj::PART + ((iter & 1) * FusedProj::MAXB + (tid < nb ? tid : 0)) * 8, tag, tid < nb, msg);
         if (!ok) break;
         s1 = msg[0]; s0 = msg[1];
-        lo = (tid < nb) ? (double)__int_as_float(__double2loint(msg[3])) : -INFINITY;
-        hi = (tid < nb) ? (double)__int_as_float(__double2hiint(msg[3])) : INFINITY;
+        if (first) {
+            lo = (tid < nb) ? (double)__int_as_float(__double2loint(msg[3])) : -INFINITY;
+            hi = (tid < nb) ? (double)__int_as_float(__double2hiint(msg[3])) : INFINITY;
+        } else {
+            lo = (tid < nb) ? msg[2] : -INFINITY;
+            hi = (tid < nb) ? msg[3] : INFINITY;
+        }
         const bool was_first = first;
         if (first) {
             const double m = (tid < nb) ? msg[2] : -INFINITY;

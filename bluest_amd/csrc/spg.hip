@@ -59,6 +59,7 @@ struct ProjLds {
     long long c[2][16];
     double d2[2][16];
     double d3[2][16];
+    double xf[8];           // results of the cross-workgroup fold of a Newton pass (k_proj_fused)
 };
 
 __device__ __forceinline__ double block_max(double x, ProjLds &s, int tid, int &ph)
@@ -782,6 +783,32 @@ __device__ __forceinline__ bool mailbox_recv(const double *box, unsigned int tag
     }
     return __syncthreads_and(ok) != 0;
 }
+// the same without the barrier: per-lane result (1 = arrived or inactive, 0 = timed out)
+__device__ __forceinline__ int mailbox_poll(const double *box, unsigned int tag, bool active, double (&v)[4])
+{
+    int ok = 1;
+    v[0] = v[1] = v[2] = v[3] = 0.0;
+    if (active) {
+        const unsigned long long *w = reinterpret_cast<const unsigned long long *>(box);
+        unsigned int spins = 0;
+        for (;;) {
+            unsigned long long q[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) q[i] = __hip_atomic_load(w + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool all = true;
+#pragma unroll
+            for (int i = 0; i < 8; i++) all = all && (unsigned int)(q[i] >> 32) == tag;
+            if (all) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[i] = __longlong_as_double((long long)((q[2 * i] & 0xffffffffull) | (q[2 * i + 1] << 32)));
+                break;
+            }
+            if (++spins > PROJ_SPIN_LIMIT) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return ok;
+}
 
 template <int ITEMS>
 __global__ __launch_bounds__(1024) void k_proj_fused(const double *__restrict__ x, const double *__restrict__ g, double lambda,
@@ -869,25 +896,34 @@ __global__ __launch_bounds__(1024) void k_proj_fused(const double *__restrict__ 
         const double bracket_bits = __hiloint2double(__float_as_int(__double2float_rd(hi)), __float_as_int(__double2float_ru(lo)));
         if (tid < 8)
             mailbox_send(sy + FusedProj::PART + ((iter & 1) * FusedProj::MAXB + b) * 8, tag, s1, s0, first ? mb : lo, first ? bracket_bits : hi);
-        double msg[4];
-        ok = mailbox_recv(sy + FusedProj::PART + ((iter & 1) * FusedProj::MAXB + (tid < nb ? tid : 0)) * 8, tag, tid < nb, msg);
-        if (!ok) break;
-        s1 = msg[0]; s0 = msg[1];
-        if (first) {
-            lo = (tid < nb) ? (double)__int_as_float(__double2loint(msg[3])) : -INFINITY;
-            hi = (tid < nb) ? (double)__int_as_float(__double2hiint(msg[3])) : INFINITY;
-        } else {
-            lo = (tid < nb) ? msg[2] : -INFINITY;
-            hi = (tid < nb) ? msg[3] : INFINITY;
-        }
+        // the <= 64 messages are received and folded by wavefront 0 alone (wavefront reductions, no LDS, no barrier; the same
+        // operation order as a workgroup-wide fold whose other wavefronts contribute identities), then ONE barrier hands the
+        // five results to everybody
         const bool was_first = first;
-        if (first) {
-            const double m = (tid < nb) ? msg[2] : -INFINITY;
-            rmax = block_max(m, sm, tid, ph);
-            if (s0 > 0.0) s1 = fma(s0, m - rmax, s1);        // re-base this workgroup's partial to the grid-wide max
-            lo -= rmax; hi -= rmax;                          // pass 0 compared in absolute coordinates
+        if (tid < WAVE) {
+            double msg[4];
+            const int got = mailbox_poll(sy + FusedProj::PART + ((iter & 1) * FusedProj::MAXB + (tid < nb ? tid : 0)) * 8, tag, tid < nb, msg);
+            const bool all_ok = __ballot(got == 0) == 0ull;
+            double q1 = msg[0], q0 = msg[1], ql, qh, rm = 0.0;
+            if (first) {
+                ql = (tid < nb) ? (double)__int_as_float(__double2loint(msg[3])) : -INFINITY;
+                qh = (tid < nb) ? (double)__int_as_float(__double2hiint(msg[3])) : INFINITY;
+                const double m = (tid < nb) ? msg[2] : -INFINITY;
+                rm = wave_max(m);
+                if (q0 > 0.0) q1 = fma(q0, m - rm, q1);          // re-base this workgroup's partial to the grid-wide max
+                ql -= rm; qh -= rm;                              // pass 0 compared in absolute coordinates
+            } else {
+                ql = (tid < nb) ? msg[2] : -INFINITY;
+                qh = (tid < nb) ? msg[3] : INFINITY;
+            }
+            q1 = wave_sum(q1); q0 = wave_sum(q0); ql = wave_max(ql); qh = -wave_max(-qh);
+            if (tid == 0) { sm.xf[0] = all_ok ? 1.0 : 0.0; sm.xf[1] = q1; sm.xf[2] = q0; sm.xf[3] = ql; sm.xf[4] = qh; sm.xf[5] = rm; }
         }
-        block_pass4(s1, s0, lo, hi, sm, tid, ph);
+        __syncthreads();
+        ok = sm.xf[0] != 0.0;
+        if (!ok) break;
+        s1 = sm.xf[1]; s0 = sm.xf[2]; lo = sm.xf[3]; hi = sm.xf[4];
+        if (first) rmax = sm.xf[5];
         if (first) {
 #pragma unroll
             for (int k = 0; k < ITEMS; k++) r[k] -= rmax;
@@ -1000,7 +1036,7 @@ static int simplex_impl(const double *x_dev, const double *g_dev, double lambda,
             static int maxp = getenv("BLUEST_PROJ_MAXP") ? atoi(getenv("BLUEST_PROJ_MAXP")) : (int)FusedProj::MAXP;   // timing experiments
             static int bracket = getenv("BLUEST_PROJ_NO_BRACKET") ? 0 : 1;   // timing experiments
             static int maxb = getenv("BLUEST_PROJ_MAXB") ? atoi(getenv("BLUEST_PROJ_MAXB")) : 64;   // 64 measured best at L = 245505 (61 -> 42 us)
-            const int nbf = std::max(1, std::min(std::min(nb, ncu), std::min(maxb, (int)FusedProj::MAXB)));
+            const int nbf = std::max(1, std::min(std::min(nb, ncu), std::min(std::min(maxb, 64), (int)FusedProj::MAXB)));   // <= 64: one wavefront folds the messages
             const int64_t items = (L + 1024LL * nbf - 1) / (1024LL * nbf);
             if (items <= 16 && !getenv("BLUEST_PROJ_MULTI_LAUNCH")) {
 #define PF(IT) hipLaunchKernelGGL((k_proj_fused<IT>), dim3(nbf), dim3(1024), 0, st, x_dev, g_dev, lambda, z, floor, L, ws, nb, p_dev, d_dev, \

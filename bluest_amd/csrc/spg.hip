@@ -340,14 +340,14 @@ __global__ __launch_bounds__(SIMPLEX_BLOCK) void k_simplex(const double *__restr
         if (proj_pending(spg_state, spg_mode)) {   // line search pending: the next trial point instead of a new direction
             if (!xnew) return;                     // (without the fused trial outputs the caller launches bluest_spg_trial)
             const double alpha = spg_state[SPG_ALPHA];
-            for (int64_t i = tid; i < L; i += SIMPLEX_BLOCK) spg_trial_point(i, alpha, x, d, scale, xnew, mtrial);
+            for (int64_t i = tid; i < L; i += blockDim.x) spg_trial_point(i, alpha, x, d, scale, xnew, mtrial);
             if (tid == 0) *enable = 1;
             return;
         }
         if (spg_mode == 1) lambda = spg_state[SPG_LAMBDA];   // direction: the step length lives in HBM
     }
     constexpr int R = ITEMS > 0 ? ITEMS : 1;
-    constexpr int B = SIMPLEX_BLOCK;
+    const int B = (int)blockDim.x;   // <= SIMPLEX_BLOCK; short vectors run with fewer wavefronts: every workgroup reduction is cheaper
     double r[R], sc[R];
     auto scale_of = [&](double xi) -> double { return floor > 0.0 ? fmax(xi, floor) : 1.0; };
     auto ratio_of = [&](int64_t i, double xi) -> double {
@@ -1067,7 +1067,11 @@ static int simplex_impl(const double *x_dev, const double *g_dev, double lambda,
         HIP_TRY(hipGetLastError());
         return BLUEST_OK;
     }
-#define SP(IT) hipLaunchKernelGGL((k_simplex<IT>), dim3(1), dim3(SIMPLEX_BLOCK), 0, st, x_dev, g_dev, lambda, z, floor, L, p_dev, d_dev, stats_dev, spg_state, spg_mode, \
+    // short vectors (the solver's working set is a few hundred entries): as few wavefronts as hold the vector with 4 entries per
+    // thread -- the kernel is a chain of workgroup reductions, and those cost ~1.8 us each across 16 wavefronts
+    int sblock = SIMPLEX_BLOCK;
+    while (sblock > 64 && (int64_t)(sblock / 2) * 4 >= L) sblock /= 2;
+#define SP(IT) hipLaunchKernelGGL((k_simplex<IT>), dim3(1), dim3(sblock), 0, st, x_dev, g_dev, lambda, z, floor, L, p_dev, d_dev, stats_dev, spg_state, spg_mode, \
                                   trial_scale, trial_xnew, trial_m, trial_enable)
     if (L <= SIMPLEX_BLOCK * 4) SP(4);
     else if (L <= SIMPLEX_BLOCK * 12) SP(12);

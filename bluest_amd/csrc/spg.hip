@@ -464,8 +464,9 @@ struct FusedProj {
 struct ProjWs {            // layout of the caller-provided workspace (doubles)
     // [0, 2L): interleaved (r_i, s_i) pairs
     static __host__ __device__ int64_t part_off(int64_t L) { return 2 * L; }            // 4 doubles per block
-    static __host__ __device__ int64_t tau_off(int64_t L, int nb) { return 2 * L + 4LL * nb; }   // tau, rmax
-    static __host__ __device__ int64_t sync_off(int64_t L, int nb) { return 2 * L + 4LL * nb + 16; }   // single-launch path
+    // (room for at least 64 blocks of partials: the single-launch path may run 64 workgroups of 256 threads on a short vector)
+    static __host__ __device__ int64_t tau_off(int64_t L, int nb) { return 2 * L + 4LL * (nb > 64 ? nb : 64); }   // tau, rmax
+    static __host__ __device__ int64_t sync_off(int64_t L, int nb) { return tau_off(L, nb) + 16; }   // single-launch path
     static __host__ __device__ int64_t total(int64_t L, int nb) { return sync_off(L, nb) + FusedProj::DOUBLES; }
 };
 
@@ -821,6 +822,7 @@ __global__ __launch_bounds__(1024) void k_proj_fused(const double *__restrict__ 
     __shared__ ProjLds sm;
     int ph = 0;
     const int tid = threadIdx.x, nb = gridDim.x, b = blockIdx.x;
+    const int64_t BT = blockDim.x;   // 1024, or 256 for vectors that 64 workgroups of 256 hold: cheaper workgroup reductions
     double *t = ws + ProjWs::tau_off(L, nb_ws);
     double *sy = ws + ProjWs::sync_off(L, nb_ws);
     if (proj_idle(spg_state) || t[12] != 0.0) {   // t[12]: sticky "a wait timed out" flag
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(1024) void k_proj_fused(const double *__restrict__ 
         const double alpha = spg_state[SPG_ALPHA];
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
-            const int64_t i = ((int64_t)k * nb + b) * 1024 + tid;
+            const int64_t i = ((int64_t)k * nb + b) * BT + tid;
             if (i < L) spg_trial_point(i, alpha, x, d, scale, xnew, mtrial);
         }
         if (b == 0 && tid == 0) *enable = 1;
@@ -848,7 +850,7 @@ __global__ __launch_bounds__(1024) void k_proj_fused(const double *__restrict__ 
     double rmax = -INFINITY;
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
-        const int64_t i = ((int64_t)k * nb + b) * 1024 + tid;
+        const int64_t i = ((int64_t)k * nb + b) * BT + tid;
         r[k] = -INFINITY; sc[k] = 0.0;
         if (i < L) {
             const double xi = x[i];
@@ -948,7 +950,7 @@ __global__ __launch_bounds__(1024) void k_proj_fused(const double *__restrict__ 
     long long npos = 0;
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
-        const int64_t i = ((int64_t)k * nb + b) * 1024 + tid;
+        const int64_t i = ((int64_t)k * nb + b) * BT + tid;
         if (i < L) {
             const double pi = sc[k] * fmax(r[k] - tau, 0.0);
             const double di = pi - x[i];
@@ -1036,10 +1038,14 @@ static int simplex_impl(const double *x_dev, const double *g_dev, double lambda,
             static int maxp = getenv("BLUEST_PROJ_MAXP") ? atoi(getenv("BLUEST_PROJ_MAXP")) : (int)FusedProj::MAXP;   // timing experiments
             static int bracket = getenv("BLUEST_PROJ_NO_BRACKET") ? 0 : 1;   // timing experiments
             static int maxb = getenv("BLUEST_PROJ_MAXB") ? atoi(getenv("BLUEST_PROJ_MAXB")) : 64;   // 64 measured best at L = 245505 (61 -> 42 us)
-            const int nbf = std::max(1, std::min(std::min(nb, ncu), std::min(std::min(maxb, 64), (int)FusedProj::MAXB)));   // <= 64: one wavefront folds the messages
-            const int64_t items = (L + 1024LL * nbf - 1) / (1024LL * nbf);
+            // workgroup size: 256 threads when 64 of them hold the vector with <= 4 entries per thread (K_tot <= 65536), else 1024
+            static int bt_env = getenv("BLUEST_PROJ_THREADS") ? atoi(getenv("BLUEST_PROJ_THREADS")) : 0;   // timing experiments
+            const int bt = bt_env ? bt_env : (L <= 64LL * 256 * 4 ? 256 : 1024);
+            const int nb_bt = (int)((L + bt - 1) / bt);
+            const int nbf = std::max(1, std::min(std::min(nb_bt, ncu), std::min(std::min(maxb, 64), (int)FusedProj::MAXB)));   // <= 64: one wavefront folds the messages
+            const int64_t items = (L + (int64_t)bt * nbf - 1) / ((int64_t)bt * nbf);
             if (items <= 16 && !getenv("BLUEST_PROJ_MULTI_LAUNCH")) {
-#define PF(IT) hipLaunchKernelGGL((k_proj_fused<IT>), dim3(nbf), dim3(1024), 0, st, x_dev, g_dev, lambda, z, floor, L, ws, nb, p_dev, d_dev, \
+#define PF(IT) hipLaunchKernelGGL((k_proj_fused<IT>), dim3(nbf), dim3(bt), 0, st, x_dev, g_dev, lambda, z, floor, L, ws, nb, p_dev, d_dev, \
                                   stats_dev, spg_state, spg_mode, trial_scale, trial_xnew, trial_m, trial_enable, maxp, bracket)
                 if (items <= 1) PF(1); else if (items <= 2) PF(2); else if (items <= 4) PF(4); else if (items <= 8) PF(8); else PF(16);
 #undef PF

@@ -263,7 +263,7 @@ class DeviceSpg(object):
             # NaN and raises a sticky flag in its workspace): say so instead of handing back a NaN allocation
             L = self.L
             if L > 4096:
-                off = 2 * L + 4 * ((L + 1023) // 1024)
+                off = 2 * L + 4 * max((L + 1023) // 1024, 64)          # csrc/spg.hip ProjWs::tau_off
                 if float(self.pws[off + 12]) != 0.0:
                     self.pws[off + 12:off + 13].copy_(self._zero)
                     raise RuntimeError("device SPG: the single-launch simplex projection timed out waiting for a workgroup "

@@ -14,6 +14,6 @@ for n, k, o in ((20, 5, 8), (25, 6, 1)):
         if L != mos.L:
             continue
         nb = (L + 1023) // 1024
-        off = 2 * L + 4 * nb
+        off = 2 * L + 4 * max(nb, 64)
         t = ws[off:off + 16].cpu().numpy()
         print("K_tot %d: %d projections, %.2f passes on average" % (L, int(t[10]), t[9] / max(t[10], 1)))

@@ -45,9 +45,10 @@ spg_sap_default_params = {
                               # practical purposes but keeps near-ties smooth -- the plain max there cost 40 % more time on the
                               # hard cases (line-search stalls at the kinks) for objectives equal to 1e-5
     "polish_full_stages": 0,  # how many leading stages run on the full problem (0 = all but the last)
-    "polish_full_loose": 5.0, # stall tolerance of the full-problem stages in working-set mode, in units of rel_tol (25 was
-                              # 10-40 % faster on multi-output problems but left the n = 16, two-output test problem 2.9e-4 above
-                              # its optimum: the working set is drawn from where these stages stop; tools/loose_sweep.py)
+    "polish_full_loose": 2.0, # stall tolerance of the full-problem stages in working-set mode, in units of rel_tol: the working set
+                              # is drawn from where these stages stop.  Chosen together with stall_window on 28 multi-output
+                              # shapes (tools/param_ab.sh, n = 15..24): (loose, window) = (5, 100): worst end point 2.5e-4 above
+                              # the best of all variants, mean 2.0e-5; (2, 60): 4.4e-5 / 9.6e-6 at the same total time (+1 %)
     "sparsify_tol": 1.0e-5,   # final support selection: keep the fewest largest entries whose objective is within this (relative)
                               # of the full iterate's (0 = off)
     "prune_tol": 1.0e-7,      # (when that is off) drop the smallest entries holding less than this share of the budget
@@ -55,7 +56,7 @@ spg_sap_default_params = {
     "restarts": 6,            # restarts of the LAST continuation stage (each re-initialises the spectral step from the pruned point)
     "restart_tol": 1.0e-5,    # stop restarting when a restart improved the objective by less than this (relative)
     "rel_tol": 2.0e-6,        # device loop: also stop when f decreased by less than rel_tol*f over the last
-    "stall_window": 100,      #              stall_window iterations (the flat optimum keeps the projected gradient ~1e-4)
+    "stall_window": 60,       #              stall_window iterations (the flat optimum keeps the projected gradient ~1e-4)
 }
 
 

@@ -160,8 +160,9 @@ class Stepper(object):
     """W warm-up steps, then repeats x K timed steps; a hipGraph of `cycle` consecutive steps is replayed when that is possible
     (cycle <= K, so replays really happen inside the timed region) and everything else is launched eagerly -- the line says which"""
 
-    def __init__(self, torch, step, ring_len, steps, graph_steps, allow_graph, barrier):
+    def __init__(self, torch, step, ring_len, steps, graph_steps, allow_graph, barrier, agree=None):
         self.torch, self.step, self.barrier = torch, step, barrier
+        self.agree = agree if agree is not None else (lambda v: v)      # N > 1: max over the ranks, so all of them loop alike
         self.steps = steps
         self.cycle = 0
         self.graph = None
@@ -212,13 +213,20 @@ class Stepper(object):
         self.run(self.steps)
         self.barrier()
         pilot = time.perf_counter() - t0
-        repeats = max(1, int(np.ceil(MIN_TIMED_S / max(pilot, 1e-9))))
-        self.barrier()
-        t0 = time.perf_counter()
-        for _ in range(repeats):
-            self.run(self.steps)
-        self.barrier()
-        return (time.perf_counter() - t0) / (repeats * self.steps), repeats
+        repeats = int(self.agree(max(1, int(np.ceil(MIN_TIMED_S / max(pilot, 1e-9))))))
+        while True:
+            self.barrier()
+            t0 = time.perf_counter()
+            for _ in range(repeats):
+                self.run(self.steps)
+            self.barrier()
+            elapsed = time.perf_counter() - t0
+            # the pilot block carries the synchronisation latency, so short blocks under-estimate the repeats: go again.  Every
+            # decision is taken on a value all ranks agree on (a different repeat count per rank would unbalance the collectives)
+            slowest = float(self.agree(elapsed))
+            if slowest >= MIN_TIMED_S or repeats >= 10 ** 6:
+                return elapsed / (repeats * self.steps), repeats
+            repeats = int(np.ceil(repeats * 1.25 * MIN_TIMED_S / max(slowest, 1e-9)))
 
 
 def chain_time(torch, fn, R=50, reps=20):
@@ -342,7 +350,15 @@ def main():
     # RCCL launches are left eager (a collective inside a captured graph is a different code path of the library); the peer-write
     # exchange is a plain kernel and is captured with the rest of the step
     graphable = (sharded is None) or (sharded.exchange is not None)
-    stepper = Stepper(torch, step, len(ring), args.steps, args.graph_steps, graphable and not args.no_graph, barrier)
+    def agree(v):
+        """max over the ranks (host value); identity on one GPU"""
+        if world == 1:
+            return v
+        t = torch.tensor([float(v)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    stepper = Stepper(torch, step, len(ring), args.steps, args.graph_steps, graphable and not args.no_graph, barrier, agree)
     sec_per_step, repeats = stepper.timed(args.warmup)
     if world > 1:
         t = torch.tensor([sec_per_step], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -363,7 +379,7 @@ def main():
         assert float((var[0] / v_mine - 1).abs().max()) < 1e-10, "sharded evaluation disagrees with the single-GPU one"
         fv = torch.empty_like(v_full); fg = torch.empty_like(g_full); fs = torch.empty_like(st_full)
         full_step = lambda i: full.eval(ring[i % len(ring)], out=(fv, fg, fs))      # noqa: E731
-        rep_stepper = Stepper(torch, full_step, len(ring), args.steps, args.graph_steps, not args.no_graph, barrier)
+        rep_stepper = Stepper(torch, full_step, len(ring), args.steps, args.graph_steps, not args.no_graph, barrier, agree)
         rep_sec, _ = rep_stepper.timed(args.warmup)
         t = torch.tensor([rep_sec], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -65,7 +65,8 @@ def sap_wallclock(prob, reps=4):
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         row = {"setup_s": t1 - t0, "solve_s": t2 - t1, "total_s": t2 - t0, "spg_iterations": int(mos.solver_info["it"]),
-               "objective_evaluations": int(mos.solver_info["count"]), "max_variance": float(max(mos.variances(m)))}
+               "objective_evaluations": int(mos.solver_info["count"]), "max_variance": float(max(mos.variances(m))),
+               "setup_phases_ms": {k: round(v, 3) for k, v in mos.setup_phases.items()}}
         # everything the solve does (full-problem and working-set steps, restricted plans, pricing, host checks) per trial point
         row["solve_us_per_evaluation"] = row["solve_s"] / max(row["objective_evaluations"], 1) * 1e6
         t3 = time.perf_counter()

@@ -1,6 +1,32 @@
 """Host-side hygiene around the GPU path: what the CPU must NOT do while it drives the kernels."""
 
 
+import os
+import sys
+import time
+
+_DEBUG_TIMING = bool(os.environ.get("BLUEST_DEBUG_TIMING"))
+
+
+class phase_clock(object):
+    """wall-clock split of a host-side section (`tick(label)` after each phase; ~0.1 us each); BLUEST_DEBUG_TIMING=1 prints it"""
+
+    def __init__(self, name):
+        self.name, self.t, self.rows = name, time.perf_counter(), []
+
+    def tick(self, label):
+        now = time.perf_counter()
+        self.rows.append((label, now - self.t))
+        self.t = now
+
+    def as_dict(self):
+        return {k + "_ms": v * 1e3 for k, v in self.rows}
+
+    def report(self):
+        if _DEBUG_TIMING and self.rows:
+            sys.stderr.write("[bluest timing] %s: %s\n" % (self.name, "  ".join("%s %.2f ms" % (k, v * 1e3) for k, v in self.rows)))
+
+
 class host_section(object):
     """Context of the constructors and of solve(): two things on the HOST that cost more than the GPU work they surround.
 
@@ -15,13 +41,16 @@ class host_section(object):
       thread inside the section (threadpoolctl, if installed; its previous limits are restored on exit)."""
 
     _controller = None
-    _controller_modules = -1
+    _controller_key = None
+    _BLAS_CARRIERS = ("numpy", "scipy.linalg", "scipy.sparse.linalg", "torch", "sklearn", "mkl")
 
     @classmethod
     def _blas(cls):
-        import sys
-        if cls._controller_modules != len(sys.modules):        # a BLAS may have been imported since (scipy.linalg is lazy)
-            cls._controller_modules = len(sys.modules)
+        # the scan (a dlopen of every loaded BLAS / OpenMP runtime) is repeated only when a package that brings its own BLAS has
+        # been imported since (scipy.linalg is lazy), not whenever sys.modules grew
+        key = tuple(name in sys.modules for name in cls._BLAS_CARRIERS)
+        if cls._controller_key != key:
+            cls._controller_key = key
             try:
                 from threadpoolctl import ThreadpoolController
                 cls._controller = ThreadpoolController()
@@ -44,6 +73,14 @@ class host_section(object):
             import gc
             gc.enable()
         return False
+
+
+def warm():
+    """everything a host_section touches for the first time -- the import of threadpoolctl and its scan of the loaded
+    libraries -- done at package import, NOT inside the first timed constructor: on a box whose image is still paging in
+    (the first minutes of a fresh GPU lease) one first-touch file read costs up to a second, which the round-2 driver run
+    booked as `sap_wallclock.cold.setup_s` = 1.0 s (11.9 ms on a box with a warm page cache)."""
+    host_section._blas()
 
 
 def in_host_section(fn):

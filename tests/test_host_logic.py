@@ -103,3 +103,36 @@ def test_support_multipliers_recover_the_kkt_weights():
     mu = support_multipliers(G, x)
     assert mu.min() >= 0 and abs(mu.sum() - 1) < 1e-12 and np.abs(mu - mu_true).max() < 1e-6
     assert np.array_equal(support_multipliers(G[:1], x), np.ones(1))
+
+
+def test_first_host_section_touches_no_file_and_imports_nothing():
+    """round-2 driver run: `sap_wallclock.cold.setup_s` = 1.0 s on a freshly leased box whose image was still paging in, against
+    12 ms on a warm one -- the first host_section imported threadpoolctl and scanned the loaded libraries inside the timed
+    constructor.  After `import bluest_amd.sap` a fresh subprocess must enter its first section, and run the host half of
+    MOSAP's set-up, without opening a file or importing a module."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+import numpy as np
+import bluest_amd.sap, bluest_amd.mosap
+from bluest_amd import synth
+from bluest_amd.host import host_section
+from bluest_amd.mosap import build_mappings
+from bluest_amd.sap import LazyIndicators, normalise_groups
+prob = synth.problem(8, 3, 2)
+events = []
+sys.addaudithook(lambda ev, args: events.append((ev, str(args)[:120])) if ev in ("open", "import", "ctypes.dlopen") else None)
+with host_section():
+    groups = [g.copy() for g in prob["groups"]]
+    normalise_groups(groups, 3, flatten=False)
+    e = LazyIndicators(groups, 8)[0]
+    maps = build_mappings(groups, [[g.copy() for g in groups]] * 2, np.cumsum([0] + [len(g) for g in groups]), 8)
+    tot = (np.ones(len(e)) @ e)
+bad = [ev for ev in events if ev[0] != "import" or "None" in ev[1]]      # "import" of an already loaded module still reports
+bad = [ev for ev in events if ev[0] in ("open", "ctypes.dlopen")]
+print("EVENTS", bad)
+assert not bad, bad
+'''
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=__import__("os").path.dirname(__import__("os").path.dirname(__file__)), timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr

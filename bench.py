@@ -125,6 +125,7 @@ def cpu_baseline(prob, seconds=14.0):
     B2: the sparse objectiveK_c-style loop (cmisc.cpp:25-40) + the same solve and gradK."""
     from oracle import oracle as orc
     orc.build()
+    orc.select_fast_math()          # the reference's compiler flags for the timed legs (the checker uses the strict build)
     sap = orc.OracleSAP(prob["C"][0], prob["kmax"], prob["groups"], prob["costs"])
     m = prob["m"][0]
     res = {}

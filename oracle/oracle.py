@@ -29,20 +29,34 @@ _u8p = ctypes.POINTER(ctypes.c_uint8)
 
 
 def build(force=False):
-    """Compile liboracle_bluest.so (gcc) and, when the reference tree is present, oracle/_ref."""
-    so = os.path.join(_HERE, "liboracle_bluest.so")
+    """Compile the C restatement (gcc; strict-IEEE build for the checker, fast-math twin for the timed CPU baseline) and, when
+    the reference tree is present, oracle/_ref."""
     src = os.path.join(_HERE, "bluest_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "liboracle_bluest.so"], stdout=subprocess.DEVNULL)
+    for name in ("liboracle_bluest_strict.so", "liboracle_bluest.so"):
+        so = os.path.join(_HERE, name)
+        if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, name], stdout=subprocess.DEVNULL)
     if os.path.exists("/root/reference/bluest/cmisc.cpp"):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
-    return so
+    return os.path.join(_HERE, "liboracle_bluest_strict.so")
+
+
+_FAST = False
+
+
+def select_fast_math():
+    """bench.py's cpu_baseline leg only: switch to the build with the reference's own compiler flags (setup.py:6, -ffast-math).
+    Loading a -ffast-math shared object sets FTZ/DAZ for the whole process (crtfastmath), so the CHECKER never does: tests and
+    smoke() stay on the strict-IEEE build."""
+    global _FAST, _LIB
+    if not _FAST:
+        _FAST, _LIB = True, None
 
 
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liboracle_bluest.so")
+        so = os.path.join(_HERE, "liboracle_bluest.so" if _FAST else "liboracle_bluest_strict.so")
         if not os.path.exists(so):
             build()
         _LIB = ctypes.CDLL(so)
@@ -58,7 +72,9 @@ _REF = None
 
 def ref_native():
     """the reference's OWN native module, compiled from /root/reference/bluest/cmisc.cpp into oracle/_ref/ by
-    `make -C oracle ref` (build container only; the binary travels to the GPU box, the source does not).  None if absent."""
+    `make -C oracle ref` (build container only; the binary travels to the GPU box, the source does not).  None if absent.
+    Built with the reference's flags (-ffast-math): importing it sets FTZ/DAZ for the process, so only bench.py's cpu_baseline,
+    gen_golden.py and a SUBPROCESS of the test suite load it."""
     global _REF
     if _REF is None:
         import glob

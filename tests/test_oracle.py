@@ -221,20 +221,44 @@ def test_weighted_simplex_projection(oracle):
 
 def test_reference_native_module_agrees_with_restatement(oracle):
     """oracle/_ref (the reference's own cmisc.cpp, compiled where /root/reference exists) vs the C restatement, and the
-    'as executed' evaluation used as bench.py's reference-kind CPU baseline"""
-    cm = oracle.ref_native()
-    if cm is None:
+    'as executed' evaluation used as bench.py's reference-kind CPU baseline.  Runs in a subprocess: oracle/_ref carries the
+    reference's -ffast-math, and importing it would switch the whole pytest process to flush-to-zero."""
+    import glob
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not glob.glob(os.path.join(root, "oracle", "_ref", "_cmisc_bluest*.so")):
         pytest.skip("oracle/_ref not built (no reference tree here)")
-    prob = synth.problem(10, 4, 1)
-    sap = oracle.OracleSAP(prob["C"][0], 4, prob["groups"], prob["costs"])
-    m = prob["m"][0]
-    Va, ga, _ = sap.variance_GH_as_executed(m)
-    Vb, gb, _ = sap.variance_GH(m, nohess=True)
-    assert abs(Va / Vb - 1) < 1e-14 and rel_err(ga, gb) < 1e-14
-    for k in (1, 3):
-        PHI = np.zeros(100)
-        cm.objectiveK_c(PHI, 10, k, sap.sizes[k], m[sap.cumsizes[k - 1]:sap.cumsizes[k]], sap.groups[k - 1].ravel(), sap.invcovs[k - 1])
-        assert rel_err(PHI, oracle.objectiveK(10, k, sap.sizes[k], m[sap.cumsizes[k - 1]:sap.cumsizes[k]], sap.groups[k - 1], sap.invcovs[k - 1])) < 1e-15
+    code = """
+import numpy as np
+from oracle import oracle
+from bluest_amd import synth
+cm = oracle.ref_native()
+prob = synth.problem(10, 4, 1)
+sap = oracle.OracleSAP(prob["C"][0], 4, prob["groups"], prob["costs"])
+m = prob["m"][0]
+Va, ga, _ = sap.variance_GH_as_executed(m)
+Vb, gb, _ = sap.variance_GH(m, nohess=True)
+assert abs(Va / Vb - 1) < 1e-14 and np.abs(ga - gb).max() / np.abs(gb).max() < 1e-14
+for k in (1, 3):
+    PHI = np.zeros(100)
+    args = (10, k, sap.sizes[k], m[sap.cumsizes[k - 1]:sap.cumsizes[k]])
+    cm.objectiveK_c(PHI, *args, sap.groups[k - 1].ravel(), sap.invcovs[k - 1])
+    ours = oracle.objectiveK(*args, sap.groups[k - 1], sap.invcovs[k - 1])
+    assert np.abs(PHI - ours).max() / np.abs(ours).max() < 1e-15
+print("ok")
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_checker_does_not_change_the_floating_point_environment(oracle):
+    """the oracle the tests load is the strict-IEEE build: subnormals survive in this process after using it"""
+    oracle.lib()
+    tiny = np.float64(5e-324)
+    assert tiny > 0 and np.float64(1e-310) * np.float64(0.5) > 0
+    assert np.finfo(np.float64).smallest_subnormal > 0
 
 
 def _estimator_case(G, case, sizes):

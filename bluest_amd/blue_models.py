@@ -6,7 +6,8 @@ In scope here: given covariances and model costs -> model groups (cliques of the
 groups), their union over the outputs, group costs, one MOSAP on the GPU, `solver="spg"`, the reference's return dictionaries;
 `solve()` then samples the selected groups through the user's `sampler` / `evaluate` and forms the BLUE estimators.
 Out of scope (refused with BLUESTError): estimating covariances or costs by sampling, the SPD
-projection of incomplete covariances, saving / loading model graphs, MLMC / MFMC / plain-MC drivers, MPI sample splitting.
+projection of incomplete covariances, saving / loading model graphs, MLMC / MFMC / plain-MC drivers.  An MPI communicator passed
+as `comm` is honoured the way the reference uses it (optimiser and estimators on rank 0 + bcast, samples split over the ranks).
 
 Conventions kept from the reference (bluest/blue_models.py:43-56, :166-179): in a user covariance an infinite entry means "never
 couple these two models", a zero entry means "uncorrelated" (such pairs are not coupled either when `remove_uncorrelated`, the
@@ -22,6 +23,17 @@ from .host import in_host_section
 from .sap import BLUESTError
 
 default_params = {"verbose": True, "comm": None, "remove_uncorrelated": True, "optimization_solver": "spg", "sample_batch_size": 1}
+
+
+class _SerialComm(object):
+    """what `get_comm()` returns when no MPI communicator was passed (the reference defaults to mpi4py's COMM_WORLD,
+    bluest/blue_models.py:22; mpi4py is not a dependency of this build): one rank, collectives are identities"""
+
+    def Get_rank(self): return 0
+    def Get_size(self): return 1
+    def bcast(self, obj, root=0): return obj
+    def allreduce(self, obj, op=None): return obj
+    def barrier(self): return None
 
 
 class _Coupling(object):
@@ -85,8 +97,10 @@ class BLUEProblem(object):
         self.params = dict(default_params, **params)
         self.default_params = default_params
         comm = self.params["comm"]
-        self.mpiRank = 0 if comm is None else comm.Get_rank()
-        self.mpiSize = 1 if comm is None else comm.Get_size()
+        if comm is None:
+            comm = _SerialComm()
+        self.mpiRank = comm.Get_rank()
+        self.mpiSize = comm.Get_size()
         self.comm = comm
         self.warning = self.mpiRank == 0
         self.verbose = bool(self.params["verbose"]) and self.warning
@@ -223,8 +237,7 @@ class BLUEProblem(object):
                 if self.verbose:
                     cost_MC = max(C[n][0, 0] / Vs[n] for n in range(self.n_outputs)) * costs[0]
                     print("\nBLUE cost: ", result["cost"], "MC cost: ", cost_MC, "Savings: ", cost_MC / result["cost"])
-        if self.comm is not None:
-            result = self.comm.bcast(result, root=0)
+        result = self.comm.bcast(result, root=0)                        # :526
         self.MOSAP_output = result
         if result is None:
             raise BLUESTError("MOSAP solution failed!")
@@ -239,9 +252,14 @@ class BLUEProblem(object):
 
     def _group_sums(self, ls, N):
         """sum over N joint samples of the models `ls`, per output: [n_outputs][len(ls)] (what bluest/blue_fn.py returns first).
-        Host Python around the user's model -- sampling is not part of the accelerated path."""
+        Host Python around the user's model -- sampling is not part of the accelerated path.  With an MPI communicator of
+        several ranks the N samples are split as the reference splits them (blue_fn.py:107-111: N // size each, the first
+        N % size ranks one more) and the sums are all-reduced (:178-182), so every rank returns the sums of all N."""
+        comm = self.get_comm()
+        size, rank = comm.Get_size(), comm.Get_rank()
+        mine = int(N) // size + (1 if rank < int(N) % size else 0)
         sums = [[0 for _ in ls] for _ in range(self.n_outputs)]
-        for _ in range(int(N)):
+        for _ in range(mine):
             while True:
                 values = self.evaluate(ls, self.sampler(ls))
                 if all(np.all(np.isfinite(v)) for out in values for v in out):
@@ -249,6 +267,10 @@ class BLUEProblem(object):
             for n in range(self.n_outputs):
                 for i in range(len(ls)):
                     sums[n][i] = sums[n][i] + values[n][i]
+        if size > 1:
+            for n in range(self.n_outputs):
+                for i in range(len(ls)):
+                    sums[n][i] = comm.allreduce(sums[n][i])            # default op of mpi4py's allreduce is SUM
         return sums
 
     def solve(self, K=4, budget=None, eps=None, groups=None, multi_groups=None, solver=None, verbose=True, continuous_relaxation=False,
@@ -268,7 +290,12 @@ class BLUEProblem(object):
             got = self._group_sums(ls, count) if count > 0 else [[0] * len(ls)] * self.n_outputs
             for n in range(self.n_outputs):
                 sums[n].append(got[n])
-        mus, Vs = self.MOSAP.compute_BLUE_estimators(sums, out["samples"])
+        if self.mpiRank == 0:                                           # only rank 0 owns a MOSAP (:565-571)
+            mus, Vs = self.MOSAP.compute_BLUE_estimators(sums, out["samples"])
+        else:
+            mus, Vs = None, None
+        mus = self.comm.bcast(mus, root=0)
+        Vs = self.comm.bcast(Vs, root=0)
         return mus, np.sqrt(Vs), out["cost"]
 
     # ---- refused ----------------------------------------------------------------------------------------------------------------

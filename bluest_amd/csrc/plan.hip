@@ -451,9 +451,13 @@ __global__ void k_combine_grad(const double *__restrict__ grad, int64_t grad_str
 // Blocks are only recycled after a device synchronisation (plan_release), so no kernel of the previous owner is still running.
 #include <map>
 #include <unordered_map>
+// Blocks belong to the DEVICE they were allocated on: the cache is keyed by (device, size) and a block is only ever handed to a
+// request made with the same current device (Plan(device=...) is a public argument; a block of cuda:0 inside a plan of cuda:1
+// would be a memory fault, not an error code).
+struct BlockInfo { size_t size; int device; };
 static std::mutex g_cache_mutex;
-static std::multimap<size_t, void *> g_cache;              // free blocks by size
-static std::unordered_map<void *, size_t> g_block_size;    // every block handed out or cached
+static std::multimap<std::pair<int, size_t>, void *> g_cache;   // free blocks by (device, size)
+static std::unordered_map<void *, BlockInfo> g_block_info;      // every block handed out or cached
 static size_t g_cache_bytes = 0;
 static const size_t CACHE_CAP = 3ull << 30;
 
@@ -465,52 +469,72 @@ static hipError_t pool_alloc(void **p, size_t bytes)
         while (cls < want) cls <<= 1;
         want = cls;
     }
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
     {
         std::lock_guard<std::mutex> lock(g_cache_mutex);
-        auto it = g_cache.lower_bound(want);
-        if (it != g_cache.end() && it->first <= 2 * want + (1u << 20)) {
+        auto it = g_cache.lower_bound(std::make_pair(dev, want));
+        if (it != g_cache.end() && it->first.first == dev && it->first.second <= 2 * want + (1u << 20)) {
             *p = it->second;
-            g_cache_bytes -= it->first;
+            g_cache_bytes -= it->first.second;
             g_cache.erase(it);
             return hipSuccess;
         }
     }
-    hipError_t e = hipMalloc(p, want);
-    if (e != hipSuccess) {       // out of memory: give the cached blocks back and try once more
+    e = hipMalloc(p, want);
+    if (e != hipSuccess) {       // out of memory: give this device's cached blocks back and try once more
         (void)hipGetLastError();
         std::vector<void *> drop;
         {
             std::lock_guard<std::mutex> lock(g_cache_mutex);
-            for (auto &kv : g_cache) { drop.push_back(kv.second); g_block_size.erase(kv.second); }
-            g_cache.clear();
-            g_cache_bytes = 0;
+            for (auto it = g_cache.begin(); it != g_cache.end();) {
+                if (it->first.first != dev) { ++it; continue; }
+                drop.push_back(it->second);
+                g_cache_bytes -= it->first.second;
+                g_block_info.erase(it->second);
+                it = g_cache.erase(it);
+            }
         }
         for (void *q : drop) (void)hipFree(q);
         e = hipMalloc(p, want);
     }
     if (e == hipSuccess) {
         std::lock_guard<std::mutex> lock(g_cache_mutex);
-        g_block_size[*p] = want;
+        g_block_info[*p] = BlockInfo{want, dev};
     }
     return e;
 }
-static hipError_t pool_free(void *p)
+// recycle = false: the block is handed back to the runtime instead of the cache (error paths: nothing that a faulted or
+// half-finished sequence touched is given to the next plan)
+static hipError_t pool_free(void *p, bool recycle = true)
 {
-    size_t sz = 0;
     {
         std::lock_guard<std::mutex> lock(g_cache_mutex);
-        auto it = g_block_size.find(p);
-        if (it == g_block_size.end()) return hipFree(p);
-        sz = it->second;
-        if (g_cache_bytes + sz <= CACHE_CAP) {
-            g_cache.emplace(sz, p);
-            g_cache_bytes += sz;
+        auto it = g_block_info.find(p);
+        if (it == g_block_info.end()) return hipFree(p);
+        const BlockInfo bi = it->second;
+        if (recycle && g_cache_bytes + bi.size <= CACHE_CAP) {
+            g_cache.emplace(std::make_pair(bi.device, bi.size), p);
+            g_cache_bytes += bi.size;
             return hipSuccess;
         }
-        g_block_size.erase(it);
+        g_block_info.erase(it);
     }
     return hipFree(p);
 }
+
+// current device for the lifetime of the object (a plan's memory and kernels live on plan->device, whatever device is current
+// in the thread that happens to drop or use it)
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceScope(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev && dev >= 0) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+};
 
 static void plan_free_device(bluest_plan_s *p)
 {
@@ -534,6 +558,7 @@ extern "C" int bluest_plan_create(bluest_plan_t *plan, int n_models, int64_t L_g
     bluest_plan_s *p = new bluest_plan_s();
     p->N = n_models;
     p->L = L_global;
+    if (hipGetDevice(&p->device) != hipSuccess) { delete p; return fail(BLUEST_ERR_HIP, "hipGetDevice failed"); }
     *plan = p;
     return BLUEST_OK;
 }
@@ -548,6 +573,7 @@ static std::vector<bluest_plan_s *> g_deferred;
 
 static void plan_release(bluest_plan_s *p)
 {
+    DeviceScope scope(p->device);       // the caller may be on another device (a destructor runs wherever the last reference dies)
     (void)hipDeviceSynchronize();       // the blocks go back to the cache: nothing of this plan may still be running
     plan_free_device(p);
     delete p;
@@ -1143,6 +1169,7 @@ extern "C" int bluest_plan_restrict(bluest_plan_t parent, const int64_t *keep, i
     if (!parent->finalized) return fail(BLUEST_ERR_STATE, "parent plan not finalized");
     if (n_keep <= 0 || n_keep > parent->L) return fail(BLUEST_ERR_ARG, "n_keep=%lld out of range", (long long)n_keep);
     PhaseTimer timer("plan_restrict");
+    DeviceScope scope(parent->device);                   // the sub-plan lives where its parent's inverses are
     std::vector<int32_t> pos((size_t)parent->L, -1);
     for (int64_t i = 0; i < n_keep; i++) {
         if (keep[i] < 0 || keep[i] >= parent->L || (i > 0 && keep[i] <= keep[i - 1]))
@@ -1209,7 +1236,7 @@ extern "C" int bluest_plan_restrict(bluest_plan_t parent, const int64_t *keep, i
         sub->outs.push_back(std::move(nd));
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();     // the descriptors are released below
-    (void)pool_free(d);
+    (void)pool_free(d, e == hipSuccess);                 // after a HIP error the block goes back to the runtime, not to the cache
     if (e != hipSuccess) { bluest_plan_destroy(sub); HIP_TRY(e); }
     timer.lap("gather inverses (device)");
     rc = bluest_plan_finalize(sub, max_candidates);

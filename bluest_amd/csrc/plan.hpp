@@ -25,6 +25,7 @@ struct OutputDesc {
 };
 
 struct bluest_plan_s {
+    int device = -1;      // HIP device the plan's memory lives on (current device at bluest_plan_create)
     int N = 0;
     int64_t L = 0;
     std::vector<OutputDesc> outs;

@@ -1027,14 +1027,16 @@ static int simplex_impl(const double *x_dev, const double *g_dev, double lambda,
     if (ws && L > 4096) {   // long vector: streaming parts on many CUs
         const int nb = (int)((L + 1023) / 1024);
         {   // single launch with grid barriers while (r, s) of the whole vector fit the registers of <= #CU workgroups
-            static int ncu = 0;
-            if (!ncu) {
-                int dev = 0;
+            static int ncu_of[64] = {0};          // compute units per device (index = HIP device id)
+            int dev = 0;
+            HIP_TRY(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 64) return fail(BLUEST_ERR_ARG, "device id %d out of range", dev);
+            if (!ncu_of[dev]) {
                 hipDeviceProp_t prop;
-                HIP_TRY(hipGetDevice(&dev));
                 HIP_TRY(hipGetDeviceProperties(&prop, dev));
-                ncu = prop.multiProcessorCount;
+                ncu_of[dev] = prop.multiProcessorCount;
             }
+            const int ncu = ncu_of[dev];
             static int maxp = getenv("BLUEST_PROJ_MAXP") ? atoi(getenv("BLUEST_PROJ_MAXP")) : (int)FusedProj::MAXP;   // timing experiments
             static int bracket = getenv("BLUEST_PROJ_NO_BRACKET") ? 0 : 1;   // timing experiments
             static int maxb = getenv("BLUEST_PROJ_MAXB") ? atoi(getenv("BLUEST_PROJ_MAXB")) : 64;   // 64 measured best at L = 245505 (61 -> 42 us)

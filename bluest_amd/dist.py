@@ -111,34 +111,55 @@ class PeerExchange(object):
             pass
 
     @staticmethod
-    def create(max_doubles, device, group=None, rounds=8):
+    def create(max_doubles, device, group=None, rounds=8, _factory=None):
+        """collective.  The sequence of collectives is the same on every rank whatever fails where: (1) construction (its
+        all_gather of the handles is inside), (2) ONE all-reduce(MIN) agreeing that every rank constructed, (3) -- only if all
+        did -- `rounds` self-test rounds, each with the group's all_reduce of the SAME element count on every rank and no early
+        exit, (4) ONE all-reduce(MIN) of the local verdicts.  A failure on one rank alone (hipIpcOpenMemHandle, a mailbox
+        time-out) therefore ends with `None` on ALL ranks instead of mismatched collectives.
+        _factory (tests): callable(max_doubles, device, group) -> exchange object, to inject one-sided failures."""
         import sys
-        ok, why, ex = 1, "", None
-        try:
-            ex = PeerExchange(max_doubles, device, group=group)
-            rng = np.random.RandomState(99 + ex.rank)
-            for r in range(rounds):                               # self-test on THIS hardware against the group's all_reduce
-                n = max_doubles if r % 2 == 0 else max(1, max_doubles // 3)
-                a = torch.from_numpy(rng.randn(n) * 10.0 ** rng.randint(-3, 4)).to(ex.device)
-                b = a.clone()
-                ex.all_reduce(a)
-                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
-                torch.cuda.synchronize(ex.device)
-                if ex.timed_out() or not bool(torch.isfinite(a).all()) or float((a - b).abs().max()) > 1e-12 * float(b.abs().max() + 1e-300):
-                    ok, why = 0, "self-test round %d disagrees with all_reduce" % r
-                    break
-        except Exception as err:
-            ok, why = 0, "%s: %s" % (type(err).__name__, err)
-        # every rank must take the same decision
-        flag = torch.tensor([float(ok)], dtype=torch.float64, device=torch.device(device) if dist.get_backend(group) == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        if float(flag[0]) < 1.0:
+        on_device = dist.get_backend(group) == "nccl"
+
+        def agree(ok):
+            flag = torch.tensor([float(ok)], dtype=torch.float64, device=torch.device(device) if on_device else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            return float(flag[0]) >= 1.0
+
+        def give_up(ex, why):
             if why:
                 sys.stderr.write("bluest_amd.dist: peer-write exchange unavailable on rank %d (%s); using the group's all_reduce\n"
                                  % (dist.get_rank(group), why))
             if ex is not None:
                 ex.close()
             return None
+
+        ok, why, ex = 1, "", None
+        try:
+            ex = (_factory or PeerExchange)(max_doubles, device, group=group)
+        except Exception as err:
+            ok, why = 0, "%s: %s" % (type(err).__name__, err)
+        if not agree(ok):                                          # (2) somebody could not even set up its mailboxes
+            return give_up(ex, why or "another rank could not set up its mailboxes")
+        rng = np.random.RandomState(99 + dist.get_rank(group))
+        buf_dev = torch.device(device) if on_device or ex.device.type == "cuda" else torch.device("cpu")
+        for r in range(rounds):                                    # (3) self-test on THIS hardware against the group's all_reduce
+            n = max_doubles if r % 2 == 0 else max(1, max_doubles // 3)
+            a = torch.from_numpy(rng.randn(n) * 10.0 ** rng.randint(-3, 4)).to(buf_dev)
+            b = a.clone()
+            try:
+                if ok:
+                    ex.all_reduce(a)
+            except Exception as err:
+                ok, why = 0, "%s: %s" % (type(err).__name__, err)
+            dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)   # unconditional: same op and count on every rank
+            if ok:
+                if buf_dev.type == "cuda":
+                    torch.cuda.synchronize(buf_dev)
+                if ex.timed_out() or not bool(torch.isfinite(a).all()) or float((a - b).abs().max()) > 1e-12 * float(b.abs().max() + 1e-300):
+                    ok, why = 0, "self-test round %d disagrees with all_reduce" % r
+        if not agree(ok):                                          # (4)
+            return give_up(ex, why)
         return ex
 
 

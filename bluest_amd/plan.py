@@ -167,7 +167,7 @@ class Plan(object):
     def __del__(self):
         try:
             if getattr(self, "_h", None):
-                self.lib.bluest_plan_destroy(self._h)
+                self.lib.bluest_plan_destroy(self._h)      # switches to the plan's own device for the release (DeviceScope)
                 self._h = None
         except Exception:
             pass

@@ -170,3 +170,83 @@ def test_shard_partition_properties():
     cuts = shard_bounds(sizes, 3)
     owned = np.concatenate([shard_output(outs[2], sizes, a, b)["mapping"] for a, b in zip(cuts, cuts[1:])])
     assert sorted(owned.tolist()) == sorted(outs[2]["mapping"].tolist())
+
+
+class _FakeExchange(object):
+    """stand-in for dist.PeerExchange on CPU tensors: all_reduce through the group itself, with failures injected on ONE rank"""
+
+    def __init__(self, max_doubles, device, group=None, fail=None):
+        self.rank, self.device, self.fail, self.calls, self.closed = dist.get_rank(group), torch.device("cpu"), fail, 0, False
+        self.group = group
+        if fail == ("construct", self.rank):
+            raise RuntimeError("hipIpcOpenMemHandle: invalid argument (injected)")
+
+    def all_reduce(self, t):
+        self.calls += 1
+        if self.fail == ("raise", self.rank) and self.calls == 2:
+            raise RuntimeError("injected launch failure")
+        if self.fail == ("corrupt", self.rank) and self.calls == 3:
+            t += 1.0                      # this rank alone disagrees with the reference all_reduce
+            return t
+        # a correct exchange that does NOT use the group (the real one writes peer memory): every rank can compute the sum
+        # because the self-test vectors are seeded
+        tot = torch.zeros_like(t)
+        for r in range(dist.get_world_size(self.group)):
+            tot += _nth_selftest_vector(r, self.calls - 1, self.max_doubles)
+        t.copy_(tot)
+        return t
+
+    def timed_out(self):
+        return self.fail == ("timeout", self.rank) and self.calls >= 4
+
+    def close(self):
+        self.closed = True
+
+
+def _nth_selftest_vector(rank, r_index, max_doubles):
+    """the vector PeerExchange.create draws on `rank` in self-test round r_index (same generator, same order)"""
+    rng = np.random.RandomState(99 + rank)
+    for r in range(r_index + 1):
+        n = max_doubles if r % 2 == 0 else max(1, max_doubles // 3)
+        a = rng.randn(n) * 10.0 ** rng.randint(-3, 4)
+    return torch.from_numpy(a)
+
+
+def exchange_worker(rank, world, port, ret):
+    from bluest_amd.dist import PeerExchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = {}
+        for fail in (None, ("construct", 1), ("raise", 0), ("corrupt", 1), ("timeout", 0)):
+            made = []
+
+            def factory(max_doubles, device, group=None, fail=fail):
+                ex = _FakeExchange(max_doubles, device, group=group, fail=fail)
+                ex.max_doubles = max_doubles
+                made.append(ex)
+                return ex
+            ex = PeerExchange.create(30, "cpu", rounds=6, _factory=factory)
+            # the group is still usable and in step after every scenario: a plain collective gives the right answer
+            t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+            dist.all_reduce(t)
+            out[str(fail)] = (ex is not None, float(t[0]), [e.closed for e in made])
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_exchange_create_survives_one_sided_failures():
+    """a rank whose constructor raises, or whose self-test fails alone, must not leave the others inside collectives of
+    a different shape.  Every scenario ends with the same decision on both ranks and a group that still works."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(exchange_worker, args=(world, free_port(), ret), nprocs=world, join=True)
+    for fail in ("None", "('construct', 1)", "('raise', 0)", "('corrupt', 1)", "('timeout', 0)"):
+        a, b = ret[0][fail], ret[1][fail]
+        assert a[0] == b[0] == (fail == "None"), (fail, a, b)
+        assert a[1] == b[1] == 3.0
+        if fail != "None":
+            assert all(a[2]) and all(b[2])          # whatever was constructed has been closed on both ranks

@@ -136,3 +136,49 @@ assert not bad, bad
 '''
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=__import__("os").path.dirname(__import__("os").path.dirname(__file__)), timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_blueproblem_mpi_semantics_without_mpi():
+    """with a communicator of several ranks only rank 0 owns a MOSAP; the other ranks must get the estimators through
+    bcast (bluest/blue_models.py:565-571), the samples are split over the ranks and the sums all-reduced (blue_fn.py:107-111,
+    :178-182); without a communicator get_comm() is a one-rank stand-in"""
+    from bluest_amd.blue_models import BLUEProblem
+
+    class FakeComm(object):
+        def __init__(self, rank, size, root_values=None):
+            self.rank, self.size, self.root_values, self.reduced = rank, size, list(root_values or []), []
+        def Get_rank(self): return self.rank
+        def Get_size(self): return self.size
+        def bcast(self, obj, root=0):
+            return obj if self.rank == root else self.root_values.pop(0)
+        def allreduce(self, obj, op=None):
+            self.reduced.append(obj)
+            return obj * self.size          # pretend every rank contributed the same
+
+    class P(BLUEProblem):
+        calls = 0
+        def sampler(self, ls, N=1): return [0.5 for _ in ls]
+        def evaluate(self, ls, samples):
+            P.calls += 1
+            return [[1.0 for _ in ls] for _ in range(self.n_outputs)]
+
+    C = np.eye(3) + 0.5
+    serial = P(3, C=C, costs=np.array([4.0, 2.0, 1.0]), verbose=False)
+    assert serial.get_comm().Get_rank() == 0 and serial.get_comm().Get_size() == 1 and serial.get_comm().bcast(7) == 7
+    assert serial._group_sums([0, 2], 5) == [[5.0, 5.0]]
+    # 3 ranks, 7 samples: 3 + 2 + 2
+    counts = []
+    for r in range(3):
+        P.calls = 0
+        p = P(3, C=C, costs=np.array([4.0, 2.0, 1.0]), verbose=False, comm=FakeComm(r, 3))
+        sums = p._group_sums([0, 1], 7)
+        counts.append(P.calls)
+        assert sums == [[3.0 * P.calls, 3.0 * P.calls]] and len(p.comm.reduced) == 2
+    assert counts == [3, 2, 2]
+    # a non-root rank has no MOSAP: solve() takes the estimators from the broadcast
+    comm = FakeComm(1, 2, root_values=[[1.25], np.array([4.0])])
+    p = P(3, C=C, costs=np.array([4.0, 2.0, 1.0]), verbose=False, comm=comm)
+    p.MOSAP_output = {"budget": 10.0, "eps": None, "samples": np.array([2.0, 0.0]), "flattened_groups": [[0], [1]],
+                      "variances": [4.0], "cost": 8.0}
+    mus, errs, cost = p.solve(budget=10.0)
+    assert p.MOSAP is None and mus == [1.25] and errs[0] == 2.0 and cost == 8.0

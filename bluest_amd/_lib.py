@@ -49,6 +49,7 @@ SIGNATURES = {
     "bluest_plan_phi_chunks": [c_vp, c_vp, c_int, c_i64, c_vp],
     "bluest_plan_phi": [c_vp, c_vp, c_int, c_i64, c_vp, c_vp],
     "bluest_plan_solve": [c_vp, c_vp, c_int, c_f64, c_vp, c_vp, c_vp, c_vp],
+    "bluest_plan_solve_pinv": [c_vp, c_vp, c_int, c_f64, c_vp, c_vp, c_vp, c_vp],
     "bluest_plan_grad": [c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_vp],
     "bluest_plan_eval": [c_vp, c_vp, c_int, c_i64, c_f64, c_vp, c_vp, c_i64, c_vp, c_vp],
     "bluest_plan_combine_grad": [c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_vp, c_i64, c_vp],

@@ -258,6 +258,99 @@ __global__ __launch_bounds__(64) void k_solve_from_record(int N, int n_out, cons
     solve_wave<NT>(lds, N, delta, s1, s2, big, (want_v & 1) != 0, var + e, v + e * N, status + e, lane);
 }
 
+// Rare path (bluest_plan_solve_pinv): what the reference's variance_GH returns when the restricted Phi is rank-deficient --
+// numpy pinv, i.e. eigenvalues not larger than 1e-15 * max|lambda| dropped (misc.py:487,490).  One wavefront per (candidate,
+// output), lane r = row r; cyclic Jacobi exactly as sym_pinv_jacobi (mirrors.hip) does it per group, with the matrix and the
+// eigenvectors in LDS because the size is a run-time value here.  Models outside the index set keep zero rows / columns: their
+// eigenvalues are zero and drop out, so the pseudo-inverse of the padded matrix is the padded pseudo-inverse.
+__device__ __forceinline__ void jacobi_pinv_lds(double *A, double *Q, int N, int LD, int lane)
+{
+    for (int sweep = 0; sweep < 60; sweep++) {
+        int rotated = 0;
+        for (int p = 0; p < N - 1; p++)
+            for (int q = p + 1; q < N; q++) {
+                const double apq = A[p * LD + q], app = A[p * LD + p], aqq = A[q * LD + q];      // same address in every lane
+                if (!(fabs(apq) > 1.0e-18 * sqrt(fabs(app * aqq)))) continue;                    // uniform (also skips zeros / NaN)
+                rotated = 1;
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                if (lane < N) {
+                    const double arp = A[lane * LD + p], arq = A[lane * LD + q];
+                    A[lane * LD + p] = c * arp - sn * arq;
+                    A[lane * LD + q] = sn * arp + c * arq;
+                    const double vrp = Q[lane * LD + p], vrq = Q[lane * LD + q];
+                    Q[lane * LD + p] = c * vrp - sn * vrq;
+                    Q[lane * LD + q] = sn * vrp + c * vrq;
+                }
+                wave_lds_sync();
+                if (lane < N) {
+                    const double apr = A[p * LD + lane], aqr = A[q * LD + lane];
+                    A[p * LD + lane] = c * apr - sn * aqr;
+                    A[q * LD + lane] = sn * apr + c * aqr;
+                }
+                wave_lds_sync();
+            }
+        if (!rotated) break;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_pinv_from_record(int N, int n_out, const double *__restrict__ rec, double delta,
+                                                         double *__restrict__ var, double *__restrict__ v,
+                                                         int32_t *__restrict__ status)
+{
+    extern __shared__ double pinv_sm[];
+    const int LD = N + 1;
+    double *A = pinv_sm, *Q = pinv_sm + N * LD;
+    const int o = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
+    const int reclen = N * N + 2 * N + 1;
+    const double *r = rec + ((int64_t)c * n_out + o) * reclen;
+    const int64_t e = (int64_t)c * n_out + o;
+    const bool s1 = lane < N && r[N * N + lane] > 0.0;
+    const bool s2 = lane < N && r[N * N + N + lane] > 0.0;
+    const bool big = r[N * N + 2 * N] > 0.0;
+    const unsigned long long mask1 = __ballot(s1);
+    const unsigned long long mask2 = (delta != 0.0) ? __ballot(lane < N) : __ballot(s2);
+    int st = BLUEST_EVAL_OK;
+    double V = 0.0, vmine = 0.0;
+    if (!big) { st = BLUEST_EVAL_INF; V = INFINITY; }
+    else if (mask1 == 0ull) { st = BLUEST_EVAL_NO_MODEL0; V = NAN; }
+    else {
+        if (!(mask1 & 1ull)) st = BLUEST_EVAL_NO_MODEL0;
+        const int npass = (mask1 == mask2) ? 1 : 2;
+        for (int pass = 0; pass < npass; pass++) {
+            const unsigned long long mask = pass == 0 ? mask1 : mask2;
+            if (lane < N)
+                for (int j = 0; j < N; j++) {
+                    const bool in = ((mask >> lane) & 1ull) && ((mask >> j) & 1ull);
+                    A[lane * LD + j] = in ? 0.5 * (r[lane * N + j] + r[j * N + lane]) + (lane == j ? delta : 0.0) : 0.0;
+                    Q[lane * LD + j] = lane == j ? 1.0 : 0.0;
+                }
+            wave_lds_sync();
+            jacobi_pinv_lds(A, Q, N, LD, lane);
+            const double w = lane < N ? A[lane * LD + lane] : 0.0;
+            const double cut = 1.0e-15 * wave_max(fabs(w));
+            if (lane < N) A[lane * LD + lane] = fabs(w) > cut ? 1.0 / w : 0.0;        // the diagonal now holds 1/lambda or 0
+            wave_lds_sync();
+            const int t = __ffsll((long long)mask1) - 1;       // first row of the restricted matrix (model 0 unless unsampled)
+            if (pass == 0) {
+                double acc = 0.0;
+                for (int ee = 0; ee < N; ee++) acc += Q[t * LD + ee] * A[ee * LD + ee] * Q[t * LD + ee];
+                V = acc;
+            }
+            if (pass == npass - 1) {                           // row 0 of pinv(Phi): zero when model 0 is outside the support
+                double acc = 0.0;
+                if (lane < N && (mask2 & 1ull))
+                    for (int ee = 0; ee < N; ee++) acc += Q[0 * LD + ee] * A[ee * LD + ee] * Q[lane * LD + ee];
+                vmine = acc;
+            }
+            wave_lds_sync();
+        }
+    }
+    if (lane < N) v[e * N + lane] = vmine;
+    if (lane == 0) { var[e] = V; status[e] = st; }
+}
+
 // KU = largest group size with a fully unrolled register path in this instantiation (the host picks the smallest
 // KU covering the plan, so the common small-k plans keep a small register footprint)
 template <int KU>
@@ -1349,6 +1442,18 @@ extern "C" int bluest_plan_solve(bluest_plan_t plan, const double *phi_dev, int 
                                    phi_dev, delta, 1, var_dev, v_dev, status_dev)
     NT_DISPATCH(plan->N, LSR);
 #undef LSR
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_solve_pinv(bluest_plan_t plan, const double *phi_dev, int n_cand, double delta, double *var_dev,
+                                      double *v_dev, int32_t *status_dev, void *stream)
+{
+    int rc = plan_ready(plan, n_cand); if (rc) return rc;
+    if (!phi_dev || !var_dev || !v_dev || !status_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    const int n_out = (int)plan->outs.size(), N = plan->N;
+    hipLaunchKernelGGL(k_pinv_from_record, dim3(n_out, n_cand), dim3(64), (size_t)2 * N * (N + 1) * sizeof(double),
+                       (hipStream_t)stream, N, n_out, phi_dev, delta, var_dev, v_dev, status_dev);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }

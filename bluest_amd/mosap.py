@@ -248,6 +248,16 @@ class MOSAP(object):
         var = var[0].cpu().numpy()
         status = status[0].cpu().numpy()
         g_all = grad[0].cpu().numpy() if host else grad[0]
+        if (status == EVAL_SINGULAR).any():
+            # rank-deficient restricted Phi of some output: the reference's pinv semantics (misc.py:487,490) for those outputs
+            var_p, grad_p, status_p = self.plan.eval_pinv(m, delta=delta)
+            var_p, status_p = var_p[0].cpu().numpy(), status_p[0].cpu().numpy()
+            g_p = grad_p[0].cpu().numpy() if host else grad_p[0]
+            g_all = g_all.copy() if host else g_all.clone()
+            for n in np.flatnonzero(status == EVAL_SINGULAR):
+                off, Ln = self.plan.grad_off[n], len(self.mappings[n])
+                g_all[off:off + Ln] = g_p[off:off + Ln]
+                var[n], status[n] = var_p[n], status_p[n]
         variances, gradients, hessians = [], [], []
         for n in range(self.n_outputs):
             off, Ln = self.plan.grad_off[n], len(self.mappings[n])
@@ -256,8 +266,6 @@ class MOSAP(object):
                 variances.append(np.inf)
                 hessians.append(None)
                 continue
-            if status[n] == EVAL_SINGULAR:
-                status_to_python(int(status[n]), "variance_GH[output %d]" % n)
             variances.append(float(var[n]))
             if nohess:
                 hessians.append(None)

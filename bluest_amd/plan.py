@@ -227,6 +227,19 @@ class Plan(object):
                                              status.data_ptr(), _stream()))
         return var, v, status
 
+    def eval_pinv(self, m, delta=0.0):
+        """the evaluation for a rank-deficient restricted Phi (rare; the caller saw EVAL_SINGULAR): V and grad V as the reference's
+        variance_GH computes them through numpy's pinv (misc.py:487,490).  Returns (var, grad, status) like eval()."""
+        rec = self.phi(m)
+        nc = rec.shape[0]
+        var = torch.empty((nc, self.n_out), dtype=torch.float64, device=self.device)
+        v = torch.empty((nc, self.n_out, self.N), dtype=torch.float64, device=self.device)
+        status = torch.empty((nc, self.n_out), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.bluest_plan_solve_pinv(self._h, rec.data_ptr(), nc, float(delta), var.data_ptr(), v.data_ptr(),
+                                                  status.data_ptr(), _stream()))
+        return var, self.grad(v, status), status
+
     def solve_grad(self, rec, delta=0.0, out=None):
         """solve + gradient from an (all-reduced) Phi record of ONE candidate in one launch: (var, grad, status)"""
         assert rec.shape[0] == 1

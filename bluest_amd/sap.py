@@ -640,7 +640,10 @@ class SAP(object):
         if st == EVAL_INF:
             return np.inf, g      # the reference returns a 2-tuple here (misc.py:484)
         if st == EVAL_SINGULAR:
-            status_to_python(st, "variance_GH")
+            # rank-deficient restricted Phi: the reference's variance_GH goes through numpy's pinv (misc.py:487,490) and returns a
+            # finite value; so does the Jacobi eigen-pinv path of the plan (rare, a second evaluation)
+            var, grad, status = self.plan.eval_pinv(m, delta=delta)
+            g = grad[0] if isinstance(m, torch.Tensor) else grad[0].cpu().numpy()
         V = float(var[0, 0])
         if nohess:
             return V, g, None

@@ -167,6 +167,14 @@ int bluest_plan_phi_chunks(bluest_plan_t plan, const double *m_dev, int n_cand, 
 int bluest_plan_solve(bluest_plan_t plan, const double *phi_dev, int n_cand, double delta, double *var_dev,
                       double *v_dev, int32_t *status_dev, void *stream);
 
+/* Phase B for a RANK-DEFICIENT restricted Phi (status BLUEST_EVAL_SINGULAR from bluest_plan_solve / _eval): what the
+ * reference's variance_GH returns there -- V = pinv(Phi[idx,idx])[0,0] (bluest/misc.py:490) and v = row 0 of pinv(Phi)
+ * (bluest/misc.py:487) with numpy's cut-off (eigenvalues <= 1e-15 * max|lambda| dropped), by a cyclic Jacobi
+ * eigen-decomposition.  Same arguments as bluest_plan_solve; the status is never BLUEST_EVAL_SINGULAR.  Rare path:
+ * one wavefront per (candidate, output), ~ms. */
+int bluest_plan_solve_pinv(bluest_plan_t plan, const double *phi_dev, int n_cand, double delta, double *var_dev,
+                           double *v_dev, int32_t *status_dev, void *stream);
+
 /* Phase C (a9): grad_o,i = -v[g_i]^T invcov_i v[g_i] for every group of every output (this GPU's shard);
  * grad_dev: n_cand rows of grad_len doubles (row stride grad_stride); +inf where status == BLUEST_EVAL_INF. */
 int bluest_plan_grad(bluest_plan_t plan, const double *v_dev, const int32_t *status_dev, int n_cand,

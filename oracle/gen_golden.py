@@ -262,6 +262,71 @@ def gen_hh(bluest, fname):
     print(fname, out["errors_over_eps"], out["total_cost"])
 
 
+def gen_ns(bluest, fname):
+    """second paper data set: Navier-Stokes, 12 models, 6 outputs, K = 7 (bluest_NS.py:142), covariances
+    with cond up to 1.5e11.  The stored model graphs are complete and SG lists all 12 models for every output, so the groups of
+    `setup_solver(K=7)` (blue_models.py:462-476) are all 3301 subsets of up to 7 models for every output.  Two cases:
+      full    every output uses every group (identity mappings);
+      ragged  every output keeps a seeded ~60 % of the groups of each size (plus the first group of each size): the union /
+              mapping logic of blue_models.py:491-501 and mosap.py:54-67 on real covariances.
+    Allocations: a dense seeded one and a sparse one (40 groups + {0}); outputs of MOSAP.variances / variance_GH."""
+    d = dict(np.load(os.path.join(REF, "examples/paper_examples/navier_stokes/NS_model_data_full.npz")))
+    n = int(d["M"]); n_out = int(d["n_outputs"]); kmax = 7
+    assert np.array_equal(d["SG"], np.tile(np.arange(n), (n_out, 1)))
+    Cs = [d["C%d" % o] for o in range(n_out)]
+    assert all(np.isfinite(C).all() and (C != 0).all() for C in Cs)          # complete graphs: every subset is a clique
+    allg = synth.all_groups(n, kmax)
+    out = {"n": n, "n_out": n_out, "kmax": kmax, "costs": d["costs"], "eps": 1e-3 * np.sqrt(np.array([C[0, 0] for C in Cs]))}   # bluest_NS.py:115
+    for o in range(n_out):
+        out["C%d" % o] = Cs[o]
+    rng = np.random.RandomState(2026)
+    for case in ("full", "ragged"):
+        if case == "full":
+            multi_groups = [[g.copy() for g in allg] for _ in range(n_out)]
+        else:
+            multi_groups = []
+            for o in range(n_out):
+                mg = []
+                for k in range(kmax):
+                    keep = rng.rand(len(allg[k])) < 0.6
+                    keep[0] = True                                  # keeps a group with model 0 for every size
+                    mg.append(allg[k][keep])
+                multi_groups.append(mg)
+        groups = []
+        for k in range(kmax):                                       # union, sorted, as blue_models.py:491-501
+            rows = sorted({tuple(map(int, g)) for o in range(n_out) for g in multi_groups[o][k]})
+            groups.append(np.array(rows, dtype=np.int64).reshape(-1, k + 1))
+        costs = synth.group_costs(groups, d["costs"])
+        multi_costs = [synth.group_costs(mg, d["costs"]) for mg in multi_groups]
+        mos = bluest.MOSAP([C.copy() for C in Cs], kmax, [kmax] * n_out, lists_of(groups),
+                           [lists_of(mg) for mg in multi_groups], costs, multi_costs, verbose=False)
+        L = mos.L
+        m_dense = 10 * rng.rand(L)
+        m_sparse = np.zeros(L)
+        pick = rng.choice(L, 40, replace=False)
+        m_sparse[pick] = 1 + 50 * rng.rand(40)
+        m_sparse[0] = 7.0                                           # group {0}: model 0 of every output is sampled
+        out[case + "_L"] = L
+        out[case + "_group_costs"] = costs
+        for k in range(kmax):
+            out["%s_g_k%d" % (case, k + 1)] = groups[k]
+        for o in range(n_out):
+            out["%s_map%d" % (case, o)] = np.asarray(mos.mappings[o], dtype=np.int64)
+        for tag, m in (("dense", m_dense), ("sparse", m_sparse)):
+            Vs = np.array(mos.variances(m))
+            Vgh, grads, _ = mos.variance_GH(m, nohess=True)
+            out["%s_m_%s" % (case, tag)] = m
+            out["%s_Vs_%s" % (case, tag)] = Vs
+            out["%s_Vgh_%s" % (case, tag)] = np.array(Vgh)
+            for o in range(n_out):
+                out["%s_grad%d_%s_sub" % (case, o, tag)] = grads[o][::7]
+                out["%s_grad%d_%s_norm" % (case, o, tag)] = np.linalg.norm(grads[o])
+        if case == "full":
+            out["cond_phi_dense"] = np.array([np.linalg.cond(mos.SAPS[o].get_phi(m_dense)) for o in range(n_out)])
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, out["full_Vs_dense"], out["ragged_L"], out["cond_phi_dense"])
+
+
 def gen_spg(bluest, spgmod, n, kmax, fname, maxit):
     """reference spg() (spg.py:39-132) driven by the reference's variance / variance_GH callbacks in the scaled
     variable x = cost*m/B, with the build-defined simplex projection.  Records EVERY callback evaluation so the
@@ -405,12 +470,12 @@ def main():
     gen_intproj(bluest, misc, "intproj_known_answers.npz")
     gen_singular(bluest, "singular_phi_known_answer.npz")
     gen_spg_bound(bluest, spgmod, 12, 12, "spg_bound_n12_all.npz", maxit=400)
+    gen_ns(bluest, "ns_paper_known_answer.npz")
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--new-only":       # the fixtures added in round 2, leaving the others untouched
+    if len(sys.argv) > 1 and sys.argv[1] == "--new-only":       # the fixtures added in round 3, leaving the others untouched
         cm_, bluest_, misc_, spgmod_ = import_reference()
-        gen_singular(bluest_, "singular_phi_known_answer.npz")
-        gen_spg_bound(bluest_, spgmod_, 12, 12, "spg_bound_n12_all.npz", maxit=400)
+        gen_ns(bluest_, "ns_paper_known_answer.npz")
     else:
         main()

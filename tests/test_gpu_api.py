@@ -371,6 +371,28 @@ def test_spg_optimum_is_certified_n25_k6(oracle):
     assert gap <= 1e-4, (gap, sap.solver_info)
 
 
+def test_ns_paper_eps_mode_end_to_end_is_certified(oracle):
+    """the Navier-Stokes paper problem as its driver poses it (bluest_NS.py:115,142): setup_solver(K=7, eps=1e-3*sqrt(C_00))
+    on the stored model graphs -> every output meets its tolerance, the most demanding one exactly, and the total cost is
+    within 1e-4 of the oracle's duality bound for min cost s.t. V_o <= eps_o^2"""
+    from bluest_amd import BLUEProblem
+    from conftest import golden
+    G = golden("ns_paper_known_answer.npz")
+    n, n_out, kmax = int(G["n"]), int(G["n_out"]), int(G["kmax"])
+    Cs = [G["C%d" % o] for o in range(n_out)]
+    eps = G["eps"]
+    p = BLUEProblem(n, C=[c.copy() for c in Cs], costs=G["costs"], n_outputs=n_out, verbose=False)
+    out = p.setup_solver(K=kmax, eps=list(eps), continuous_relaxation=True)
+    m = p.MOSAP.samples
+    ratios = np.array(p.MOSAP.variances(m)) / eps ** 2
+    assert ratios.max() <= 1 + 1e-9 and abs(ratios.max() - 1) < 1e-9
+    assert abs(out["total_cost"] / float(m @ p.MOSAP.costs) - 1) < 1e-12
+    groups = synth.all_groups(n, kmax)
+    gap, Vs, _ = _certify(oracle, Cs, kmax, groups, synth.group_costs(groups, G["costs"]), m, eps=eps)
+    assert np.abs(np.array(p.MOSAP.variances(m)) / Vs - 1).max() < 1e-5        # cond(Phi) 1e10
+    assert gap <= 1e-4, (gap, p.MOSAP.solver_info)
+
+
 def test_plan_dropped_during_capture_does_not_invalidate_it():
     """a plan whose last reference disappears while a hipGraph is being captured (reference count, not only the cyclic
     collector) is parked by the library and released after the capture: the capture survives and replays correctly"""

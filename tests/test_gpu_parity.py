@@ -260,12 +260,14 @@ def test_group_sharded_hip_plans_ragged(gpu):
         _check_shards_against_full(torch, n, sizes, outs, mos.plan, mos.mappings, m, (2, 3))
 
 
-def test_singular_phi_is_reported(gpu):
-    """deliberate deviation, quantified by tests/golden/singular_phi_known_answer.npz: on a rank-deficient information matrix
-    (every model touched, two of them perfectly correlated) the reference returns a pinv value from variance_GH (0.0918,
-    misc.py:487,490) and an unrelated number from variance (0.0135, np.linalg.solve on a numerically singular matrix,
-    misc.py:472); the build assembles the same Phi (1e-12, incl. the pseudo-inverses of the singular blocks) and then reports
-    BLUEST_EVAL_SINGULAR -> AssertionError from both (relative pivot test, csrc/solve.hpp)"""
+def test_singular_phi_follows_the_reference_pinv(gpu):
+    """tests/golden/singular_phi_known_answer.npz: a rank-deficient information matrix (every model touched, two of them
+    perfectly correlated).  The reference's variance_GH goes through numpy's pinv (misc.py:487,490) and returns 0.0917511931...
+    and a finite gradient: the build's elimination reports BLUEST_EVAL_SINGULAR (relative pivot test, csrc/solve.hpp) and
+    variance_GH then takes the Jacobi eigen-pinv path (bluest_plan_solve_pinv) -> the same numbers.  variance() is
+    np.linalg.solve on a numerically singular matrix in the reference (misc.py:472: 0.0135, an artefact of LU rounding): not
+    reproducible by construction, it stays an AssertionError here."""
+    from bluest_amd.mosap import MOSAP
     from bluest_amd.sap import SAP
     G = golden("singular_phi_known_answer.npz")
     groups = [G["g_k%d" % k].copy() for k in (1, 2, 3)]
@@ -274,13 +276,44 @@ def test_singular_phi_is_reported(gpu):
     assert rel_err(sap.get_phi(G["m"]), G["PHI"]) < 1e-12
     with pytest.raises(AssertionError):
         sap.variance(G["m"])
-    with pytest.raises(AssertionError):
-        sap.variance_GH(G["m"], nohess=True)
+    Vgh, grad, _ = sap.variance_GH(G["m"], nohess=True)
+    assert abs(Vgh / float(G["Vgh_pinv"]) - 1) < 1e-9 and abs(Vgh - 0.09175119314243015) < 1e-10
+    assert rel_err(grad, G["grad_pinv"]) < 1e-9
+    # through MOSAP (two outputs, the second one regular): only the singular output takes the fallback
+    rng = np.random.RandomState(1)
+    A = rng.randn(5, 10)
+    C2 = A @ A.T / 10
+    gl = [G["g_k%d" % k].copy() for k in (1, 2, 3)]
+    mos = MOSAP([G["C"].copy(), C2], 3, [3, 3], [g.copy() for g in gl], [[g.copy() for g in gl] for _ in range(2)], np.ones(8),
+                [np.ones(8)] * 2, verbose=False)
+    Vs, grads, _ = mos.variance_GH(G["m"], nohess=True)
+    assert abs(Vs[0] / float(G["Vgh_pinv"]) - 1) < 1e-9 and rel_err(grads[0], G["grad_pinv"]) < 1e-9
+    ref2 = SAP(C2, 3, [g.copy() for g in gl], np.ones(8), verbose=False).variance_GH(G["m"], nohess=True)
+    assert abs(Vs[1] / ref2[0] - 1) < 1e-12 and rel_err(grads[1], ref2[1]) < 1e-12
     # with a regularisation the matrix is definite again and the three agree (reference semantics of delta, misc.py:461)
     V = sap.variance(G["m"], delta=1e-3)
     Vgh, grad, _ = sap.variance_GH(G["m"], delta=1e-3, nohess=True)
     PHI = G["PHI"] + 1e-3 * np.eye(5)
     assert abs(V / np.linalg.inv(PHI)[0, 0] - 1) < 1e-11 and abs(Vgh / V - 1) < 1e-12
+
+
+def test_pinv_path_equals_the_elimination_on_regular_matrices(gpu):
+    """bluest_plan_solve_pinv on well-conditioned problems reproduces the elimination path (V, grad V; incl. a dropped model
+    and an unsampled model 0, where V is the first entry of the restricted pseudo-inverse, misc.py:490)"""
+    from bluest_amd.sap import SAP
+    for n, kmax in ((5, 3), (12, 4), (20, 3)):
+        prob = synth.problem(n, kmax, 1)
+        sap = SAP(prob["C"][0], kmax, [g.tolist() for g in prob["groups"]], prob["costs"], verbose=False)
+        ms = [prob["m"][0].copy(), prob["m"][0].copy(), prob["m"][0].copy()]
+        ES = sap.ES
+        ms[1][ES[n - 1] == 1] = 0.0           # the last model drops out
+        ms[2][sap.e == 1] = 0.0               # model 0 unsampled
+        for m in ms:
+            var, grad, status = sap.plan.eval(m)
+            var_p, grad_p, status_p = sap.plan.eval_pinv(m)
+            assert int(status[0, 0]) == int(status_p[0, 0])
+            assert abs(float(var_p[0, 0]) / float(var[0, 0]) - 1) < 1e-9
+            assert rel_err(grad_p[0].cpu().numpy(), grad[0].cpu().numpy()) < 1e-8
 
 
 def test_model0_unsampled(gpu):
@@ -351,6 +384,35 @@ def test_hh_paper_known_answer(gpu):
     eps = np.sqrt(np.array([C[0, 0] for C in Cs])) / 1000
     assert np.allclose(np.sqrt(Vs) / eps, [0.8906, 1.00004, 0.9479, 0.5477, 0.5583], rtol=2e-4)
     assert abs(float(samples @ costs) / 60626.8057 - 1) < 1e-8
+
+
+@pytest.mark.parametrize("case", ["full", "ragged"])
+def test_ns_paper_known_answer(gpu, case):
+    """Navier-Stokes paper data (bluest_NS.py:115-142; 12 models, 6 outputs, K = 7, K_tot = 3301 / 3285 with per-output group
+    subsets): the mappings are the reference's (mosap.py:54-67), V and grad V agree to cond(Phi) * eps (cond up to 1.8e10)"""
+    from bluest_amd.mosap import MOSAP
+    from test_oracle import _ns_case
+    G = golden("ns_paper_known_answer.npz")
+    n_out, kmax = int(G["n_out"]), int(G["kmax"])
+    groups, maps, multi = _ns_case(G, case)
+    Cs = [G["C%d" % o] for o in range(n_out)]
+    costs = synth.group_costs(groups, G["costs"])
+    mos = MOSAP(Cs, kmax, [kmax] * n_out, [g.tolist() for g in groups], [[g.tolist() for g in mg] for mg in multi], costs,
+                [synth.group_costs(mg, G["costs"]) for mg in multi], verbose=False)
+    assert mos.L == int(G["%s_L" % case])
+    for o in range(n_out):
+        assert np.array_equal(mos.mappings[o], maps[o])
+    cond = G["cond_phi_dense"]
+    for tag in ("dense", "sparse"):
+        m = G["%s_m_%s" % (case, tag)]
+        Vs = np.array(mos.variances(m))
+        Vgh, grads, _ = mos.variance_GH(m, nohess=True)
+        for o in range(n_out):
+            tol = max(1e-11, 50 * cond[o] * 2.2e-16)
+            assert abs(Vs[o] / G["%s_Vs_%s" % (case, tag)][o] - 1) < tol, (o, tag)
+            assert abs(Vgh[o] / G["%s_Vgh_%s" % (case, tag)][o] - 1) < tol, (o, tag)
+            assert rel_err(grads[o][::7], G["%s_grad%d_%s_sub" % (case, o, tag)]) < max(1e-5, 10 * tol), (o, tag)
+            assert abs(np.linalg.norm(grads[o]) / float(G["%s_grad%d_%s_norm" % (case, o, tag)]) - 1) < max(1e-5, 10 * tol)
 
 
 @pytest.mark.parametrize("fname", ["spg_traj_n6.npz", "spg_traj_n12_k4.npz"])

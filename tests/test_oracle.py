@@ -155,6 +155,44 @@ def test_hh_paper_known_answer(oracle):
     assert abs(float(G["total_cost"]) - 60626.8057) < 1e-3
 
 
+def _ns_case(G, case):
+    n_out, kmax = int(G["n_out"]), int(G["kmax"])
+    groups = [G["%s_g_k%d" % (case, k)] for k in range(1, kmax + 1)]
+    maps = [G["%s_map%d" % (case, o)] for o in range(n_out)]
+    flat = np.concatenate([np.pad(g, ((0, 0), (0, kmax - g.shape[1])), constant_values=-1) for g in groups])
+    cum = np.cumsum([0] + [len(g) for g in groups])
+    multi = []
+    for o in range(n_out):                       # output o's own group lists, recovered through its mapping
+        rows = flat[maps[o]]
+        multi.append([rows[(maps[o] >= cum[k]) & (maps[o] < cum[k + 1]), :k + 1] for k in range(kmax)])
+    return groups, maps, multi
+
+
+@pytest.mark.parametrize("case", ["full", "ragged"])
+def test_ns_paper_known_answer(oracle, case):
+    """Navier-Stokes paper data (bluest_NS.py:115-142): 12 models, 6 outputs, K = 7, cond(Phi) up to 1.8e10; `ragged` = every
+    output on its own ~60 % of the groups.  The restatement reproduces the reference's mappings exactly and V / grad V to
+    cond * eps."""
+    G = golden("ns_paper_known_answer.npz")
+    n_out, kmax = int(G["n_out"]), int(G["kmax"])
+    groups, maps, multi = _ns_case(G, case)
+    Cs = [G["C%d" % o] for o in range(n_out)]
+    costs = synth.group_costs(groups, G["costs"])
+    assert rel_err(costs, G["%s_group_costs" % case]) < 1e-15
+    mos = oracle.OracleMOSAP(Cs, kmax, [kmax] * n_out, groups, multi, costs, [synth.group_costs(mg, G["costs"]) for mg in multi])
+    assert mos.L == int(G["%s_L" % case])
+    for o in range(n_out):
+        assert np.array_equal(mos.mappings[o], maps[o])
+    for tag in ("dense", "sparse"):
+        m = G["%s_m_%s" % (case, tag)]
+        assert rel_err(mos.variances(m), G["%s_Vs_%s" % (case, tag)]) < 1e-12        # same numpy pinv / solve: exact here
+        Vgh, grads, _ = mos.variance_GH(m, nohess=True)
+        assert rel_err(Vgh, G["%s_Vgh_%s" % (case, tag)]) < 1e-12
+        for o in range(n_out):       # measured <= 1.7e-6 (output 0, cond(Phi) 1.8e10: the reference's gradK_c is -ffast-math)
+            assert rel_err(grads[o][::7], G["%s_grad%d_%s_sub" % (case, o, tag)]) < 1e-5
+            assert abs(np.linalg.norm(grads[o]) / float(G["%s_grad%d_%s_norm" % (case, o, tag)]) - 1) < 1e-5
+
+
 @pytest.mark.parametrize("fname", ["spg_traj_n6.npz", "spg_traj_n12_k4.npz"])
 def test_spg_trajectory(oracle, fname):
     """oracle spg()+callbacks reproduce the reference spg() run call by call (every f evaluated, every |g|)"""

@@ -72,6 +72,11 @@ SIGNATURES = {
     "bluest_xchg_allreduce_sum": [c_vp, c_vp, c_i64, c_vp],
     "bluest_xchg_status": [c_vp, c_i64p, ctypes.POINTER(c_int)],
     "bluest_xchg_destroy": [c_vp],
+    "bluest_master_max_support": [c_vp, ctypes.POINTER(c_int)],
+    "bluest_master_newton": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp, c_f64, c_int, c_vp, c_vp],
+    "bluest_ma_update": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp, c_vp],
+    "bluest_support_point": [c_i64, c_int, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp],
+    "bluest_price": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp],
     "bluest_simplex_workspace_doubles": [c_i64, c_i64p],
     "bluest_simplex_project": [c_vp, c_vp, c_f64, c_f64, c_f64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
 }

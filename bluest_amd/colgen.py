@@ -1,0 +1,220 @@
+"""
+Second-order finish of solver="spg" on the GPU (C-ABI Part 6, csrc/newton.hip): multiplicative phase on all groups, then
+column generation with a Newton master on the support and a certified duality gap from every pricing round.
+
+The reference passes this problem -- min_m max_o V_o(m)/s_o s.t. cost.m = B, m >= 0 -- to third-party NLP solvers together with
+the Hessian of bluest/misc.py:497-503 (bluest/sap.py:387-456, bluest/mosap.py:578-673); none of them is available to this
+build, and a first-order method alone needs ~1300 iterations and leaves a residual of a few 1e-6.
+
+Everything numeric runs in hand-written kernels; the host only moves a few KB per round (the support's values, the
+multipliers, 1024 pricing candidates) and decides which groups enter.  torch is used for buffers and the stream only.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import check
+from .plan import EVAL_OK, _stream
+
+MASTER_OUT = 16            # layout of the master's result record (include/bluest_hip.h, bluest_master_newton)
+N_CAND = 1024              # BLUEST_PRICE_CANDIDATES
+
+
+class _Buffers(object):
+    """ONE device buffer for everything the host reads back per round, so that a round costs one device-to-host copy"""
+
+    def __init__(self, dev, n_out, s_max):
+        self.n_out, self.s_max = n_out, s_max
+        sizes = [("out", MASTER_OUT + n_out), ("xs", s_max), ("mu", n_out), ("var", n_out), ("csup", s_max), ("topv", N_CAND), ("topi", N_CAND)]
+        self.off, tot = {}, 0
+        for name, n in sizes:
+            self.off[name] = (tot, n)
+            tot += n
+        self.buf = torch.from_numpy(np.zeros(tot)).to(dev)
+        self.base = self.buf.data_ptr()
+
+    def ptr(self, name):
+        return self.base + 8 * self.off[name][0]
+
+    def fetch(self):
+        h = self.buf.cpu().numpy()
+        out = {name: h[o:o + n] for name, (o, n) in self.off.items()}
+        out["topi"] = out["topi"].view(np.int64)
+        return out
+
+    def put(self, name, values):
+        o, n = self.off[name]
+        v = np.zeros(n)
+        v[:len(values)] = values
+        self.buf[o:o + n] = torch.from_numpy(v)          # small H2D copy (slice assignment from a CPU tensor: a memcpy)
+
+
+def master_max_support(plan):
+    s = ctypes.c_int(0)
+    with torch.cuda.device(plan.device):
+        check(plan.lib.bluest_master_max_support(plan._h, ctypes.byref(s)))
+    return int(s.value)
+
+
+def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
+    """x (numpy, length L, on the unit simplex) minimising max_o V_o(B x / cost)/s_o, and an info dict with the certified gap.
+    Returns (None, reason) when the master problem does not fit the single-workgroup kernel (the caller falls back)."""
+    prm = prm or {}
+    ma_its = int(prm.get("ma_iterations", 200))
+    ma_p = float(prm.get("ma_p", 32.0))
+    init_mult = int(prm.get("support_init", 3))
+    eps_list = tuple(prm.get("background", (1.0e-3, 1.0e-6)))
+    gap_tol = float(prm.get("gap_tol", 1.0e-7))
+    enter_tol = float(prm.get("enter_tol", 1.0e-8))
+    max_rounds = int(prm.get("max_rounds", 60))
+    newton_maxit = int(prm.get("newton_maxit", 60))
+    lib, dev = plan.lib, plan.device
+    L, N, n_out = plan.L, plan.N, plan.n_out
+    w = np.asarray(costs, dtype=np.float64)
+    s = np.asarray(s, dtype=np.float64)
+    s_max = master_max_support(plan)
+    enter_per = int(prm.get("enter_per_round", N))
+    if s_max < min(L, 2 * N + 2):
+        return None, "master problem does not fit one workgroup (support limit %d)" % s_max
+
+    def to_dev(a, dtype=np.float64):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(dev)
+
+    cc_h = B / w
+    cc, s_d = to_dev(cc_h), to_dev(s)
+    bufs = _Buffers(dev, n_out, s_max)
+    var = torch.empty((1, n_out), dtype=torch.float64, device=dev)
+    grad = torch.empty((1, plan.grad_len), dtype=torch.float64, device=dev)
+    status = torch.empty((1, n_out), dtype=torch.int32, device=dev)
+    info = {"rounds": 0, "newton_it": 0, "master_evals": 0, "full_evals": 0, "ma_iterations": ma_its}
+    with torch.cuda.device(dev):
+        st = _stream()
+        # ---- background: Phi_o(uniform allocation), one Phi pass -----------------------------------------------------
+        u_m = to_dev(cc_h / L)
+        rec = plan.phi(u_m).cpu().numpy()[0]                     # (n_out, N*N + 2N + 1): the sums come first
+        phi_u = np.ascontiguousarray(rec[:, :N * N])
+        info["full_evals"] += 1
+        # ---- phase 1: multiplicative algorithm from the uniform point (or x0) ------------------------------------------------
+        xh = np.full(L, 1.0 / L) if x0 is None else np.maximum(np.asarray(x0, dtype=np.float64), 0.0)
+        xh = xh / xh.sum()
+        if x0 is not None:
+            xh = (1.0 - 1.0e-3) * xh + 1.0e-3 / L                # the multiplicative update cannot leave a zero
+        x_d, m_d = to_dev(xh), to_dev(cc_h * xh)
+        for _ in range(ma_its):
+            check(lib.bluest_plan_eval(plan._h, m_d.data_ptr(), 1, L, 0.0, var.data_ptr(), grad.data_ptr(), plan.grad_len, status.data_ptr(), st))
+            check(lib.bluest_ma_update(plan._h, var.data_ptr(), status.data_ptr(), grad.data_ptr(), s_d.data_ptr(), cc.data_ptr(), ma_p,
+                                       x_d.data_ptr(), m_d.data_ptr(), st))
+        info["full_evals"] += ma_its
+        xh = x_d.cpu().numpy()
+        if not np.isfinite(xh).all() or xh.sum() <= 0.0:
+            return None, "multiplicative phase produced a non-finite iterate"
+        xh = np.maximum(xh, 0.0) / xh.sum()
+        # ---- initial support: the largest entries ---------------------------------------------------------------------------
+        S0 = min(L, s_max, max(init_mult * N, N + 1))
+        keep = np.sort(np.argsort(-xh, kind="stable")[:S0])
+        xs = xh[keep] / xh[keep].sum()
+        mu = np.full(n_out, 1.0 / n_out)
+        best_lb, F_last, gap = 0.0, np.inf, np.inf
+        x_full = None
+        sup_d = torch.empty(s_max, dtype=torch.int64, device=dev)
+        for stage, eps in enumerate(eps_list):
+            bg_d = to_dev(eps * phi_u)
+            mtol = 1.0e-2
+            for rnd in range(max_rounds):
+                S = len(keep)
+                bufs.put("xs", xs)
+                bufs.put("mu", mu)
+                keep_h = np.ascontiguousarray(keep, dtype=np.int64)
+                cc_keep = np.ascontiguousarray(cc_h[keep])
+                check(lib.bluest_master_newton(plan._h, S, keep_h.ctypes.data, cc_keep.ctypes.data, s_d.data_ptr(), bg_d.data_ptr(), float(eps),
+                                               bufs.ptr("xs"), bufs.ptr("mu"), float(mtol), newton_maxit, bufs.ptr("out"), st))
+                sup_d[:S] = torch.from_numpy(keep_h)
+                check(lib.bluest_support_point(L, S, sup_d.data_ptr(), bufs.ptr("xs"), cc.data_ptr(), float(eps), m_d.data_ptr(), st))
+                check(lib.bluest_plan_eval(plan._h, m_d.data_ptr(), 1, L, 0.0, bufs.ptr("var"), grad.data_ptr(), plan.grad_len, status.data_ptr(), st))
+                check(lib.bluest_price(plan._h, grad.data_ptr(), bufs.ptr("mu"), s_d.data_ptr(), cc.data_ptr(), S, sup_d.data_ptr(),
+                                       bufs.ptr("csup"), bufs.ptr("topv"), bufs.ptr("topi"), st))
+                h = bufs.fetch()                                  # the round's only synchronisation
+                out = h["out"]
+                info["rounds"] += 1
+                info["newton_it"] += int(out[4])
+                info["master_evals"] += int(out[5])
+                info["full_evals"] += 1
+                if int(out[7]) == 2 or not np.isfinite(out[0]):
+                    return None, "master start not evaluable"
+                xs, mu = h["xs"][:S].copy(), h["mu"].copy()
+                F = float(out[0])
+                pos = xs > 0.0
+                # certified bound (valid for ANY multipliers / vectors: weak duality), budget 1 in the scaled variable
+                a = mu / s
+                A = 2.0 * float(a @ h["var"])
+                cmax = max(float(h["topv"].max()), float(h["csup"][:S].max()))
+                lb = A * A / (4.0 * cmax) if cmax > 0.0 else 0.0
+                best_lb = max(best_lb, lb)
+                gap = 1.0 - best_lb / F
+                level = float(h["csup"][:S][pos] @ xs[pos]) / float(xs[pos].sum())
+                order = np.argsort(-h["topv"], kind="stable")
+                cand_i, cand_v = h["topi"][order], h["topv"][order]
+                in_pos = set(keep[pos].tolist())
+                enter = []
+                room = s_max - int(pos.sum())
+                for i, v in zip(cand_i.tolist(), cand_v.tolist()):
+                    if len(enter) >= min(enter_per, room) or i < 0 or v / level - 1.0 <= enter_tol:
+                        break
+                    if i not in in_pos:
+                        enter.append(i)
+                if log is not None:
+                    log("eps %.0e round %2d F_eps %.12e gap %.3e |S| %3d nnz %3d newton %2d evals %3d enter %3d kkt %.1e status %d"
+                        % (eps, rnd, F, gap, S, int(pos.sum()), int(out[4]), int(out[5]), len(enter), out[2], int(out[7])))
+                x_full = (keep[pos], xs[pos] / xs[pos].sum())
+                F_last = F
+                if len(enter) == 0:
+                    if mtol > 1.0e-9:
+                        mtol = 1.0e-9                              # the support is priced out at a loose master: tighten once
+                        keep, xs = keep[pos], xs[pos] / xs[pos].sum()
+                        continue
+                    break
+                viol = cand_v[0] / level - 1.0
+                mtol = max(1.0e-9, min(1.0e-2, 1.0e-2 * float(viol)))
+                new_keep = np.concatenate([keep[pos], np.asarray(enter, dtype=np.int64)])
+                new_x = np.concatenate([xs[pos], np.zeros(len(enter))])   # enter at zero: the master frees them (reduced cost < 0)
+                o2 = np.argsort(new_keep, kind="stable")
+                keep, xs = new_keep[o2], new_x[o2] / new_x.sum()
+                if gap <= gap_tol and stage == len(eps_list) - 1:
+                    pass                                           # keep pricing until no column enters: cheap, and it lowers F
+        # ---- polish on the final support without background (the function the reference evaluates) --------------------------
+        keep, xs = x_full
+        S = len(keep)
+        bufs.put("xs", xs)
+        bufs.put("mu", mu)
+        keep_h = np.ascontiguousarray(keep, dtype=np.int64)
+        cc_keep = np.ascontiguousarray(cc_h[keep])
+        check(lib.bluest_master_newton(plan._h, S, keep_h.ctypes.data, cc_keep.ctypes.data, s_d.data_ptr(), None, 0.0,
+                                       bufs.ptr("xs"), bufs.ptr("mu"), 1.0e-10, newton_maxit, bufs.ptr("out"), st))
+        h = bufs.fetch()
+        out = h["out"]
+        info["newton_it"] += int(out[4])
+        info["master_evals"] += int(out[5])
+        # the truth: F of the sparse allocation itself, evaluated by the plan (no background) -- before and after the polish
+        def true_F(xv):
+            mm = np.zeros(L)
+            mm[keep] = cc_h[keep] * np.maximum(xv, 0.0) / max(float(np.maximum(xv, 0.0).sum()), 1e-300)
+            vv, _, stt = plan.eval(mm, want_grad=False)
+            if not (stt[0].cpu().numpy() == EVAL_OK).all():
+                return np.inf
+            return float((vv[0].cpu().numpy() / s).max())
+        F_true = true_F(xs)
+        info["polished"] = False
+        if int(out[7]) != 2 and np.isfinite(out[0]):
+            F_pol = true_F(h["xs"][:S])
+            if F_pol < F_true:
+                xs, mu, F_true = h["xs"][:S].copy(), h["mu"].copy(), F_pol
+                info["polished"] = True
+    if not np.isfinite(F_true):
+        return None, "final allocation not evaluable"
+    x = np.zeros(L)
+    x[keep] = np.maximum(xs, 0.0)
+    x /= x.sum()
+    info.update({"F": F_true, "F_background": F_last, "lower_bound": best_lb, "gap": 1.0 - best_lb / F_true, "mu": mu,
+                 "support": int((x > 0).sum()), "kkt": float(out[2])})
+    return x, info

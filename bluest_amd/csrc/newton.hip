@@ -1,0 +1,858 @@
+// newton.hip -- Part 6 of include/bluest_hip.h: the second-order finish of solver="spg".
+//
+//   k_ma_update      one step of the multiplicative algorithm on the full problem (phase 1: locates the support)
+//   k_master_newton  active-set Newton (SQP, Levenberg-Marquardt damped) on a support of <= 64 groups: ONE workgroup runs the
+//                    whole solve -- evaluations, Hessian, KKT system, step control -- out of LDS
+//   k_price          reduced costs of ALL groups at the priced point + the dual bound + the most violating candidates
+//   k_support_point  allocation vector of the full problem from a support vector (+ the uniform background)
+//
+// The algorithm is restated in numpy by the test infrastructure; tests compare the two.
+// The reference hands this problem to third-party NLP solvers with the Hessian of bluest/misc.py:497-503 /
+// bluest/cmisc.cpp:74-97 (bluest/sap.py:387-456); there is no reference code to follow.
+#include "plan.hpp"
+
+#define MASTER_THREADS 512
+#define MASTER_SMAX 64
+#define MASTER_PACT 4      // outputs that can be active (tie at the maximum) at once inside the master
+#define MASTER_OUT 16      // doubles in front of r[] in the result record
+
+struct MasterArgs {
+    int N, n_out, S, KM;               // models, outputs, support size (<= 64), largest group size in the support
+    double eps_bg, tol, act_tol, floor_x;
+    double fb;                         // > 0: fraction-to-the-boundary rule (no entry reaches zero: the polish without background)
+    int maxit;
+    const double *const *invcov;       // [n_out] reference-layout pseudo-inverses of every output (plan memory)
+    const int64_t *boff;               // [n_out * S] offset (doubles) of block (o, j) inside invcov[o]; -1: output o lacks group j
+    const double *cc;                  // [S] B / w_j
+    const uint8_t *idx;                // [S * KM] model indices of the support groups (padded)
+    const int32_t *kk;                 // [S] group sizes
+    const double *s;                   // [n_out] output scales
+    const double *bg;                  // [n_out * N * N] eps_bg * Phi_o(uniform allocation), or NULL (eps_bg == 0)
+    double *x;                         // [S] in: start (>= 0), out: solution (sum 1)
+    double *mu;                        // [n_out] in: multipliers of the previous master (or < 0: none), out: multipliers
+    double *out;                       // [MASTER_OUT + n_out]: F, lam, kkt, spread, it, evals, solves, status, damp, ..., r[n_out]
+};
+
+struct MasterLds {                     // carved out of dynamic LDS by master_carve()
+    double *PHI, *TACT, *BLK, *M, *AAC, *GQ;
+    double *x, *xt, *d, *cc, *Dm, *glv, *mvec, *r, *rt, *mu, *muh, *scal;
+    int *kk, *fi, *act, *istate;
+    signed char *pos;
+    unsigned char *idx;
+    unsigned long long *memb;          // [N] bit j: support group j contains the model
+    int LDN, LDM, KE;
+};
+
+__host__ __device__ inline size_t master_lds_bytes(int N, int n_out, int S, int KM)
+{
+    const size_t LDN = N + 1, LDM = (S + MASTER_PACT + 2) | 1, KE = (size_t)KM * (KM + 1) / 2;
+    size_t d = (size_t)n_out * N * LDN + (size_t)MASTER_PACT * N * LDN + (size_t)S * n_out * KE + (size_t)S * LDM +
+               (size_t)MASTER_PACT * S * KM + (size_t)S * MASTER_PACT + 7 * (size_t)S + 4 * (size_t)n_out + 64 + (size_t)N;
+    size_t bytes = d * sizeof(double) + (3 * (size_t)S + 2 * MASTER_PACT + 24) * sizeof(int) + (size_t)S * N + (size_t)S * KM + 64;
+    return (bytes + 15) & ~(size_t)15;
+}
+
+__device__ inline void master_carve(MasterLds &L, unsigned char *base, int N, int n_out, int S, int KM)
+{
+    L.LDN = N + 1; L.LDM = (S + MASTER_PACT + 2) | 1; L.KE = KM * (KM + 1) / 2;
+    double *p = reinterpret_cast<double *>(base);
+    L.PHI = p;  p += (size_t)n_out * N * L.LDN;
+    L.TACT = p; p += (size_t)MASTER_PACT * N * L.LDN;
+    L.BLK = p;  p += (size_t)S * n_out * L.KE;
+    L.M = p;    p += (size_t)S * L.LDM;
+    L.AAC = p;  p += (size_t)MASTER_PACT * S * KM;
+    L.GQ = p;   p += (size_t)S * MASTER_PACT;
+    L.x = p; p += S; L.xt = p; p += S; L.d = p; p += S; L.cc = p; p += S; L.Dm = p; p += S; L.glv = p; p += S; L.mvec = p; p += S;
+    L.r = p; p += n_out; L.rt = p; p += n_out; L.mu = p; p += n_out; L.muh = p; p += n_out;
+    L.scal = p; p += 64;
+    L.memb = reinterpret_cast<unsigned long long *>(p); p += N;
+    int *q = reinterpret_cast<int *>(p);
+    L.kk = q; q += S; L.fi = q; q += S; L.act = q; q += 2 * MASTER_PACT; L.istate = q; q += 24;      // act: current list, then the iteration's list (act0)
+    q += S;     // spare
+    L.pos = reinterpret_cast<signed char *>(q);
+    L.idx = reinterpret_cast<unsigned char *>(L.pos + (size_t)S * N);
+}
+
+// scal[] slots
+enum { SC_F = 0, SC_LAMEST, SC_DAMP, SC_TAU, SC_LAM, SC_PRED, SC_KKT, SC_SPREAD, SC_QMAX, SC_FT, SC_LAMX };
+// istate[] slots
+enum { IS_NACT = 0, IS_NF, IS_OK, IS_DONE, IS_ACCEPT, IS_IT, IS_EVALS, IS_SOLVES, IS_STATUS, IS_NACT0, IS_TINY, IS_NALIVE, IS_ALIVE /* .. +PACT */ };
+
+// packed symmetric index of (l, l2), l <= l2, in a k x k block
+__device__ __forceinline__ int sym_e(int l, int l2, int k) { return l * k - l * (l - 1) / 2 + (l2 - l); }
+
+// r[o] = V_o / s_o of the allocation with support vector xv (LDS) -- all threads.  Leaves T_o = Phi_o^-1 (on the touched
+// models, zero elsewhere) in L.PHI.  Fixed summation orders: the result is bit-reproducible (every rank of a sharded solve
+// runs this redundantly and must get the same bits).
+__device__ void master_eval(const MasterArgs &A, MasterLds &L, const double *xv, double *rout, int tid)
+{
+    const int N = A.N, n_out = A.n_out, S = A.S, LDN = L.LDN, KE = L.KE;
+    const int wave = tid >> 6, lane = tid & 63, nw = MASTER_THREADS / 64;
+    for (int j = tid; j < S; j += MASTER_THREADS) L.mvec[j] = (1.0 - A.eps_bg) * L.cc[j] * xv[j];
+    __syncthreads();
+    for (int t = tid; t < n_out * N * N; t += MASTER_THREADS) {
+        const int o = t / (N * N), a = (t / N) % N, b = t % N;
+        double acc = A.bg ? A.bg[t] : 0.0;
+        unsigned long long both = L.memb[a] & L.memb[b];          // support groups containing both models, ascending order
+        while (both) {
+            const int j = __ffsll((long long)both) - 1;
+            both &= both - 1ull;
+            const double mj = L.mvec[j];
+            if (mj > 0.0) {
+                const int pa = L.pos[j * N + a], pb = L.pos[j * N + b];
+                const int lo = pa < pb ? pa : pb, hi = pa < pb ? pb : pa;
+                acc = fma(mj, L.BLK[((size_t)j * n_out + o) * KE + sym_e(lo, hi, L.kk[j])], acc);
+            }
+        }
+        L.PHI[((size_t)o * N + a) * LDN + b] = acc;
+    }
+    __syncthreads();
+    // in-place Gauss-Jordan inverse, one wavefront per output, lane = row (SPD: no pivoting)
+    for (int o = wave; o < n_out; o += nw) {
+        double *P = L.PHI + (size_t)o * N * LDN;
+        const bool mine = lane < N;
+        bool untouched = false;
+        if (mine && !(P[lane * LDN + lane] > 0.0)) { untouched = true; P[lane * LDN + lane] = 1.0; }
+        wave_lds_sync();
+        bool bad = false;
+        for (int p = 0; p < N; p++) {
+            const double piv = P[p * LDN + p];
+            if (!(piv > 0.0) || !isfinite(piv)) { bad = true; break; }            // wave-uniform (same address)
+            const double rinv = 1.0 / piv;
+            if (mine && lane != p) {
+                const double f = P[lane * LDN + p] * rinv;
+                for (int c = 0; c < N; c++)
+                    if (c != p) P[lane * LDN + c] = fma(-f, P[p * LDN + c], P[lane * LDN + c]);
+                P[lane * LDN + p] = -f;
+            }
+            wave_lds_sync();
+            if (lane == p) {
+                for (int c = 0; c < N; c++)
+                    if (c != p) P[p * LDN + c] *= rinv;
+                P[p * LDN + p] = rinv;
+            }
+            wave_lds_sync();
+        }
+        if (untouched) P[lane * LDN + lane] = 0.0;
+        wave_lds_sync();
+        if (lane == 0) {
+            const double v00 = P[0];
+            rout[o] = (!bad && v00 > 0.0 && isfinite(v00)) ? v00 / A.s[o] : INFINITY;
+        }
+    }
+    __syncthreads();
+}
+
+// Hessian of the Lagrangian in reciprocal form + damping into M (free x free, compressed), E columns appended -- all threads
+__device__ void master_build_system(const MasterArgs &A, MasterLds &L, int tid)
+{
+    const int N = A.N, S = A.S, KM = A.KM, LDN = L.LDN, LDM = L.LDM;
+    const int nf = L.istate[IS_NF], nact = L.istate[IS_NACT], nact0 = L.istate[IS_NACT0];
+    const double dl = L.scal[SC_DAMP] * fabs(L.scal[SC_LAMEST]);
+    for (int t = tid; t < nf * nf; t += MASTER_THREADS) {
+        const int fa = t / nf, fb = t % nf;
+        if (fa > fb) continue;
+        const int i = L.fi[fa], j = L.fi[fb];
+        const int ki = L.kk[i], kj = L.kk[j];
+        double h = 0.0;
+        for (int a = 0; a < nact0; a++) {              // curvature of every output of the iteration's active set
+            const int o = L.act[a + MASTER_PACT];      // act0 list lives behind the current list
+            const double ro = L.r[o];
+            const double *T = L.TACT + (size_t)a * N * LDN;
+            const double *ai = L.AAC + ((size_t)a * S + i) * KM, *aj = L.AAC + ((size_t)a * S + j) * KM;
+            double acc = 0.0;
+            for (int l = 0; l < ki; l++) {
+                const double *Trow = T + (size_t)L.idx[i * KM + l] * LDN;
+                double tt = 0.0;
+                for (int l2 = 0; l2 < kj; l2++) tt = fma(Trow[L.idx[j * KM + l2]], aj[l2], tt);
+                acc = fma(ai[l], tt, acc);
+            }
+            const double cci = (1.0 - A.eps_bg) * L.cc[i], ccj = (1.0 - A.eps_bg) * L.cc[j];
+            const double gi = L.GQ[i * MASTER_PACT + a], gj = L.GQ[j * MASTER_PACT + a];
+            h += L.muh[o] * ((2.0 / A.s[o]) * cci * ccj * acc / (ro * ro) - 2.0 * gi * gj * ro);
+        }
+        if (fa == fb) h += dl * L.Dm[i];
+        L.M[fa * LDM + fb] = h;
+        L.M[fb * LDM + fa] = h;
+    }
+    // E = [GQ columns of the CURRENT active outputs, 1]
+    for (int t = tid; t < nf * (nact + 1); t += MASTER_THREADS) {
+        const int fa = t / (nact + 1), e = t % (nact + 1);
+        double v = 1.0;
+        if (e < nact) {
+            int a0 = 0;                                 // position of this output in the act0 list (GQ columns follow act0)
+            for (int q = 0; q < nact0; q++) if (L.act[q + MASTER_PACT] == L.act[e]) a0 = q;
+            v = L.GQ[L.fi[fa] * MASTER_PACT + a0];
+        }
+        L.M[fa * LDM + nf + e] = v;
+    }
+    __syncthreads();
+}
+
+// wave 0: Gauss-Jordan on [M | E] -> Y = M^-1 E (left in the E columns of M), K = E^T Y (L.scal[32..]).  L.istate[IS_OK]
+__device__ void master_factor_wave(const MasterArgs &A, MasterLds &L, int lane)
+{
+    const int LDM = L.LDM;
+    const int nf = L.istate[IS_NF], nact = L.istate[IS_NACT];
+    const int ne = nact + 1;
+    bool ok = true;
+    for (int p = 0; p < nf; p++) {
+        const double piv = L.M[p * LDM + p];
+        if (!(piv > 0.0) || !isfinite(piv)) { ok = false; break; }
+        const double rinv = 1.0 / piv;
+        if (lane < nf && lane != p) {
+            const double f = L.M[lane * LDM + p] * rinv;
+            for (int c = p + 1; c < nf + ne; c++) L.M[lane * LDM + c] = fma(-f, L.M[p * LDM + c], L.M[lane * LDM + c]);
+        }
+        wave_lds_sync();
+    }
+    if (!ok) { if (lane == 0) L.istate[IS_OK] = 0; wave_lds_sync(); return; }
+    double Y[MASTER_PACT + 1], Eo[MASTER_PACT + 1];
+#pragma unroll
+    for (int e = 0; e < MASTER_PACT + 1; e++) { Y[e] = 0.0; Eo[e] = 0.0; }
+    if (lane < nf) {
+        const double di = 1.0 / L.M[lane * LDM + lane];
+        for (int e = 0; e < ne; e++) {
+            Y[e] = L.M[lane * LDM + nf + e] * di;
+            L.M[lane * LDM + nf + e] = Y[e];
+            Eo[e] = e < nact ? L.GQ[L.fi[lane] * MASTER_PACT + e] : 1.0;      // act == act0 order: GQ column e
+        }
+    }
+    for (int e = 0; e < ne; e++)
+        for (int e2 = 0; e2 < ne; e2++) {
+            const double k = wave_sum(Eo[e] * Y[e2]);
+            if (lane == 0) L.scal[32 + e * (MASTER_PACT + 1) + e2] = k;
+        }
+    if (lane == 0) { L.istate[IS_OK] = 1; for (int e = 0; e < MASTER_PACT; e++) L.istate[IS_ALIVE + e] = e < nact; }
+    wave_lds_sync();
+}
+
+// wave 0: the small KKT system  K z + [1_p; 0] tau = rhs_q,  sum z[0..p) = rhs_sum  over the alive outputs, then the step
+// out_j = -Y z on the free rows.  soc = false: the SQP step (rhs_q = q at x, rhs_sum = 1): outputs whose multiplier comes out
+// negative leave the alive set, multipliers / lam / tau are published.  soc = true: the second-order correction (rhs_q = q at
+// the trial point, rhs_sum = 0) with the alive set as the step left it.  Every lane solves redundantly (identical inputs).
+__device__ void master_small_solve(const MasterArgs &A, MasterLds &L, int lane, bool soc, double *outvec)
+{
+    const int S = A.S, LDM = L.LDM;
+    const int nf = L.istate[IS_NF], nact = L.istate[IS_NACT];
+    const int W = MASTER_PACT + 3;
+    int alive[MASTER_PACT];
+    for (int e = 0; e < MASTER_PACT; e++) alive[e] = L.istate[IS_ALIVE + e];
+    double z[MASTER_PACT + 2];
+    bool ok = false;
+    int map[MASTER_PACT + 1], p = 0;
+    for (int round = 0; round <= MASTER_PACT; round++) {
+        p = 0;
+        for (int e = 0; e < nact; e++) if (alive[e]) map[p++] = e;
+        map[p] = nact;                                                       // the "ones" column (index nact in K)
+        const int n = p + 2;
+        double Am[(MASTER_PACT + 2) * (MASTER_PACT + 3)];
+        for (int a = 0; a < n; a++) for (int b = 0; b <= n; b++) Am[a * W + b] = 0.0;
+        for (int a = 0; a <= p; a++)
+            for (int b = 0; b <= p; b++) Am[a * W + b] = L.scal[32 + map[a] * (MASTER_PACT + 1) + map[b]];
+        for (int a = 0; a < p; a++) { Am[a * W + p + 1] = 1.0; Am[(p + 1) * W + a] = 1.0; Am[a * W + n] = L.scal[(soc ? 20 : 16) + map[a]]; }
+        Am[(p + 1) * W + n] = soc ? 0.0 : 1.0;
+        bool sing = false;                                                   // Gaussian elimination with partial pivoting
+        for (int c = 0; c < n; c++) {
+            int pr = c; double best = fabs(Am[c * W + c]);
+            for (int rr = c + 1; rr < n; rr++) if (fabs(Am[rr * W + c]) > best) { best = fabs(Am[rr * W + c]); pr = rr; }
+            if (!(best > 0.0)) { sing = true; break; }
+            if (pr != c) for (int b = 0; b <= n; b++) { const double t = Am[c * W + b]; Am[c * W + b] = Am[pr * W + b]; Am[pr * W + b] = t; }
+            const double ri = 1.0 / Am[c * W + c];
+            for (int rr = 0; rr < n; rr++) {
+                if (rr == c) continue;
+                const double f = Am[rr * W + c] * ri;
+                if (f != 0.0) for (int b = c; b <= n; b++) Am[rr * W + b] -= f * Am[c * W + b];
+            }
+        }
+        if (sing) break;
+        for (int a = 0; a < n; a++) z[a] = Am[a * W + n] / Am[a * W + a];
+        int worst = -1; double wv = -1.0e-12;
+        if (!soc && p > 1) for (int a = 0; a < p; a++) if (z[a] < wv) { wv = z[a]; worst = a; }
+        if (worst < 0) { ok = true; break; }
+        alive[map[worst]] = 0;
+    }
+    if (!ok) { if (lane == 0) L.istate[IS_OK] = 0; wave_lds_sync(); return; }
+    double zf[MASTER_PACT + 2];
+    for (int e = 0; e < MASTER_PACT + 2; e++) zf[e] = 0.0;
+    for (int a = 0; a < p; a++) zf[map[a]] = z[a];
+    const double lam = z[p], tau = z[p + 1];
+    double di = 0.0;
+    if (lane < nf) {
+        for (int e = 0; e < nact; e++) di = fma(L.M[lane * LDM + nf + e], zf[e], di);
+        di = fma(L.M[lane * LDM + nf + nact], lam, di);
+    }
+    for (int j = lane; j < S; j += 64) outvec[j] = 0.0;
+    wave_lds_sync();
+    if (lane < nf) outvec[L.fi[lane]] = -di;
+    if (lane == 0 && !soc) {
+        L.scal[SC_LAM] = lam; L.scal[SC_TAU] = tau;
+        double tot = 0.0;
+        for (int e = 0; e < nact; e++) { zf[e] = zf[e] > 0.0 ? zf[e] : 0.0; tot += zf[e]; }
+        for (int e = 0; e < nact; e++) L.scal[24 + e] = tot > 0.0 ? zf[e] / tot : 0.0;     // new multipliers, act order
+        for (int e = 0; e < MASTER_PACT; e++) L.istate[IS_ALIVE + e] = alive[e];
+        int na = 0;
+        for (int e = 0; e < nact; e++) na += alive[e];
+        L.istate[IS_NALIVE] = na;
+    }
+    if (lane == 0) L.istate[IS_OK] = 1;
+    wave_lds_sync();
+}
+
+__global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
+{
+    extern __shared__ __align__(16) unsigned char master_sm[];
+    MasterLds L;
+    const int N = A.N, n_out = A.n_out, S = A.S, KM = A.KM;
+    master_carve(L, master_sm, N, n_out, S, KM);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int LDN = L.LDN, KE = L.KE;
+    // ---- load the support ---------------------------------------------------------------------------
+    for (int j = tid; j < S; j += MASTER_THREADS) { L.kk[j] = A.kk[j]; L.cc[j] = A.cc[j]; const double v = A.x[j]; L.x[j] = v > 0.0 ? v : 0.0; }
+    for (int t = tid; t < S * KM; t += MASTER_THREADS) L.idx[t] = A.idx[t];
+    for (int t = tid; t < S * N; t += MASTER_THREADS) L.pos[t] = -1;
+    for (int o = tid; o < n_out; o += MASTER_THREADS) L.mu[o] = A.mu[o];
+    if (tid < 24) L.istate[tid] = 0;
+    if (tid < 64) L.scal[tid] = 0.0;
+    __syncthreads();
+    for (int t = tid; t < S * KM; t += MASTER_THREADS) {
+        const int j = t / KM, l = t % KM;
+        if (l < L.kk[j]) L.pos[j * N + L.idx[t]] = (signed char)l;
+    }
+    for (int a = tid; a < N; a += MASTER_THREADS) {
+        unsigned long long mk = 0ull;
+        for (int j = 0; j < S; j++)
+            for (int l = 0; l < L.kk[j]; l++) if (L.idx[j * KM + l] == a) mk |= 1ull << j;
+        L.memb[a] = mk;
+    }
+    for (int t = tid; t < S * n_out * KE; t += MASTER_THREADS) {
+        const int e = t % KE, o = (t / KE) % n_out, j = t / (KE * n_out);
+        const int k = L.kk[j];
+        double v = 0.0;
+        const int64_t off = A.boff[(size_t)o * S + j];
+        if (off >= 0 && e < k * (k + 1) / 2) {
+            int l = 0, rem = e;
+            while (rem >= k - l) { rem -= k - l; l++; }
+            const int l2 = l + rem;
+            const double *b = A.invcov[o] + off;
+            v = 0.5 * (b[l * k + l2] + b[l2 * k + l]);
+        }
+        L.BLK[t] = v;
+    }
+    if (wave == 0) {   // normalise the start
+        double sx = 0.0;
+        for (int j = lane; j < S; j += 64) sx += L.x[j];
+        sx = wave_sum(sx);
+        for (int j = lane; j < S; j += 64) L.x[j] = sx > 0.0 ? L.x[j] / sx : 1.0 / S;
+    }
+    if (tid == 0) { L.scal[SC_DAMP] = 1.0e-2; L.istate[IS_STATUS] = 0; }
+    __syncthreads();
+    master_eval(A, L, L.x, L.r, tid);
+    if (tid == 0) {
+        L.istate[IS_EVALS] = 1;
+        double F = 0.0;
+        for (int o = 0; o < n_out; o++) F = fmax(F, L.r[o]);
+        if (!isfinite(F)) { L.istate[IS_DONE] = 1; L.istate[IS_STATUS] = 2; }       // start not evaluable
+        L.scal[SC_F] = F;
+        L.scal[SC_KKT] = INFINITY; L.scal[SC_SPREAD] = INFINITY;
+    }
+    __syncthreads();
+
+    for (int it = 0; it < A.maxit && !L.istate[IS_DONE]; it++) {
+        // ---- active outputs and their curvature weights (thread 0) -------------------------------------
+        if (tid == 0) {
+            const double F = L.scal[SC_F];
+            int nact = 0;
+            // candidates: within act_tol of the maximum, or carrying a multiplier; keep the MASTER_PACT largest by (mu, r)
+            for (int o = 0; o < n_out; o++) L.muh[o] = 0.0;
+            for (int pick = 0; pick < MASTER_PACT; pick++) {
+                int best = -1; double bm = -1.0, br = -1.0;
+                for (int o = 0; o < n_out; o++) {
+                    bool taken = false;
+                    for (int q = 0; q < nact; q++) if (L.act[q] == o) taken = true;
+                    if (taken) continue;
+                    const bool cand = (L.r[o] >= F * (1.0 - A.act_tol)) || (L.mu[o] > 1.0e-12);
+                    if (!cand) continue;
+                    const double m_o = L.mu[o] > 0.0 ? L.mu[o] : 0.0;
+                    if (m_o > bm || (m_o == bm && L.r[o] > br)) { best = o; bm = m_o; br = L.r[o]; }
+                }
+                if (best < 0) break;
+                L.act[nact++] = best;
+            }
+            // ascending output order (deterministic, matches the restatement)
+            for (int a = 0; a < nact; a++) for (int b = a + 1; b < nact; b++) if (L.act[b] < L.act[a]) { const int t = L.act[a]; L.act[a] = L.act[b]; L.act[b] = t; }
+            double tot = 0.0;
+            for (int a = 0; a < nact; a++) { const double m_o = L.mu[L.act[a]] > 0.0 ? L.mu[L.act[a]] : 0.0; L.muh[L.act[a]] = m_o; tot += m_o; }
+            for (int a = 0; a < nact; a++) L.muh[L.act[a]] = tot > 0.0 ? L.muh[L.act[a]] / tot : 1.0 / nact;
+            tot = 0.0;
+            for (int a = 0; a < nact; a++) { L.muh[L.act[a]] = fmax(L.muh[L.act[a]], 1.0e-3 / nact); tot += L.muh[L.act[a]]; }
+            for (int a = 0; a < nact; a++) L.muh[L.act[a]] /= tot;
+            for (int a = 0; a < nact; a++) L.act[a + MASTER_PACT] = L.act[a];      // act0: the iteration's set (GQ / TACT / AAC order)
+            L.istate[IS_NACT] = nact; L.istate[IS_NACT0] = nact;
+        }
+        __syncthreads();
+        // ---- derivatives at x: T (kept for the active outputs), a_{o,j}, gradients in reciprocal form ---------------
+        // T_o = Phi_o^-1 of the current x is in L.PHI: left there by the initial evaluation or by the accepted trial evaluation
+        const int nact0 = L.istate[IS_NACT0];
+        for (int t = tid; t < nact0 * N * LDN; t += MASTER_THREADS) {
+            const int a = t / (N * LDN);
+            L.TACT[t] = L.PHI[(size_t)L.act[a + MASTER_PACT] * N * LDN + (t - a * N * LDN)];
+        }
+        __syncthreads();
+        for (int t = tid; t < nact0 * S * KM; t += MASTER_THREADS) {
+            const int l = t % KM, j = (t / KM) % S, a = t / (KM * S);
+            const int o = L.act[a + MASTER_PACT], k = L.kk[j];
+            double acc = 0.0;
+            if (l < k) {
+                const double *T = L.TACT + (size_t)a * N * LDN;
+                const double *B = L.BLK + ((size_t)j * n_out + o) * KE;
+                for (int l2 = 0; l2 < k; l2++) {
+                    const int lo = l < l2 ? l : l2, hi = l < l2 ? l2 : l;
+                    acc = fma(B[sym_e(lo, hi, k)], T[(size_t)L.idx[j * KM + l2] * LDN + 0], acc);
+                }
+            }
+            L.AAC[t] = acc;
+        }
+        __syncthreads();
+        for (int t = tid; t < S * nact0; t += MASTER_THREADS) {
+            const int a = t % nact0, j = t / nact0;
+            const int o = L.act[a + MASTER_PACT], k = L.kk[j];
+            const double *T = L.TACT + (size_t)a * N * LDN;
+            double acc = 0.0;
+            for (int l = 0; l < k; l++) acc = fma(L.AAC[((size_t)a * S + j) * KM + l], T[(size_t)L.idx[j * KM + l] * LDN + 0], acc);
+            const double ro = L.r[o];
+            L.GQ[j * MASTER_PACT + a] = -(1.0 - A.eps_bg) * L.cc[j] * acc / A.s[o] / (ro * ro);
+        }
+        if (tid == 0) {
+            for (int a = 0; a < nact0; a++) L.scal[16 + a] = -1.0 / L.r[L.act[a + MASTER_PACT]];      // q of the act0 outputs
+            double qm = -INFINITY;
+            for (int o = 0; o < n_out; o++) qm = fmax(qm, -1.0 / L.r[o]);
+            L.scal[SC_QMAX] = qm;
+        }
+        __syncthreads();
+        if (wave == 0) {   // reduced costs with the curvature weights -> free set
+            double part = 0.0;
+            for (int j = lane; j < S; j += 64) {
+                double g = 0.0;
+                for (int a = 0; a < nact0; a++) g = fma(L.muh[L.act[a + MASTER_PACT]], L.GQ[j * MASTER_PACT + a], g);
+                L.glv[j] = g;
+                part = fma(g, L.x[j], part);
+            }
+            const double lam_est = -wave_sum(part);
+            int nf = 0;
+            for (int base = 0; base < S; base += 64) {
+                const int j = base + lane;
+                const bool fr = j < S && (L.x[j] > 0.0 || L.glv[j] + lam_est < 0.0);
+                const unsigned long long bal = __ballot(fr);
+                if (fr) L.fi[nf + __popcll(bal & ((1ull << lane) - 1ull))] = j;
+                nf += __popcll(bal);
+                if (j < S) L.Dm[j] = 1.0 / fmax(L.x[j], A.floor_x);
+            }
+            if (lane == 0) { L.scal[SC_LAMEST] = lam_est; L.istate[IS_NF] = nf; L.istate[IS_ACCEPT] = 0; }
+        }
+        __syncthreads();
+        // ---- damped attempts -------------------------------------------------------------------------------------
+        bool converged = false;
+        for (int attempt = 0; attempt < 40; attempt++) {
+            if (tid == 0) L.istate[IS_NACT] = L.istate[IS_NACT0];
+            if (tid < MASTER_PACT) L.act[tid] = L.act[tid + MASTER_PACT];
+            __syncthreads();
+            master_build_system(A, L, tid);
+            if (wave == 0) {
+                master_factor_wave(A, L, lane);
+                if (L.istate[IS_OK]) master_small_solve(A, L, lane, false, L.d);
+                if (lane == 0) L.istate[IS_SOLVES] += 1;
+            }
+            __syncthreads();
+            if (!L.istate[IS_OK]) {              // M not positive definite (or singular small system): more damping
+                __syncthreads();
+                if (tid == 0) L.scal[SC_DAMP] *= 10.0;
+                __syncthreads();
+                if (L.scal[SC_DAMP] > 1.0e12) break;
+                continue;
+            }
+            // new multipliers (full vector) and, at the first attempt, the KKT residual at x
+            if (wave == 0) {
+                const int nact = L.istate[IS_NACT0];
+                if (attempt == 0) {
+                    double part = 0.0;
+                    for (int j = lane; j < S; j += 64) {
+                        double g = 0.0;
+                        for (int a = 0; a < nact; a++) g = fma(L.scal[24 + a], L.GQ[j * MASTER_PACT + a], g);
+                        L.xt[j] = g;                    // scratch
+                        part = fma(g, L.x[j], part);
+                    }
+                    const double lam_x = -wave_sum(part);
+                    double worst = 0.0;
+                    for (int j = lane; j < S; j += 64) {
+                        const double rc = L.xt[j] + lam_x;
+                        worst = fmax(worst, L.x[j] > 1.0e-10 ? fabs(rc) : fmax(-rc, 0.0));      // entries below 1e-10 count as at the bound
+                    }
+                    worst = wave_max(worst) / fmax(fabs(lam_x), 1.0e-300);
+                    if (lane == 0) {
+                        double sp = 0.0;
+                        const double F = L.scal[SC_F];
+                        for (int a = 0; a < nact; a++) if (L.scal[24 + a] > 0.0) sp = fmax(sp, (F - L.r[L.act[a + MASTER_PACT]]) / F);
+                        L.scal[SC_KKT] = worst; L.scal[SC_SPREAD] = sp; L.scal[SC_LAMX] = lam_x;
+                    }
+                }
+            }
+            __syncthreads();
+            if (attempt == 0 && L.scal[SC_KKT] <= A.tol && L.scal[SC_SPREAD] <= A.tol) { converged = true; break; }
+            const double F = L.scal[SC_F];
+            const double pred = (L.scal[SC_TAU] - L.scal[SC_QMAX]) * F * F;
+            if (pred < -0.5 * F) {               // the model promises more than half of a positive objective: shorter step
+                __syncthreads();
+                if (tid == 0) L.scal[SC_DAMP] *= 10.0;
+                __syncthreads();
+                if (L.scal[SC_DAMP] > 1.0e12) break;
+                continue;
+            }
+            // projected step, renormalised.  fb > 0 (no background): every entry keeps at least 1 - fb of its value, so that no
+            // model drops out of the information matrix inside the master (V has a kink there)
+            if (wave == 0) {
+                double sx = 0.0;
+                for (int j = lane; j < S; j += 64) {
+                    const double v = fmax(L.x[j] + L.d[j], A.fb > 0.0 ? (1.0 - A.fb) * L.x[j] : 0.0);
+                    L.xt[j] = v; sx += v;
+                }
+                sx = wave_sum(sx);
+                for (int j = lane; j < S; j += 64) L.xt[j] = L.xt[j] / sx;
+            }
+            __syncthreads();
+            master_eval(A, L, L.xt, L.rt, tid);
+            // acceptance; near a tie of several outputs second-order errors split the tie and the exact max rejects a good SQP
+            // step (the Maratos effect): one second-order correction -- the minimum-norm (in M) step c that re-equalises the
+            // alive outputs at the trial point to first order, same K, another right-hand side -- gets a second evaluation
+            for (int pass = 0; pass < 2; pass++) {
+                if (tid == 0) {
+                    L.istate[IS_EVALS] += 1;
+                    double Ft = 0.0;
+                    for (int o = 0; o < n_out; o++) Ft = fmax(Ft, L.rt[o]);
+                    const double actual = Ft - F;
+                    L.istate[IS_OK] = 0;                           // reused: "try the correction"
+                    if (isfinite(Ft) && actual <= 1.0e-4 * fmin(pred, 0.0) + 1.0e-15 * F) {
+                        const double ratio = pred < 0.0 ? actual / pred : 1.0;
+                        if (ratio > 0.5) L.scal[SC_DAMP] = fmax(L.scal[SC_DAMP] * 0.1, 1.0e-14);
+                        else if (ratio < 0.1) L.scal[SC_DAMP] *= 10.0;
+                        L.istate[IS_ACCEPT] = 1;
+                        L.scal[SC_FT] = Ft;
+                        // the objective cannot resolve the remaining improvement (the KKT residual left sits in entries of negligible mass)
+                        L.istate[IS_TINY] = fabs(actual) <= 1.0e-13 * F ? L.istate[IS_TINY] + 1 : 0;
+                    } else if (pass == 0 && isfinite(Ft) && L.istate[IS_NALIVE] > 1) {
+                        for (int a = 0; a < L.istate[IS_NACT0]; a++) L.scal[20 + a] = -1.0 / L.rt[L.act[a + MASTER_PACT]];
+                        L.istate[IS_OK] = 1;
+                    } else {
+                        L.scal[SC_DAMP] *= 10.0;
+                    }
+                }
+                __syncthreads();
+                if (pass == 1 || !L.istate[IS_OK]) break;
+                __syncthreads();
+                if (wave == 0) {
+                    master_small_solve(A, L, lane, true, L.glv);          // c into glv (free after the free-set step)
+                    if (L.istate[IS_OK]) {
+                        double sx = 0.0;
+                        for (int j = lane; j < S; j += 64) {
+                            const double v = fmax(L.x[j] + L.d[j] + L.glv[j], A.fb > 0.0 ? (1.0 - A.fb) * L.x[j] : 0.0);
+                            L.xt[j] = v; sx += v;
+                        }
+                        sx = wave_sum(sx);
+                        for (int j = lane; j < S; j += 64) L.xt[j] = L.xt[j] / sx;
+                    }
+                }
+                __syncthreads();
+                if (!L.istate[IS_OK]) {                             // singular correction system: plain rejection
+                    __syncthreads();
+                    if (tid == 0) L.scal[SC_DAMP] *= 10.0;
+                    break;
+                }
+                master_eval(A, L, L.xt, L.rt, tid);
+            }
+            __syncthreads();
+            if (L.istate[IS_ACCEPT] || L.scal[SC_DAMP] > 1.0e12) break;
+        }
+        __syncthreads();
+        // ---- take the multipliers; take the step if one was accepted ------------------------------------------------
+        if (converged || L.istate[IS_ACCEPT]) {
+            if (tid == 0) {
+                for (int o = 0; o < n_out; o++) L.mu[o] = 0.0;
+                for (int a = 0; a < L.istate[IS_NACT0]; a++) L.mu[L.act[a + MASTER_PACT]] = L.scal[24 + a];
+            }
+        }
+        if (converged) { if (tid == 0) L.istate[IS_DONE] = 1; __syncthreads(); break; }
+        if (!L.istate[IS_ACCEPT]) { if (tid == 0) { L.istate[IS_DONE] = 1; L.istate[IS_STATUS] = 1; } __syncthreads(); break; }   // stalled
+        for (int j = tid; j < S; j += MASTER_THREADS) L.x[j] = L.xt[j];
+        for (int o = tid; o < n_out; o += MASTER_THREADS) L.r[o] = L.rt[o];
+        if (tid == 0) { L.scal[SC_F] = L.scal[SC_FT]; L.istate[IS_IT] = it + 1; if (L.istate[IS_TINY] >= 2) L.istate[IS_DONE] = 1; }
+        __syncthreads();
+    }
+    __syncthreads();
+    // ---- results ------------------------------------------------------------------------------------------------------
+    for (int j = tid; j < S; j += MASTER_THREADS) A.x[j] = L.x[j];
+    for (int o = tid; o < n_out; o += MASTER_THREADS) { A.mu[o] = L.mu[o]; A.out[MASTER_OUT + o] = L.r[o]; }
+    if (tid == 0) {
+        A.out[0] = L.scal[SC_F]; A.out[1] = L.scal[SC_LAM]; A.out[2] = L.scal[SC_KKT]; A.out[3] = L.scal[SC_SPREAD];
+        A.out[4] = L.istate[IS_IT]; A.out[5] = L.istate[IS_EVALS]; A.out[6] = L.istate[IS_SOLVES]; A.out[7] = L.istate[IS_STATUS];
+        A.out[8] = L.scal[SC_DAMP]; A.out[9] = L.scal[SC_LAMX];
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// phase 1: multiplicative algorithm on the full problem.  For the p-norm surrogate  f = || (r_o)_o ||_p  the update
+//     x_i <- x_i * ( sum_o wgt_o c_i q_{o,i} / s_o ) / ( sum_o wgt_o r_o ),     wgt_o ~ r_o^(p-1),  q_{o,i} = -dV_o/dm_i >= 0
+// keeps sum x = 1 exactly in exact arithmetic (V_o is homogeneous of degree -1: sum_i x_i c_i q_{o,i} = V_o) and is monotone
+// for a single output (the classical algorithm for c-optimal design weights).  No projection, no line search, no reduction:
+// one evaluation (Phi pass + solve + gradient tiles) and this elementwise kernel per iteration.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ma_update(int64_t L, int n_out, const double *__restrict__ var, const int32_t *__restrict__ status,
+                                                   const double *__restrict__ grad, const int64_t *__restrict__ goff,
+                                                   const int32_t *__restrict__ invmap, const double *__restrict__ s,
+                                                   const double *__restrict__ cc, double p, double *__restrict__ x, double *__restrict__ m)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    double rmax = 0.0;
+    bool ok = true;
+    for (int o = 0; o < n_out; o++) { ok = ok && status[o] == BLUEST_EVAL_OK; rmax = fmax(rmax, var[o] / s[o]); }
+    if (!ok || !(rmax > 0.0) || !isfinite(rmax)) return;               // not evaluable: leave the iterate alone (uniform across the grid)
+    double num = 0.0, den = 0.0;
+    for (int o = 0; o < n_out; o++) {
+        const double ro = var[o] / s[o];
+        const double w = n_out == 1 ? 1.0 : pow(ro / rmax, p - 1.0);
+        den = fma(w, ro, den);
+        const int32_t li = invmap ? invmap[(int64_t)o * L + i] : (int32_t)i;
+        if (li >= 0) num = fma(w / s[o], -grad[goff[o] + li], num);
+    }
+    const double xn = x[i] * cc[i] * num / den;
+    x[i] = xn;
+    m[i] = cc[i] * xn;
+}
+
+// allocation of the full problem from a support vector: m_i = c_i ((1 - eps) x_S[i in S] + eps / L)
+__global__ __launch_bounds__(256) void k_support_point(int64_t L, int S, const int64_t *__restrict__ sup, const double *__restrict__ xs,
+                                                       const double *__restrict__ cc, double eps, double *__restrict__ m)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    int lo = 0, hi = S;                                   // sup is ascending: binary search
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sup[mid] < i) lo = mid + 1; else hi = mid; }
+    const double xi = (lo < S && sup[lo] == i) ? xs[lo] : 0.0;
+    m[i] = cc[i] * ((1.0 - eps) * xi + eps / (double)L);
+}
+
+// pricing: c_i = cc_i sum_o (mu_o / s_o) q_{o,i} for every group; every workgroup reports its PRICE_TOP largest (value, index)
+#define PRICE_TOP 16
+#define PRICE_BLOCKS 64
+__global__ __launch_bounds__(256) void k_price(int64_t L, int n_out, const double *__restrict__ grad, const int64_t *__restrict__ goff,
+                                               const int32_t *__restrict__ invmap, const double *__restrict__ mu,
+                                               const double *__restrict__ s, const double *__restrict__ cc, int S,
+                                               const int64_t *__restrict__ sup, double *__restrict__ c_sup,
+                                               double *__restrict__ top_val, int64_t *__restrict__ top_idx)
+{
+    __shared__ double wv[4];
+    __shared__ int64_t wi[4];
+    __shared__ int wt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double best = -1.0;
+    int64_t besti = -1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < L; i += (int64_t)gridDim.x * 256) {
+        double c = 0.0;
+        for (int o = 0; o < n_out; o++) {
+            const int32_t li = invmap ? invmap[(int64_t)o * L + i] : (int32_t)i;
+            if (li >= 0 && mu[o] > 0.0) c = fma(mu[o] / s[o], -grad[goff[o] + li], c);
+        }
+        c *= cc[i];
+        if (c > best) { best = c; besti = i; }             // ascending scan: ties keep the smaller index
+    }
+    if (blockIdx.x == 0)                                   // reduced costs of the support entries themselves
+        for (int j = tid; j < S; j += 256) {
+            const int64_t i = sup[j];
+            double c = 0.0;
+            for (int o = 0; o < n_out; o++) {
+                const int32_t li = invmap ? invmap[(int64_t)o * L + i] : (int32_t)i;
+                if (li >= 0 && mu[o] > 0.0) c = fma(mu[o] / s[o], -grad[goff[o] + li], c);
+            }
+            c_sup[j] = c * cc[i];
+        }
+    for (int r = 0; r < PRICE_TOP; r++) {
+        // block argmax (ties: smaller index), fixed order
+        double v = best; int64_t ix = besti; int who = tid;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double v2 = __shfl_xor(v, off, 64);
+            const long long i2 = __shfl_xor((long long)ix, off, 64);
+            const int w2 = __shfl_xor(who, off, 64);
+            if (v2 > v || (v2 == v && i2 >= 0 && (ix < 0 || i2 < ix))) { v = v2; ix = i2; who = w2; }
+        }
+        if (lane == 0) { wv[wave] = v; wi[wave] = ix; wt[wave] = who; }
+        __syncthreads();
+        double bv = wv[0]; int64_t bi = wi[0]; int bt = wt[0];
+        for (int w = 1; w < 4; w++)
+            if (wv[w] > bv || (wv[w] == bv && wi[w] >= 0 && (bi < 0 || wi[w] < bi))) { bv = wv[w]; bi = wi[w]; bt = wt[w]; }
+        if (tid == 0) { top_val[blockIdx.x * PRICE_TOP + r] = bv; top_idx[blockIdx.x * PRICE_TOP + r] = bi; }
+        if (tid == bt) { best = -1.0; besti = -1; }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+static int master_lds_limit()
+{
+    static int limit_of[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 64 << 10;
+    if (!limit_of[dev]) {
+        hipDeviceProp_t prop;
+        limit_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? (int)std::min<size_t>(prop.sharedMemPerBlock, 160u << 10) : (64 << 10);
+    }
+    return limit_of[dev];
+}
+
+extern "C" int bluest_master_max_support(bluest_plan_t plan, int *s_max)
+{
+    if (!plan || !s_max) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
+    int rc = require_gpu(); if (rc) return rc;
+    int KM = 0;
+    for (const auto &od : plan->outs) KM = std::max(KM, od.K);
+    const int n_out = (int)plan->outs.size();
+    const size_t limit = (size_t)master_lds_limit() - 1024;
+    int S = MASTER_SMAX;
+    while (S > 0 && master_lds_bytes(plan->N, n_out, S, KM) > limit) S -= 4;
+    *s_max = S;                                            // 0: this problem does not fit the single-workgroup master
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_master_newton(bluest_plan_t plan, int S, const int64_t *support_host, const double *cc_host, const double *s_dev,
+                                    const double *bg_dev, double eps_bg, double *x_dev, double *mu_dev, double tol, int maxit,
+                                    double *out_dev, void *stream)
+{
+    if (!plan || !support_host || !cc_host || !s_dev || !x_dev || !mu_dev || !out_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
+    int rc = require_gpu(); if (rc) return rc;
+    if (S <= 0 || S > MASTER_SMAX) return fail(BLUEST_ERR_ARG, "support size %d out of range (1..%d)", S, MASTER_SMAX);
+    if (eps_bg < 0.0 || eps_bg >= 1.0 || (eps_bg > 0.0 && !bg_dev)) return fail(BLUEST_ERR_ARG, "background weight / matrices inconsistent");
+    const int n_out = (int)plan->outs.size(), N = plan->N;
+    // host-side maps, built once per plan: global group index -> (local index per output); offsets of the size classes
+    if (plan->inv_host.empty()) {
+        plan->inv_host.resize(n_out);
+        for (int o = 0; o < n_out; o++) {
+            const OutputDesc &od = plan->outs[o];
+            plan->inv_host[o].assign((size_t)plan->L, -1);
+            for (int64_t t = 0; t < od.L_o; t++) plan->inv_host[o][(size_t)od.mapping[t]] = (int32_t)t;
+        }
+    }
+    int KM = 1;
+    std::vector<int32_t> kk((size_t)S);
+    std::vector<int64_t> boff((size_t)n_out * S, -1);
+    std::vector<uint8_t> idx;
+    std::vector<std::vector<int64_t>> members((size_t)S);
+    for (int j = 0; j < S; j++) {
+        const int64_t gi = support_host[j];
+        if (gi < 0 || gi >= plan->L || (j > 0 && gi <= support_host[j - 1])) return fail(BLUEST_ERR_ARG, "support must be strictly ascending indices in [0, L_global)");
+        bool found = false;
+        for (int o = 0; o < n_out; o++) {
+            const OutputDesc &od = plan->outs[o];
+            const int32_t li = plan->inv_host[o][(size_t)gi];
+            if (li < 0) continue;
+            int64_t first = 0, goff = 0, ioff = 0;         // size class of local index li
+            int k = 1;
+            for (; k <= od.K; k++) {
+                if (li < first + od.sizes[k - 1]) break;
+                first += od.sizes[k - 1]; goff += od.sizes[k - 1] * k; ioff += od.sizes[k - 1] * k * k;
+            }
+            boff[(size_t)o * S + j] = ioff + (li - first) * (int64_t)k * k;
+            if (!found) {
+                found = true;
+                kk[j] = k;
+                members[j].assign(od.groups.begin() + goff + (li - first) * k, od.groups.begin() + goff + (li - first + 1) * k);
+            }
+        }
+        if (!found) return fail(BLUEST_ERR_ARG, "group %lld belongs to no output", (long long)gi);
+        KM = std::max(KM, kk[j]);
+    }
+    const size_t lds = master_lds_bytes(N, n_out, S, KM);
+    if (lds > (size_t)master_lds_limit()) return fail(BLUEST_ERR_ARG, "master problem needs %zu bytes of LDS (limit %d)", lds, master_lds_limit());
+    idx.assign((size_t)S * KM, 0);
+    for (int j = 0; j < S; j++) for (int l = 0; l < kk[j]; l++) idx[(size_t)j * KM + l] = (uint8_t)members[j][l];
+    // one descriptor blob: [invcov pointers][boff][cc][kk][idx]
+    const size_t b_ptr = (size_t)n_out * sizeof(void *), b_off = (size_t)n_out * S * sizeof(int64_t), b_cc = (size_t)S * sizeof(double),
+                 b_kk = (((size_t)S * sizeof(int32_t)) + 7) & ~(size_t)7, b_idx = ((size_t)S * KM + 7) & ~(size_t)7;
+    const size_t total = b_ptr + b_off + b_cc + b_kk + b_idx;
+    std::vector<unsigned char> blob(total);
+    unsigned char *h = blob.data();
+    for (int o = 0; o < n_out; o++) { const double *p = plan->outs[o].d_invcov; memcpy(h + o * sizeof(void *), &p, sizeof(void *)); }
+    memcpy(h + b_ptr, boff.data(), b_off);
+    memcpy(h + b_ptr + b_off, cc_host, b_cc);
+    memcpy(h + b_ptr + b_off + b_cc, kk.data(), (size_t)S * sizeof(int32_t));
+    memcpy(h + b_ptr + b_off + b_cc + b_kk, idx.data(), (size_t)S * KM);
+    DeviceScopeN scope(plan->device);
+    if (plan->master_bytes < total) {
+        if (plan->d_master) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(plan->d_master); plan->d_master = nullptr; }
+        const size_t want = std::max<size_t>(total * 2, 64u << 10);
+        HIP_TRY(hipMalloc(&plan->d_master, want));
+        plan->master_bytes = want;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(plan->d_master, h, total, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));                    // the staging vector dies with this call
+    unsigned char *d = (unsigned char *)plan->d_master;
+    MasterArgs A;
+    A.N = N; A.n_out = n_out; A.S = S; A.KM = KM;
+    A.eps_bg = eps_bg; A.tol = tol; A.act_tol = 1.0e-6; A.floor_x = 1.0e-6; A.maxit = maxit;
+    A.fb = eps_bg > 0.0 ? 0.0 : 0.9;       // without the background V has kinks where a model drops out: stay inside the face
+    A.invcov = (const double *const *)d;
+    A.boff = (const int64_t *)(d + b_ptr);
+    A.cc = (const double *)(d + b_ptr + b_off);
+    A.kk = (const int32_t *)(d + b_ptr + b_off + b_cc);
+    A.idx = (const uint8_t *)(d + b_ptr + b_off + b_cc + b_kk);
+    A.s = s_dev; A.bg = eps_bg > 0.0 ? bg_dev : nullptr;
+    A.x = x_dev; A.mu = mu_dev; A.out = out_dev;
+    static size_t granted = 0;
+    if (lds > granted) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_master_newton, hipFuncAttributeMaxDynamicSharedMemorySize, (int)master_lds_limit()));
+        granted = (size_t)master_lds_limit();
+    }
+    hipLaunchKernelGGL(k_master_newton, dim3(1), dim3(MASTER_THREADS), lds, st, A);
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_ma_update(bluest_plan_t plan, const double *var_dev, const int32_t *status_dev, const double *grad_dev,
+                                const double *s_dev, const double *cc_dev, double p, double *x_dev, double *m_dev, void *stream)
+{
+    if (!plan || !var_dev || !status_dev || !grad_dev || !s_dev || !cc_dev || !x_dev || !m_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
+    const int n_out = (int)plan->outs.size();
+    hipLaunchKernelGGL(k_ma_update, dim3((unsigned)((plan->L + 255) / 256)), dim3(256), 0, (hipStream_t)stream, plan->L, n_out, var_dev,
+                       status_dev, grad_dev, plan->d_goff, plan->identity ? nullptr : plan->d_invmap, s_dev, cc_dev, p, x_dev, m_dev);
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_support_point(int64_t L, int S, const int64_t *sup_dev, const double *xs_dev, const double *cc_dev, double eps,
+                                    double *m_dev, void *stream)
+{
+    if (!sup_dev || !xs_dev || !cc_dev || !m_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (L <= 0 || S <= 0) return fail(BLUEST_ERR_ARG, "sizes out of range");
+    int rc = require_gpu(); if (rc) return rc;
+    hipLaunchKernelGGL(k_support_point, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, (hipStream_t)stream, L, S, sup_dev, xs_dev, cc_dev, eps, m_dev);
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}
+
+extern "C" int bluest_price(bluest_plan_t plan, const double *grad_dev, const double *mu_dev, const double *s_dev, const double *cc_dev,
+                            int S, const int64_t *sup_dev, double *c_sup_dev, double *top_val_dev, int64_t *top_idx_dev, void *stream)
+{
+    if (!plan || !grad_dev || !mu_dev || !s_dev || !cc_dev || !sup_dev || !c_sup_dev || !top_val_dev || !top_idx_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
+    const int n_out = (int)plan->outs.size();
+    hipLaunchKernelGGL(k_price, dim3(PRICE_BLOCKS), dim3(256), 0, (hipStream_t)stream, plan->L, n_out, grad_dev, plan->d_goff,
+                       plan->identity ? nullptr : plan->d_invmap, mu_dev, s_dev, cc_dev, S, sup_dev, c_sup_dev, top_val_dev, top_idx_dev);
+    HIP_TRY(hipGetLastError());
+    return BLUEST_OK;
+}

@@ -617,23 +617,15 @@ static hipError_t pool_free(void *p, bool recycle = true)
     return hipFree(p);
 }
 
-// current device for the lifetime of the object (a plan's memory and kernels live on plan->device, whatever device is current
-// in the thread that happens to drop or use it)
-struct DeviceScope {
-    int prev = -1;
-    bool switched = false;
-    explicit DeviceScope(int dev)
-    {
-        if (hipGetDevice(&prev) == hipSuccess && prev != dev && dev >= 0) switched = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
-};
+typedef DeviceScopeN DeviceScope;      // plan.hpp
 
 static void plan_free_device(bluest_plan_s *p)
 {
     if (p->d_arena) (void)pool_free(p->d_arena);
     if (p->d_scratch) (void)pool_free(p->d_scratch);
-    p->d_arena = p->d_scratch = nullptr;
+    if (p->d_master) (void)hipFree(p->d_master);
+    p->d_arena = p->d_scratch = p->d_master = nullptr;
+    p->master_bytes = 0;
     for (auto &od : p->outs) {
         if (od.d_invcov) (void)pool_free(od.d_invcov);
         if (od.d_groups && od.owns_groups) (void)pool_free(od.d_groups);

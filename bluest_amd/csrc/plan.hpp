@@ -61,6 +61,22 @@ struct bluest_plan_s {
     size_t scratch_bytes = 0;
     int32_t *d_status = nullptr; // workspace for eval when caller passes NULL
     unsigned int *d_ticket = nullptr;   // arrival counter of the fused solve + line-search decision (bluest_plan_eval_decide)
+    // second-order finish (newton.hip): descriptor blob of the master problem (plain hipMalloc, grown on demand) and the
+    // host-side global -> local group maps it is built from
+    void *d_master = nullptr;
+    size_t master_bytes = 0;
+    std::vector<std::vector<int32_t>> inv_host;
+};
+
+// current device for the lifetime of the object (a plan's memory and kernels live on plan->device)
+struct DeviceScopeN {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceScopeN(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev && dev >= 0) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceScopeN() { if (switched) (void)hipSetDevice(prev); }
 };
 
 

@@ -13,6 +13,7 @@ from . import host
 from .host import host_section, in_host_section
 from .spg import spg
 from .spg_device import DeviceSpg, ShardedDeviceSpg
+from .colgen import colgen_solve
 
 host.warm()     # first-touch work of host_section happens at import, never inside a timed constructor
 
@@ -37,22 +38,10 @@ spg_sap_default_params = {
     "slots": 1,               # line-search trial points launched per step of the device loop (a rejected last one carries over)
     "check_every": 20,        # steps between host looks at the device state
     "scaling_floor": 1.0e-8,  # > 0: scaled SPG, steps and projections in the metric diag(1/max(x, floor)); 0: plain SPG
-    "polish": True,           # working set: run the last continuation stage on the plan restricted to the largest entries,
-    "polish_support": 16,     #   polish_support * N of them, price the excluded groups with the full gradient and let those
-    "polish_rounds": 2,       #   below the support's multiplier by price_tol (relative) join, at most polish_rounds times
-    "price_tol": 1.0e-3,
-    "price_interior": 1.0e-3, #   pricing point = (1 - this) * x + this * uniform
-    "polish_slots": 0,            # trial points per step on the working set (0 = as "slots")
-    "polish_stall_window": 60,    # stall window (iterations) of the runs on the working set: 100 -> 60 costs < 3e-5 in the objective on the
-                                  # hardest test problem (1e-7 at the headline size) and saves 12-15 % of the solve
-    "polish_stages": (2048.0, 65536.0),  # smoothing exponents on the working set (multi-output): 65536 is the max for all
-                              # practical purposes but keeps near-ties smooth -- the plain max there cost 40 % more time on the
-                              # hard cases (line-search stalls at the kinks) for objectives equal to 1e-5
-    "polish_full_stages": 0,  # how many leading stages run on the full problem (0 = all but the last)
-    "polish_full_loose": 2.0, # stall tolerance of the full-problem stages in working-set mode, in units of rel_tol: the working set
-                              # is drawn from where these stages stop.  Chosen together with stall_window on 28 multi-output
-                              # shapes (tools/param_ab.sh, n = 15..24): (loose, window) = (5, 100): worst end point 2.5e-4 above
-                              # the best of all variants, mean 2.0e-5; (2, 60): 4.4e-5 / 9.6e-6 at the same total time (+1 %)
+    "method": "newton",       # "newton": multiplicative phase + column generation with a Newton master on the support and a
+                              #   certified duality gap (bluest_amd/colgen.py, csrc/newton.hip); "spg": first-order only (also
+                              #   the fall-back when the master problem does not fit one workgroup, and for sharded plans)
+    "newton": None,           # overrides for colgen_solve (ma_iterations, background, enter_per_round, ...)
     "sparsify_tol": 1.0e-5,   # final support selection: keep the fewest largest entries whose objective is within this (relative)
                               # of the full iterate's (0 = off)
     "prune_tol": 1.0e-7,      # (when that is off) drop the smallest entries holding less than this share of the budget
@@ -171,23 +160,6 @@ def restrict_plan(plan, keep):
         raise
 
 
-def support_multipliers(G, x):
-    """mu >= 0, sum mu = 1 minimising the x-weighted variance over the support of sum_o mu_o G[o]: the multipliers of the active
-    outputs in the KKT conditions of min_x max_o V_o(x) over the simplex (stationarity: the combined gradient is constant where
-    x > 0).  G: (n_active, support) gradients, x: (support,) allocation"""
-    n_act = G.shape[0]
-    if n_act == 1:
-        return np.ones(1)
-    from scipy.optimize import nnls
-    w = np.maximum(x, 0.0)
-    w = w / w.sum()
-    Gc = G - (G @ w)[:, None]
-    A = (Gc * np.sqrt(w)[None, :]).T                       # (support, n_active)
-    rho = 1.0e3 * max(np.abs(A).max(), 1.0e-300)
-    mu, _ = nnls(np.vstack([A, rho * np.ones((1, n_act))]), np.concatenate([np.zeros(A.shape[0]), [rho]]))
-    return mu / mu.sum() if mu.sum() > 0.0 else np.full(n_act, 1.0 / n_act)
-
-
 class SpgAllocator(object):
     """SPG in the scaled variable x = cost*m/B over the unit simplex; all vectors live in HBM.
 
@@ -245,6 +217,19 @@ class SpgAllocator(object):
         if not np.isfinite(ratios(plan, scale_h * x)):
             raise BLUESTError("SPG: the initial allocation does not sample model 0 / is infeasible")
         tot = {"it": 0, "count": 0}
+        if prm["method"] == "newton" and isinstance(plan, Plan):
+            xn, ninfo = colgen_solve(plan, w, s, B, x0=None if x0 is None else x, prm=prm.get("newton"))
+            if xn is not None:
+                m = scale_h * xn
+                if budget is None:
+                    m = m * ratios(plan, m)    # rescale so that max_o V_o/eps_o^2 = 1 (V is homogeneous of degree -1)
+                self.info = {"it": ninfo["newton_it"], "count": ninfo["full_evals"] + ninfo["master_evals"], "gpmax": ninfo["kkt"],
+                             "f": ninfo["F"], "solver_info": 0, "fevals": ninfo["full_evals"], "gevals": ninfo["full_evals"],
+                             "pruned": int(L - ninfo["support"]), "method": "newton", "certified_gap": ninfo["gap"],
+                             "rounds": ninfo["rounds"], "master_evals": ninfo["master_evals"], "multipliers": ninfo["mu"]}
+                return m
+            if self.verbose:
+                print("second-order finish unavailable (%s); first-order SPG only" % ninfo)
 
         def run_stages(pl, sc_h, sc, xc, stages, polish_last, loose=5.0, window=None, slots=None):
             """the continuation stages on plan `pl` (variables scaled by sc) from xc; polish_last: the last stage gets the
@@ -290,74 +275,8 @@ class SpgAllocator(object):
                     f_prev = f_abs
             return out
 
-        # (working set only for long vectors: below a few thousand groups the full problem is cheap and converges as well)
-        working_set = bool(prm["polish"]) and self.subplan is not None and L > max(4096, 4 * int(prm["polish_support"]) * N)
-        if not working_set:
-            res = run_stages(plan, scale_h, scale, x, p_list, True)
-            x = res["x"]
-        else:
-            # WORKING SET: the smooth stages locate the support on the full problem; the last stages (where a first-order method
-            # crawls when it drags thousands of near-zero entries along) run on the plan RESTRICTED to the largest entries; the
-            # full operator then prices the excluded groups at that point (entries whose scaled gradient lies below the
-            # support's multiplier would lower the objective) and they join the set for another round.  Restricted and full
-            # operator agree exactly on allocations supported on the set.
-            n_full = int(prm["polish_full_stages"]) if prm.get("polish_full_stages") else max(1, len(p_list) - 1)
-            res = run_stages(plan, scale_h, scale, x, p_list[:max(1, min(n_full, len(p_list)))], False,
-                             loose=float(prm["polish_full_loose"]))
-            x = res["x"]
-            S = min(L, int(prm["polish_support"]) * N)
-            keep = np.sort(np.argsort(-x, kind="stable")[:S])
-            # on the restricted plan an iteration is cheap, so a sharp smooth max goes first again; the best point by the TRUE
-            # objective over all rounds is returned
-            sub_stages = [float(q) for q in prm["polish_stages"]] if n_out > 1 else [np.inf]
-            best_x, best_f, best_res = None, np.inf, None
-            for rnd in range(int(prm["polish_rounds"])):
-                try:
-                    sub = self.subplan(keep)
-                except BLUESTError:
-                    sub = None
-                if sub is None:
-                    res_full = run_stages(plan, scale_h, scale, x, p_list[-1:], True)   # cannot restrict (an output would lose model 0)
-                    if res_full is not None:
-                        res, x = res_full, res_full["x"]
-                    break
-                res_sub = run_stages(sub, scale_h[keep], to_dev(scale_h[keep]), x[keep] / x[keep].sum(), sub_stages, True,
-                                     window=int(prm["polish_stall_window"]), slots=int(prm["polish_slots"]) or None)
-                if res_sub is None:                                           # iteration budget (maxit) exhausted
-                    break
-                res = res_sub
-                x = np.zeros(L)
-                x[keep] = res["x"]
-                # pricing at the polished point.  The multipliers mu_o of the active outputs are the ones the KKT system on the
-                # support defines (sum_o mu_o g_o constant where x > 0): a smooth-max weight of outputs that tie to 1e-6 is ~1/n
-                # whatever the true multipliers are, and reduced costs priced with it miss entering groups (measured: 2.8e-4
-                # above the optimum on the n = 16, two-output test problem).
-                f_here = ratios(plan, scale_h * x)
-                if f_here < best_f:
-                    best_x, best_f, best_res = x.copy(), f_here, res
-                # ... priced at a slightly INTERIOR point: V drops the models nobody samples (misc.py:464-470: |m| <= 1e-6), so at
-                # a sparse point the gradient is blind to a group whose benefit is to bring such a model back
-                eps_in = float(prm["price_interior"])
-                xi = (1.0 - eps_in) * x + eps_in / L
-                var, grad, status = plan.eval(scale_h * xi)
-                r = var[0].cpu().numpy() / s
-                act = np.flatnonzero(r >= r.max() * (1.0 - 1.0e-3))
-                G = plan.output_gradients(grad[0])[act] * (scale_h / s[act][:, None])      # scaled dV_o/dx of the active outputs
-                mu = support_multipliers(G[:, keep], xi[keep])
-                g = mu @ G
-                theta = float(g[keep] @ xi[keep]) / float(xi[keep].sum())     # multiplier of sum x = 1 on the support
-                viol = g - theta
-                viol[keep] = 0.0
-                enter = np.flatnonzero(viol < -float(prm["price_tol"]) * abs(theta))
-                if len(enter) == 0:
-                    break
-                if len(enter) > S // 2:
-                    enter = enter[np.argsort(viol[enter], kind="stable")[:S // 2]]
-                keep = np.sort(np.concatenate([keep[x[keep] > 0], enter]))
-                x[enter] = 1.0e-6 / max(len(enter), 1)                        # seed: the scaled metric moves zeros slowly
-                x = x / x.sum()
-            if best_x is not None:
-                x, res = best_x, best_res
+        res = run_stages(plan, scale_h, scale, x, p_list, True)
+        x = res["x"]
         xs = x
         # support selection by objective: a first-order iterate keeps hundreds of entries that together hold ~1e-4 of the
         # budget (the optimum sits on <= N entries per output; the reference's SDP solvers return such a point).  Keep the S

@@ -310,6 +310,43 @@ int bluest_xchg_allreduce_sum(bluest_xchg_t xchg, double *buf_dev, int64_t n_dou
 int bluest_xchg_status(bluest_xchg_t xchg, int64_t *calls, int *timed_out);
 int bluest_xchg_destroy(bluest_xchg_t xchg);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Part 6 -- second-order finish of solver="spg" (NEW; csrc/newton.hip, restated in numpy in oracle/master_newton.py)
+ *
+ * The reference hands  min_m max_o V_o(m)/s_o  s.t.  cost.m = B, m >= 0  to third-party NLP solvers together with the Hessian
+ * of bluest/misc.py:497-503 / bluest/cmisc.cpp:74-97 (bluest/sap.py:387-456, bluest/mosap.py:578-673).  Here, in the scaled
+ * variable x_i = cost_i m_i / B on the unit simplex:
+ *   phase 1  bluest_ma_update       multiplicative algorithm on ALL groups (one evaluation + one elementwise kernel per step)
+ *   phase 2  bluest_master_newton   Levenberg-Marquardt damped active-set Newton (SQP) on a support of <= 64 groups, one launch of
+ *                                   one workgroup per master problem;
+ *            bluest_support_point   support vector -> allocation of the full problem (+ uniform background of weight eps);
+ *            bluest_price           reduced costs c_i = (B/cost_i) sum_o (mu_o/s_o) v_{o,g_i}^T C_{i,o}^-1 v_{o,g_i} of all groups
+ *                                   from the gradient at that point: candidates to enter the support, and max_i c_i, which gives
+ *                                   the certified bound  F* >= A^2 / (4 max_i c_i),  A = 2 sum_o (mu_o/s_o) V_o  (weak duality).
+ * ---------------------------------------------------------------------------------------------------- */
+/* largest support the single-workgroup master can hold for this plan (LDS budget); 0: does not fit */
+int bluest_master_max_support(bluest_plan_t plan, int *s_max);
+/* support_host: S strictly ascending GLOBAL group indices (host); cc_host: B / cost_j (host, S); s_dev: output scales (n_out);
+ * bg_dev: n_out x N x N matrices eps_bg * Phi_o(uniform allocation) (device; may be NULL when eps_bg == 0);
+ * x_dev (S): start in, solution out; mu_dev (n_out): multipliers in (any, e.g. 1/n_out) / out;
+ * out_dev (16 + n_out doubles): F, lam, kkt residual, spread, iterations, evaluations, linear solves, status (0 converged,
+ * 1 stalled, 2 start not evaluable), damping, lam at x, ..., then r_o = V_o/s_o at the solution.  Asynchronous on `stream`
+ * after one small synchronous descriptor upload. */
+int bluest_master_newton(bluest_plan_t plan, int S, const int64_t *support_host, const double *cc_host, const double *s_dev,
+                         const double *bg_dev, double eps_bg, double *x_dev, double *mu_dev, double tol, int maxit,
+                         double *out_dev, void *stream);
+/* x_i <- x_i * cc_i * sum_o wgt_o q_{o,i}/s_o / sum_o wgt_o r_o,  m_i = cc_i x_i;  var/status/grad as bluest_plan_eval left them
+ * for the allocation m; wgt_o ~ r_o^(p-1) (p-norm surrogate of the max) */
+int bluest_ma_update(bluest_plan_t plan, const double *var_dev, const int32_t *status_dev, const double *grad_dev,
+                     const double *s_dev, const double *cc_dev, double p, double *x_dev, double *m_dev, void *stream);
+/* m_i = cc_i ((1 - eps) x_S[i in S] + eps / L); sup_dev ascending */
+int bluest_support_point(int64_t L, int S, const int64_t *sup_dev, const double *xs_dev, const double *cc_dev, double eps,
+                         double *m_dev, void *stream);
+/* c_sup_dev (S): c_i of the support entries; top_val_dev / top_idx_dev (64 * 16): per workgroup the 16 largest (c_i, i) */
+#define BLUEST_PRICE_CANDIDATES 1024
+int bluest_price(bluest_plan_t plan, const double *grad_dev, const double *mu_dev, const double *s_dev, const double *cc_dev,
+                 int S, const int64_t *sup_dev, double *c_sup_dev, double *top_val_dev, int64_t *top_idx_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

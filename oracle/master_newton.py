@@ -60,8 +60,12 @@ class SupportProblem(object):
                     continue
                 g = self.groups[j]
                 PHI[np.ix_(g, g)] += m[j] * self.blocks[o][j]
+            idx = np.flatnonzero(np.diag(PHI) > 0.0)               # models nobody samples stay out (bluest/misc.py:467-470)
+            if len(idx) == 0 or idx[0] != 0:
+                continue
             try:
-                T = np.linalg.inv(PHI)
+                T = np.zeros((N, N))
+                T[np.ix_(idx, idx)] = np.linalg.inv(PHI[np.ix_(idx, idx)])
             except np.linalg.LinAlgError:
                 continue
             if not np.isfinite(T).all() or T[0, 0] <= 0.0:
@@ -85,7 +89,7 @@ class SupportProblem(object):
         return (r, G, Hs, vs) if want_derivatives else r
 
 
-def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floor=1.0e-6, verbose=False):
+def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floor=1.0e-6, verbose=False, fb=None):
     """active-set Newton (SQP) on the support with Levenberg-Marquardt damping.  Works on rho_o = -1 / r_o (convex as well:
     1 / V_o is the Schur complement of Phi_o, concave and homogeneous of degree +1 in x; same minimisers; Newton does not crawl
     on it far from the optimum the way it does on the degree -1 function r_o, where a step is x -> 1.5 x).
@@ -95,6 +99,8 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floo
     valid for steps of the size of the background, so step LENGTH, not step fraction, is what must adapt).
     Returns dict(x, mu, lam, F, it, evals, kkt)"""
     S, n_out = prob.S, prob.n_out
+    if fb is None:
+        fb = 0.0 if prob.eps_bg > 0.0 else 0.9     # without the background V has kinks where a model drops out: stay inside the face
     x = np.maximum(np.asarray(x0, dtype=np.float64), 0.0)
     x = x / x.sum()
     mu = np.full(n_out, 1.0 / n_out) if mu0 is None else np.asarray(mu0, dtype=np.float64).copy()
@@ -105,6 +111,7 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floo
     if not np.isfinite(r.max()):
         raise ValueError("master: the starting point is not evaluable")
     kkt, lam = np.inf, 0.0
+    tiny_steps = 0
     for it in range(maxit):
         F = r.max()
         act0 = np.flatnonzero((r >= F * (1.0 - act_tol)) | (mu > 1.0e-12))
@@ -166,7 +173,7 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floo
                 glx = Gq @ mu_full
                 lam_x = -float(glx @ x)
                 rcx = glx + lam_x
-                pos = x > 0
+                pos = x > 1.0e-10                                  # entries below 1e-10 count as at the bound
                 kkt = max(float(np.abs(rcx[pos]).max()), float(np.maximum(-rcx[~pos], 0.0).max()) if (~pos).any() else 0.0) / max(abs(lam_x), 1e-300)
                 spread = float((F - r[act]).max() / F) if len(act) > 1 else 0.0
                 if verbose:
@@ -177,12 +184,35 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floo
             if pred < -0.5 * F:                                    # the model promises more than half of a positive objective
                 damp *= 10.0
                 continue
-            xt = np.maximum(x + d, 0.0)                            # projected step: entries that would turn negative become zero
+            # projected step: entries that would turn negative become zero; fb > 0 (no background): every entry keeps at least
+            # 1 - fb of its value, so that no model drops out of the information matrix inside the master (V has a kink there)
+            xt = np.maximum(x + d, (1.0 - fb) * x if fb > 0.0 else 0.0)
             xt = xt / xt.sum()
             rt = prob.evaluate(xt)
             info["evals"] += 1
             actual = rt.max() - F
-            if np.isfinite(rt.max()) and actual <= 1.0e-4 * min(pred, 0.0) + 1e-15 * F:
+            ok = np.isfinite(rt.max()) and actual <= 1.0e-4 * min(pred, 0.0) + 1e-15 * F
+            if not ok and len(act) > 1 and np.isfinite(rt.max()):
+                # near a tie of several outputs second-order errors split the tie and the exact max rejects a good SQP step (the
+                # Maratos effect).  Second-order correction: the minimum-norm (in M) step c that re-equalises the active outputs
+                # at the trial point to first order,  g_o.c - tau2 = -q_o(xt),  1.c = 0  -- the same K with another right-hand side
+                qt = -1.0 / rt[act]
+                rhs2 = np.concatenate([qt, [0.0, 0.0]])
+                try:
+                    z2 = np.linalg.solve(KK, rhs2)
+                except np.linalg.LinAlgError:
+                    z2 = None
+                if z2 is not None:
+                    c = np.zeros(S)
+                    c[fi] = -np.linalg.solve(Lc.T, Y @ z2[:p + 1])
+                    xt2 = np.maximum(x + d + c, (1.0 - fb) * x if fb > 0.0 else 0.0)
+                    xt2 = xt2 / xt2.sum()
+                    rt2 = prob.evaluate(xt2)
+                    info["evals"] += 1
+                    actual2 = rt2.max() - F
+                    if np.isfinite(rt2.max()) and actual2 <= 1.0e-4 * min(pred, 0.0) + 1e-15 * F:
+                        ok, xt, rt, actual = True, xt2, rt2, actual2
+            if ok:
                 accepted = True
                 ratio = actual / pred if pred < 0 else 1.0
                 if verbose:
@@ -192,6 +222,8 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floo
                 elif ratio < 0.1:
                     damp *= 10.0
                 break
+            if verbose:
+                print("        rejected attempt %d damp %.1e pred %.3e actual %.3e rt-F %s" % (attempt, damp, pred, actual, (rt - F)[act]))
             damp *= 10.0
             if damp > 1.0e12:
                 break
@@ -202,6 +234,10 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floo
             break
         x, r, mu = xt, rt, mu_full
         info["it"] = it + 1
+        # the objective cannot resolve the remaining improvement (the KKT residual left sits in entries of negligible mass)
+        tiny_steps = tiny_steps + 1 if abs(actual) <= 1.0e-13 * F else 0
+        if tiny_steps >= 2:
+            break
     info.update({"x": x, "mu": mu, "lam": lam, "F": float(r.max()), "r": r, "kkt": kkt})
     return info
 

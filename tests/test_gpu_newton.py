@@ -1,0 +1,92 @@
+"""
+GPU tests of the second-order finish (C-ABI Part 6, csrc/newton.hip) against its numpy restatement (oracle/master_newton.py)
+and against oracle-evaluated certificates.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from bluest_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("these tests need the GPU (run with -m gpu on the MI355X box)")
+    return torch
+
+
+def _support_problem(oracle, prob, keep, eps_bg, s):
+    """SupportProblem (numpy restatement) of a synthetic problem restricted to the groups `keep`"""
+    from oracle.master_newton import SupportProblem
+    n, kmax, n_out = prob["n"], prob["kmax"], prob["n_out"]
+    saps = [oracle.SparseOracleSAP(C, kmax, prob["groups"]) for C in prob["C"]]
+    sp0 = saps[0]
+    flat = [g for gk in sp0.groups for g in gk]
+    c = prob["budget"] / prob["costs"]
+
+    def block(o, i):
+        k = int(np.searchsorted(sp0.cumsizes, i, side="right"))
+        return saps[o].invcovs[k - 1].reshape(-1, k, k)[i - sp0.cumsizes[k - 1]]
+    phi_u = np.array([q.get_phi(c / sp0.L) for q in saps])
+    sp = SupportProblem(n, [flat[i] for i in keep], [[block(o, i) for i in keep] for o in range(n_out)], c[keep], s, eps_bg * phi_u, eps_bg)
+    return sp, phi_u, saps
+
+
+def _gpu_master(torch, plan, keep, cc_keep, s, bg, eps_bg, x0, mu0, tol=1e-10, maxit=60):
+    from bluest_amd._lib import check
+    from bluest_amd.plan import _stream
+    dev = plan.device
+    n_out = plan.n_out
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)      # noqa: E731
+    x_d, mu_d, s_d = to_dev(x0), to_dev(mu0), to_dev(s)
+    out_d = torch.zeros(16 + n_out, dtype=torch.float64, device=dev)
+    bg_d = None if bg is None else to_dev(bg)
+    keep = np.ascontiguousarray(keep, dtype=np.int64)
+    cc_keep = np.ascontiguousarray(cc_keep, dtype=np.float64)
+    with torch.cuda.device(dev):
+        check(plan.lib.bluest_master_newton(plan._h, len(keep), keep.ctypes.data, cc_keep.ctypes.data, s_d.data_ptr(),
+                                            None if bg_d is None else bg_d.data_ptr(), float(eps_bg), x_d.data_ptr(), mu_d.data_ptr(),
+                                            float(tol), int(maxit), out_d.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    return x_d.cpu().numpy(), mu_d.cpu().numpy(), out_d.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,kmax,n_out,S,eps_bg", [(8, 3, 1, 20, 1e-3), (8, 3, 2, 24, 1e-3), (10, 4, 3, 30, 1e-6), (20, 5, 8, 56, 1e-3)])
+def test_master_kernel_equals_numpy_restatement(gpu, oracle, n, kmax, n_out, S, eps_bg):
+    """one master problem from the same start: the single-workgroup kernel and the numpy restatement end at the same optimum
+    (objective to 1e-9, allocation to 1e-5, multipliers to 1e-4), both with a KKT residual below 1e-6"""
+    from oracle.master_newton import master_newton
+    from bluest_amd.plan import Plan
+    prob = synth.problem(n, kmax, n_out)
+    sizes = [len(g) for g in prob["groups"]]
+    plan = Plan(n, prob["K_tot"], [{"K": kmax, "sizes": sizes, "groups": prob["groups"], "C": prob["C"][o], "mapping": None} for o in range(n_out)])
+    rng = np.random.RandomState(5)
+    keep = np.sort(np.concatenate([[0], 1 + rng.choice(prob["K_tot"] - 1, S - 1, replace=False)]))
+    if eps_bg == 0.0:                                   # without background every model must be sampled by the support itself
+        keep = np.union1d(keep, np.arange(n))
+    s = 1.0 + 0.3 * rng.rand(n_out) if n_out > 1 else np.ones(1)
+    sp, phi_u, saps = _support_problem(oracle, prob, keep, eps_bg, s)
+    x0 = rng.rand(len(keep)) + 0.1
+    x0 /= x0.sum()
+    mu0 = np.full(n_out, 1.0 / n_out)
+    ref = master_newton(sp, x0, mu0=mu0, tol=1e-10)
+    assert ref["kkt"] <= 1e-6            # both stop at the tolerance or where the objective cannot resolve further progress
+    cc = prob["budget"] / prob["costs"]
+    x, mu, out = _gpu_master(gpu, plan, keep, cc[keep], s, None if eps_bg == 0.0 else eps_bg * phi_u, eps_bg, x0, mu0)
+    assert int(out[7]) == 0 and out[2] <= 1e-6, out[:10]
+    assert abs(out[0] / ref["F"] - 1) < 1e-9
+    assert np.abs(out[16:] / ref["r"] - 1).max() < 1e-8
+    assert np.abs(x - ref["x"]).max() < 1e-5 and abs(x.sum() - 1) < 1e-12 and x.min() >= 0
+    assert np.abs(mu - ref["mu"]).max() < 1e-4
+    # the kernel's objective is what the plan itself evaluates at that allocation (background included)
+    m = np.zeros(prob["K_tot"])
+    m[keep] = cc[keep] * x
+    m = (1 - eps_bg) * m + eps_bg * cc / prob["K_tot"]
+    var, _, st = plan.eval(m, want_grad=False)
+    assert (st.cpu().numpy() == 0).all()
+    assert abs((var[0].cpu().numpy() / s).max() / out[0] - 1) < 1e-10

@@ -76,7 +76,7 @@ SIGNATURES = {
     "bluest_master_newton": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp, c_f64, c_int, c_vp, c_vp],
     "bluest_ma_update": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp, c_vp],
     "bluest_support_point": [c_i64, c_int, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp],
-    "bluest_price": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "bluest_price": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "bluest_simplex_workspace_doubles": [c_i64, c_i64p],
     "bluest_simplex_project": [c_vp, c_vp, c_f64, c_f64, c_f64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
 }

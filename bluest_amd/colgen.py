@@ -26,7 +26,7 @@ class _Buffers(object):
 
     def __init__(self, dev, n_out, s_max):
         self.n_out, self.s_max = n_out, s_max
-        sizes = [("out", MASTER_OUT + n_out), ("xs", s_max), ("mu", n_out), ("var", n_out), ("csup", s_max), ("topv", N_CAND), ("topi", N_CAND)]
+        sizes = [("out", MASTER_OUT + n_out), ("xs", s_max), ("mu", n_out), ("var", n_out), ("y0", n_out), ("csup", s_max), ("topv", N_CAND), ("topi", N_CAND)]
         self.off, tot = {}, 0
         for name, n in sizes:
             self.off[name] = (tot, n)
@@ -115,7 +115,7 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
         keep = np.sort(np.argsort(-xh, kind="stable")[:S0])
         xs = xh[keep] / xh[keep].sum()
         mu = np.full(n_out, 1.0 / n_out)
-        best_lb, F_last, gap = 0.0, np.inf, np.inf
+        best_lb, F_last, gap, cert = 0.0, np.inf, np.inf, None
         x_full = None
         sup_d = torch.empty(s_max, dtype=torch.int64, device=dev)
         for stage, eps in enumerate(eps_list):
@@ -133,7 +133,7 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
                 check(lib.bluest_support_point(L, S, sup_d.data_ptr(), bufs.ptr("xs"), cc.data_ptr(), float(eps), m_d.data_ptr(), st))
                 check(lib.bluest_plan_eval(plan._h, m_d.data_ptr(), 1, L, 0.0, bufs.ptr("var"), grad.data_ptr(), plan.grad_len, status.data_ptr(), st))
                 check(lib.bluest_price(plan._h, grad.data_ptr(), bufs.ptr("mu"), s_d.data_ptr(), cc.data_ptr(), S, sup_d.data_ptr(),
-                                       bufs.ptr("csup"), bufs.ptr("topv"), bufs.ptr("topi"), st))
+                                       bufs.ptr("csup"), bufs.ptr("topv"), bufs.ptr("topi"), bufs.ptr("y0"), st))
                 h = bufs.fetch()                                  # the round's only synchronisation
                 out = h["out"]
                 info["rounds"] += 1
@@ -147,10 +147,12 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
                 pos = xs > 0.0
                 # certified bound (valid for ANY multipliers / vectors: weak duality), budget 1 in the scaled variable
                 a = mu / s
-                A = 2.0 * float(a @ h["var"])
+                A = 2.0 * float(a @ h["y0"])                      # y_{o,0} of the vectors the c_i were taken with (NOT V: see k_price)
                 cmax = max(float(h["topv"].max()), float(h["csup"][:S].max()))
                 lb = A * A / (4.0 * cmax) if cmax > 0.0 else 0.0
-                best_lb = max(best_lb, lb)
+                if lb > best_lb:                                  # the point + multipliers the bound was obtained at: a certificate
+                    best_lb = lb                                  # anybody can re-evaluate (tests do, with the CPU checker)
+                    cert = {"support": keep.copy(), "x": xs.copy(), "mu": mu.copy(), "background": float(eps), "lower_bound": lb}
                 gap = 1.0 - best_lb / F
                 level = float(h["csup"][:S][pos] @ xs[pos]) / float(xs[pos].sum())
                 order = np.argsort(-h["topv"], kind="stable")
@@ -216,5 +218,5 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
     x[keep] = np.maximum(xs, 0.0)
     x /= x.sum()
     info.update({"F": F_true, "F_background": F_last, "lower_bound": best_lb, "gap": 1.0 - best_lb / F_true, "mu": mu,
-                 "support": int((x > 0).sum()), "kkt": float(out[2])})
+                 "support": int((x > 0).sum()), "kkt": float(out[2]), "certificate": cert})
     return x, info

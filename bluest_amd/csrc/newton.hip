@@ -649,7 +649,8 @@ __global__ __launch_bounds__(256) void k_price(int64_t L, int n_out, const doubl
                                                const int32_t *__restrict__ invmap, const double *__restrict__ mu,
                                                const double *__restrict__ s, const double *__restrict__ cc, int S,
                                                const int64_t *__restrict__ sup, double *__restrict__ c_sup,
-                                               double *__restrict__ top_val, int64_t *__restrict__ top_idx)
+                                               double *__restrict__ top_val, int64_t *__restrict__ top_idx,
+                                               const double *__restrict__ v_ws, int N, double *__restrict__ y0)
 {
     __shared__ double wv[4];
     __shared__ int64_t wi[4];
@@ -666,6 +667,10 @@ __global__ __launch_bounds__(256) void k_price(int64_t L, int n_out, const doubl
         c *= cc[i];
         if (c > best) { best = c; besti = i; }             // ascending scan: ties keep the smaller index
     }
+    // y_{o,0}: component 0 of the vector the quadratic forms were taken with (row 0 of the inverse of the WHOLE information
+    // matrix).  The bound needs THIS number, not V: V restricts Phi to the models sampled with |m| > 1e-6 (bluest/misc.py:453-457),
+    // which the tiny background does not reach -- using V made the bound invalid on ill-conditioned data (6 % on the NS problem)
+    if (blockIdx.x == 0 && tid < n_out) y0[tid] = v_ws[(int64_t)tid * N];
     if (blockIdx.x == 0)                                   // reduced costs of the support entries themselves
         for (int j = tid; j < S; j += 256) {
             const int64_t i = sup[j];
@@ -846,13 +851,14 @@ extern "C" int bluest_support_point(int64_t L, int S, const int64_t *sup_dev, co
 }
 
 extern "C" int bluest_price(bluest_plan_t plan, const double *grad_dev, const double *mu_dev, const double *s_dev, const double *cc_dev,
-                            int S, const int64_t *sup_dev, double *c_sup_dev, double *top_val_dev, int64_t *top_idx_dev, void *stream)
+                            int S, const int64_t *sup_dev, double *c_sup_dev, double *top_val_dev, int64_t *top_idx_dev, double *y0_dev,
+                            void *stream)
 {
-    if (!plan || !grad_dev || !mu_dev || !s_dev || !cc_dev || !sup_dev || !c_sup_dev || !top_val_dev || !top_idx_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (!plan || !grad_dev || !mu_dev || !s_dev || !cc_dev || !sup_dev || !c_sup_dev || !top_val_dev || !top_idx_dev || !y0_dev) return fail(BLUEST_ERR_ARG, "null pointer");
     if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
     const int n_out = (int)plan->outs.size();
     hipLaunchKernelGGL(k_price, dim3(PRICE_BLOCKS), dim3(256), 0, (hipStream_t)stream, plan->L, n_out, grad_dev, plan->d_goff,
-                       plan->identity ? nullptr : plan->d_invmap, mu_dev, s_dev, cc_dev, S, sup_dev, c_sup_dev, top_val_dev, top_idx_dev);
+                       plan->identity ? nullptr : plan->d_invmap, mu_dev, s_dev, cc_dev, S, sup_dev, c_sup_dev, top_val_dev, top_idx_dev, plan->d_v, plan->N, y0_dev);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }

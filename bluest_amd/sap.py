@@ -227,6 +227,14 @@ class SpgAllocator(object):
                              "f": ninfo["F"], "solver_info": 0, "fevals": ninfo["full_evals"], "gevals": ninfo["full_evals"],
                              "pruned": int(L - ninfo["support"]), "method": "newton", "certified_gap": ninfo["gap"],
                              "rounds": ninfo["rounds"], "master_evals": ninfo["master_evals"], "multipliers": ninfo["mu"]}
+                cert = ninfo.get("certificate")
+                if cert is not None:
+                    # the certificate in the caller's terms: an allocation of cost B (the working budget), multipliers, and the
+                    # weight of the uniform background at which the bound  F*_B >= lower_bound  was obtained
+                    mc = np.zeros(L)
+                    mc[cert["support"]] = scale_h[cert["support"]] * np.maximum(cert["x"], 0.0) / max(float(np.maximum(cert["x"], 0.0).sum()), 1e-300)
+                    self.info["certificate"] = {"allocation": mc, "multipliers": cert["mu"], "background": cert["background"],
+                                                "lower_bound": cert["lower_bound"], "budget": B, "scales": s.copy()}
                 return m
             if self.verbose:
                 print("second-order finish unavailable (%s); first-order SPG only" % ninfo)

@@ -342,10 +342,13 @@ int bluest_ma_update(bluest_plan_t plan, const double *var_dev, const int32_t *s
 /* m_i = cc_i ((1 - eps) x_S[i in S] + eps / L); sup_dev ascending */
 int bluest_support_point(int64_t L, int S, const int64_t *sup_dev, const double *xs_dev, const double *cc_dev, double eps,
                          double *m_dev, void *stream);
-/* c_sup_dev (S): c_i of the support entries; top_val_dev / top_idx_dev (64 * 16): per workgroup the 16 largest (c_i, i) */
+/* after bluest_plan_eval (with gradient) of the priced allocation on the same stream.  c_sup_dev (S): c_i of the support
+ * entries; top_val_dev / top_idx_dev (64 * 16): per workgroup the 16 largest (c_i, i); y0_dev (n_out): component 0 of the
+ * vectors v_o the quadratic forms were taken with -- the bound's A = 2 sum_o (mu_o/s_o) y0_o */
 #define BLUEST_PRICE_CANDIDATES 1024
 int bluest_price(bluest_plan_t plan, const double *grad_dev, const double *mu_dev, const double *s_dev, const double *cc_dev,
-                 int S, const int64_t *sup_dev, double *c_sup_dev, double *top_val_dev, int64_t *top_idx_dev, void *stream);
+                 int S, const int64_t *sup_dev, double *c_sup_dev, double *top_val_dev, int64_t *top_idx_dev, double *y0_dev,
+                 void *stream);
 
 #ifdef __cplusplus
 }

@@ -395,6 +395,40 @@ class SparseOracleSAP(object):
         return var, grad, None
 
 
+def multiplier_certificate(saps, m, costs, mu, s=None, eps_in=1.0e-3):
+    """Weak-duality bound for  min F(m') = max_o V_o(m')/s_o  s.t.  costs.m' = B = costs.m, m' >= 0  from GIVEN multipliers mu (any
+    point of the simplex gives a valid bound) and y_o = row 0 of the inverse information matrix at the slightly interior point
+    (1 - eps_in) m + eps_in * (B / costs / K_tot)  (every model sampled there, so y has no blind components):
+        F* >= LB = A^2 / (4 B max_i c_i),   A = 2 sum_o (mu_o/s_o) y_{o,0},   c_i = sum_o (mu_o/s_o) y_{o,g_i}^T C_{i,o}^-1 y_{o,g_i} / w_i
+    (see optimality_certificate).  Everything is evaluated here: Phi by the objectiveK_c loop, its inverse by numpy, the
+    quadratic forms of ALL groups by gradK_c.  Returns (relative gap (F - LB)/F, F, LB)."""
+    O = len(saps)
+    m = np.asarray(m, dtype=np.float64)
+    w = np.asarray(costs, dtype=np.float64)
+    s = np.ones(O) if s is None else np.asarray(s, dtype=np.float64)
+    mu = np.maximum(np.asarray(mu, dtype=np.float64), 0.0)
+    mu = mu / mu.sum()
+    B = float(w @ m)
+    F = max(q.variance(m) / so for q, so in zip(saps, s))
+    mi = (1.0 - eps_in) * m + eps_in * (B / w / len(m))
+    a = mu / s
+    A, ci = 0.0, np.zeros(len(m))
+    for o, q in enumerate(saps):
+        if a[o] == 0.0:
+            continue
+        # y = Phi(mi)^-1 e_0 by a diagonally scaled solve (NOT numpy's pinv: its relative cut-off drops the directions that only
+        # the tiny interior weight samples, which is exactly where y must not be blind); any y gives a valid bound
+        PHI = q.get_phi(mi)
+        dsc = 1.0 / np.sqrt(np.diag(PHI))
+        y = dsc * np.linalg.solve(PHI * np.outer(dsc, dsc), dsc * np.eye(q.N, 1).ravel())
+        quad = np.concatenate([gradK(k, q.sizes[k], q.groups[k - 1], q.invcovs[k - 1], y[None, :])
+                               for k in range(1, q.K + 1) if q.sizes[k]])
+        A += 2.0 * a[o] * y[0]
+        ci += a[o] * quad / w
+    lb = A * A / (4.0 * B * float(ci.max()))
+    return (F - lb) / F, F, lb
+
+
 def optimality_certificate(saps, m, costs, s=None, tol=1.0e-7, max_rounds=60, verbose=False, max_seconds=None):
     """Duality certificate for  min_m F(m) = max_o V_o(m)/s_o  s.t.  costs.m = B, m >= 0  (the problem bluest/sap.py:387-418
     and bluest/mosap.py:578-605 hand to scipy) at a candidate allocation m, B = costs.m.  saps: one SparseOracleSAP per

@@ -24,5 +24,6 @@ for mode in ("eps", "budget"):
     V = np.array(p.MOSAP.variances(m))
     print(mode, "seconds", dt, "cost", res["total_cost"], "ratios", V / G["eps"] ** 2, "nnz", int((m > 0).sum()), p.MOSAP.solver_info)
     out[mode + "_m"] = m
+    out[mode + "_mu"] = np.asarray(p.MOSAP.solver_info.get("multipliers", np.zeros(n_out)))
     out[mode + "_V"] = V
 np.savez(os.path.join(ROOT, "gpurun_out", "ns_solve.npz"), **out)

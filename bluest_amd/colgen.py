@@ -140,6 +140,9 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
                 info["newton_it"] += int(out[4])
                 info["master_evals"] += int(out[5])
                 info["full_evals"] += 1
+                info["master_solves"] = info.get("master_solves", 0) + int(out[6])
+                if out[10:16].any():                              # experiment build (-DMASTER_TIMING): per-phase microseconds
+                    info["master_phase_us"] = [a + b for a, b in zip(info.get("master_phase_us", [0.0] * 6), out[10:16])]
                 if int(out[7]) == 2 or not np.isfinite(out[0]):
                     return None, "master start not evaluable"
                 xs, mu = h["xs"][:S].copy(), h["mu"].copy()

@@ -9,8 +9,13 @@
 // The algorithm is restated in numpy by the test infrastructure; tests compare the two.
 // The reference hands this problem to third-party NLP solvers with the Hessian of bluest/misc.py:497-503 /
 // bluest/cmisc.cpp:74-97 (bluest/sap.py:387-456); there is no reference code to follow.
-#include "plan.hpp"
+#include "plan.hpp"     // brings solve.hpp: readlane_f64, wave_lds_sync
 
+#ifdef MASTER_TIMING      // experiment build only: per-phase wall-clock (100 MHz counter) of thread 0 accumulated into out[10..15]
+#define TSTAMP(k) do { __syncthreads(); if (threadIdx.x == 0) { const long long t_ = wall_clock64(); tacc[k] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define TSTAMP(k)
+#endif
 #define MASTER_THREADS 512
 #define MASTER_SMAX 64
 #define MASTER_PACT 4      // outputs that can be active (tie at the maximum) at once inside the master
@@ -84,45 +89,60 @@ __device__ __forceinline__ int sym_e(int l, int l2, int k) { return l * k - l * 
 // r[o] = V_o / s_o of the allocation with support vector xv (LDS) -- all threads.  Leaves T_o = Phi_o^-1 (on the touched
 // models, zero elsewhere) in L.PHI.  Fixed summation orders: the result is bit-reproducible (every rank of a sharded solve
 // runs this redundantly and must get the same bits).
-__device__ void master_eval(const MasterArgs &A, MasterLds &L, const double *xv, double *rout, int tid)
+// in-place Gauss-Jordan inverse of the SPD matrix P (N x N, row stride LDN, LDS) by one wavefront, lane = row.
+// NT > 0: the row lives in NT registers, the pivot row is broadcast with v_readlane, everything is straight-line code (the
+// LDS version below serialises on LDS round trips: load - fma - store per column, ~3 us per pivot measured).  NT == 0: LDS.
+template <int NT>
+__device__ __forceinline__ bool inverse_wave(double *P, int N, int LDN, int lane)
 {
-    const int N = A.N, n_out = A.n_out, S = A.S, LDN = L.LDN, KE = L.KE;
-    const int wave = tid >> 6, lane = tid & 63, nw = MASTER_THREADS / 64;
-    for (int j = tid; j < S; j += MASTER_THREADS) L.mvec[j] = (1.0 - A.eps_bg) * L.cc[j] * xv[j];
-    __syncthreads();
-    for (int t = tid; t < n_out * N * N; t += MASTER_THREADS) {
-        const int o = t / (N * N), a = (t / N) % N, b = t % N;
-        double acc = A.bg ? A.bg[t] : 0.0;
-        unsigned long long both = L.memb[a] & L.memb[b];          // support groups containing both models, ascending order
-        while (both) {
-            const int j = __ffsll((long long)both) - 1;
-            both &= both - 1ull;
-            const double mj = L.mvec[j];
-            if (mj > 0.0) {
-                const int pa = L.pos[j * N + a], pb = L.pos[j * N + b];
-                const int lo = pa < pb ? pa : pb, hi = pa < pb ? pb : pa;
-                acc = fma(mj, L.BLK[((size_t)j * n_out + o) * KE + sym_e(lo, hi, L.kk[j])], acc);
+    const bool mine = lane < N;
+    bool bad = false;
+    if constexpr (NT > 0) {
+        double a[NT];
+#pragma unroll
+        for (int c = 0; c < NT; c++) a[c] = (mine && c < N) ? P[lane * LDN + c] : ((c == lane) ? 1.0 : 0.0);
+        bool untouched = false;
+#pragma unroll
+        for (int c = 0; c < NT; c++) if (c == lane && mine && !(a[c] > 0.0)) { untouched = true; a[c] = 1.0; }
+#pragma unroll
+        for (int p = 0; p < NT; p++) {
+            const double piv = readlane_f64(a[p], p);
+            bad = bad || !(piv > 0.0) || !isfinite(piv);
+            const double rinv = 1.0 / piv;
+            const bool is = lane == p;
+            const double f = a[p] * rinv;
+#pragma unroll
+            for (int c = 0; c < NT; c++) {
+                if (c == p) continue;
+                const double u = readlane_f64(a[c], p);
+                a[c] = is ? u * rinv : fma(-f, u, a[c]);
             }
+            a[p] = is ? rinv : -f;
         }
-        L.PHI[((size_t)o * N + a) * LDN + b] = acc;
-    }
-    __syncthreads();
-    // in-place Gauss-Jordan inverse, one wavefront per output, lane = row (SPD: no pivoting)
-    for (int o = wave; o < n_out; o += nw) {
-        double *P = L.PHI + (size_t)o * N * LDN;
-        const bool mine = lane < N;
+#pragma unroll
+        for (int c = 0; c < NT; c++) if (c == lane && untouched) a[c] = 0.0;
+        if (mine)
+#pragma unroll
+            for (int c = 0; c < NT; c++) if (c < N) P[lane * LDN + c] = a[c];
+        wave_lds_sync();
+        return bad;
+    } else {
         bool untouched = false;
         if (mine && !(P[lane * LDN + lane] > 0.0)) { untouched = true; P[lane * LDN + lane] = 1.0; }
         wave_lds_sync();
-        bool bad = false;
         for (int p = 0; p < N; p++) {
             const double piv = P[p * LDN + p];
             if (!(piv > 0.0) || !isfinite(piv)) { bad = true; break; }            // wave-uniform (same address)
             const double rinv = 1.0 / piv;
             if (mine && lane != p) {
                 const double f = P[lane * LDN + p] * rinv;
-                for (int c = 0; c < N; c++)
-                    if (c != p) P[lane * LDN + c] = fma(-f, P[p * LDN + c], P[lane * LDN + c]);
+                for (int c0 = 0; c0 < N; c0 += 8) {                               // loads first, then the updates: 16 LDS reads in flight
+                    double u[8], w[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) { const int c = c0 + q < N ? c0 + q : N - 1; u[q] = P[p * LDN + c]; w[q] = P[lane * LDN + c]; }
+#pragma unroll
+                    for (int q = 0; q < 8; q++) if (c0 + q < N && c0 + q != p) P[lane * LDN + c0 + q] = fma(-f, u[q], w[q]);
+                }
                 P[lane * LDN + p] = -f;
             }
             wave_lds_sync();
@@ -135,6 +155,46 @@ __device__ void master_eval(const MasterArgs &A, MasterLds &L, const double *xv,
         }
         if (untouched) P[lane * LDN + lane] = 0.0;
         wave_lds_sync();
+        return bad;
+    }
+}
+
+template <int NT>
+__device__ void master_eval(const MasterArgs &A, MasterLds &L, const double *xv, double *rout, int tid)
+{
+    const int N = A.N, n_out = A.n_out, S = A.S, LDN = L.LDN, KE = L.KE;
+    const int wave = tid >> 6, lane = tid & 63, nw = MASTER_THREADS / 64;
+    for (int j = tid; j < S; j += MASTER_THREADS) L.mvec[j] = (1.0 - A.eps_bg) * L.cc[j] * xv[j];
+    __syncthreads();
+    // one thread per destination (a, b) for ALL outputs: the membership / position look-ups are shared, the block reads of the
+    // outputs are independent loads; groups in ascending order (fixed summation order: bit-reproducible)
+    for (int t = tid; t < N * N; t += MASTER_THREADS) {
+        const int a = t / N, b = t % N;
+        for (int o0 = 0; o0 < n_out; o0 += 8) {
+            double acc[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) acc[q] = (A.bg && o0 + q < n_out) ? A.bg[(size_t)(o0 + q) * N * N + t] : 0.0;
+            unsigned long long both = L.memb[a] & L.memb[b];      // support groups containing both models
+            while (both) {
+                const int j = __ffsll((long long)both) - 1;
+                both &= both - 1ull;
+                const double mj = L.mvec[j];
+                if (mj > 0.0) {
+                    const int pa = L.pos[j * N + a], pb = L.pos[j * N + b];
+                    const int lo = pa < pb ? pa : pb, hi = pa < pb ? pb : pa;
+                    const double *B = L.BLK + (size_t)j * n_out * KE + sym_e(lo, hi, L.kk[j]);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) if (o0 + q < n_out) acc[q] = fma(mj, B[(size_t)(o0 + q) * KE], acc[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) if (o0 + q < n_out) L.PHI[((size_t)(o0 + q) * N + a) * LDN + b] = acc[q];
+        }
+    }
+    __syncthreads();
+    for (int o = wave; o < n_out; o += nw) {
+        double *P = L.PHI + (size_t)o * N * LDN;
+        const bool bad = inverse_wave<NT>(P, N, LDN, lane);
         if (lane == 0) {
             const double v00 = P[0];
             rout[o] = (!bad && v00 > 0.0 && isfinite(v00)) ? v00 / A.s[o] : INFINITY;
@@ -202,26 +262,37 @@ __device__ void master_factor_wave(const MasterArgs &A, MasterLds &L, int lane)
         const double rinv = 1.0 / piv;
         if (lane < nf && lane != p) {
             const double f = L.M[lane * LDM + p] * rinv;
-            for (int c = p + 1; c < nf + ne; c++) L.M[lane * LDM + c] = fma(-f, L.M[p * LDM + c], L.M[lane * LDM + c]);
+            const int cend = nf + ne;
+            for (int c0 = p + 1; c0 < cend; c0 += 8) {     // loads first, then the updates: 16 LDS reads in flight instead of a
+                double u[8], w[8];                         // load - fma - store round trip per column
+#pragma unroll
+                for (int q = 0; q < 8; q++) { const int c = c0 + q < cend ? c0 + q : cend - 1; u[q] = L.M[p * LDM + c]; w[q] = L.M[lane * LDM + c]; }
+#pragma unroll
+                for (int q = 0; q < 8; q++) if (c0 + q < cend) L.M[lane * LDM + c0 + q] = fma(-f, u[q], w[q]);
+            }
         }
         wave_lds_sync();
     }
     if (!ok) { if (lane == 0) L.istate[IS_OK] = 0; wave_lds_sync(); return; }
-    double Y[MASTER_PACT + 1], Eo[MASTER_PACT + 1];
+    double Y[MASTER_PACT + 1], Eo[MASTER_PACT + 1];        // static loop bounds + guards: the arrays stay in registers
+    const double dinv = lane < nf ? 1.0 / L.M[lane * LDM + lane] : 0.0;
 #pragma unroll
-    for (int e = 0; e < MASTER_PACT + 1; e++) { Y[e] = 0.0; Eo[e] = 0.0; }
-    if (lane < nf) {
-        const double di = 1.0 / L.M[lane * LDM + lane];
-        for (int e = 0; e < ne; e++) {
-            Y[e] = L.M[lane * LDM + nf + e] * di;
+    for (int e = 0; e < MASTER_PACT + 1; e++) {
+        Y[e] = 0.0; Eo[e] = 0.0;
+        if (e < ne && lane < nf) {
+            Y[e] = L.M[lane * LDM + nf + e] * dinv;
             L.M[lane * LDM + nf + e] = Y[e];
             Eo[e] = e < nact ? L.GQ[L.fi[lane] * MASTER_PACT + e] : 1.0;      // act == act0 order: GQ column e
         }
     }
-    for (int e = 0; e < ne; e++)
-        for (int e2 = 0; e2 < ne; e2++) {
-            const double k = wave_sum(Eo[e] * Y[e2]);
-            if (lane == 0) L.scal[32 + e * (MASTER_PACT + 1) + e2] = k;
+#pragma unroll
+    for (int e = 0; e < MASTER_PACT + 1; e++)
+#pragma unroll
+        for (int e2 = 0; e2 < MASTER_PACT + 1; e2++) {
+            if (e < ne && e2 < ne) {                       // wave-uniform
+                const double k = wave_sum(Eo[e] * Y[e2]);
+                if (lane == 0) L.scal[32 + e * (MASTER_PACT + 1) + e2] = k;
+            }
         }
     if (lane == 0) { L.istate[IS_OK] = 1; for (int e = 0; e < MASTER_PACT; e++) L.istate[IS_ALIVE + e] = e < nact; }
     wave_lds_sync();
@@ -233,72 +304,81 @@ __device__ void master_factor_wave(const MasterArgs &A, MasterLds &L, int lane)
 // the trial point, rhs_sum = 0) with the alive set as the step left it.  Every lane solves redundantly (identical inputs).
 __device__ void master_small_solve(const MasterArgs &A, MasterLds &L, int lane, bool soc, double *outvec)
 {
+    // the (<= 6 x 6) system is eliminated by lane 0 out of LDS (run-time indexed private arrays would live in scratch memory,
+    // a global round trip per access); the result is broadcast through LDS
+    __shared__ double Am[(MASTER_PACT + 2) * (MASTER_PACT + 3)];
+    __shared__ double zf[MASTER_PACT + 2];                 // multipliers in act order, then lam, tau at [PACT], [PACT+1]
+    __shared__ int alive[MASTER_PACT], map[MASTER_PACT + 1], okflag;
     const int S = A.S, LDM = L.LDM;
     const int nf = L.istate[IS_NF], nact = L.istate[IS_NACT];
     const int W = MASTER_PACT + 3;
-    int alive[MASTER_PACT];
-    for (int e = 0; e < MASTER_PACT; e++) alive[e] = L.istate[IS_ALIVE + e];
-    double z[MASTER_PACT + 2];
-    bool ok = false;
-    int map[MASTER_PACT + 1], p = 0;
-    for (int round = 0; round <= MASTER_PACT; round++) {
-        p = 0;
-        for (int e = 0; e < nact; e++) if (alive[e]) map[p++] = e;
-        map[p] = nact;                                                       // the "ones" column (index nact in K)
-        const int n = p + 2;
-        double Am[(MASTER_PACT + 2) * (MASTER_PACT + 3)];
-        for (int a = 0; a < n; a++) for (int b = 0; b <= n; b++) Am[a * W + b] = 0.0;
-        for (int a = 0; a <= p; a++)
-            for (int b = 0; b <= p; b++) Am[a * W + b] = L.scal[32 + map[a] * (MASTER_PACT + 1) + map[b]];
-        for (int a = 0; a < p; a++) { Am[a * W + p + 1] = 1.0; Am[(p + 1) * W + a] = 1.0; Am[a * W + n] = L.scal[(soc ? 20 : 16) + map[a]]; }
-        Am[(p + 1) * W + n] = soc ? 0.0 : 1.0;
-        bool sing = false;                                                   // Gaussian elimination with partial pivoting
-        for (int c = 0; c < n; c++) {
-            int pr = c; double best = fabs(Am[c * W + c]);
-            for (int rr = c + 1; rr < n; rr++) if (fabs(Am[rr * W + c]) > best) { best = fabs(Am[rr * W + c]); pr = rr; }
-            if (!(best > 0.0)) { sing = true; break; }
-            if (pr != c) for (int b = 0; b <= n; b++) { const double t = Am[c * W + b]; Am[c * W + b] = Am[pr * W + b]; Am[pr * W + b] = t; }
-            const double ri = 1.0 / Am[c * W + c];
-            for (int rr = 0; rr < n; rr++) {
-                if (rr == c) continue;
-                const double f = Am[rr * W + c] * ri;
-                if (f != 0.0) for (int b = c; b <= n; b++) Am[rr * W + b] -= f * Am[c * W + b];
+    if (lane == 0) {
+        for (int e = 0; e < MASTER_PACT; e++) alive[e] = L.istate[IS_ALIVE + e];
+        bool ok = false;
+        int p = 0;
+        for (int round = 0; round <= MASTER_PACT; round++) {
+            p = 0;
+            for (int e = 0; e < nact; e++) if (alive[e]) map[p++] = e;
+            map[p] = nact;                                                   // the "ones" column (index nact in K)
+            const int n = p + 2;
+            for (int a = 0; a < n; a++) for (int b = 0; b <= n; b++) Am[a * W + b] = 0.0;
+            for (int a = 0; a <= p; a++)
+                for (int b = 0; b <= p; b++) Am[a * W + b] = L.scal[32 + map[a] * (MASTER_PACT + 1) + map[b]];
+            for (int a = 0; a < p; a++) { Am[a * W + p + 1] = 1.0; Am[(p + 1) * W + a] = 1.0; Am[a * W + n] = L.scal[(soc ? 20 : 16) + map[a]]; }
+            Am[(p + 1) * W + n] = soc ? 0.0 : 1.0;
+            bool sing = false;                                               // Gaussian elimination with partial pivoting
+            for (int c = 0; c < n; c++) {
+                int pr = c; double best = fabs(Am[c * W + c]);
+                for (int rr = c + 1; rr < n; rr++) if (fabs(Am[rr * W + c]) > best) { best = fabs(Am[rr * W + c]); pr = rr; }
+                if (!(best > 0.0)) { sing = true; break; }
+                if (pr != c) for (int b = 0; b <= n; b++) { const double t = Am[c * W + b]; Am[c * W + b] = Am[pr * W + b]; Am[pr * W + b] = t; }
+                const double ri = 1.0 / Am[c * W + c];
+                for (int rr = 0; rr < n; rr++) {
+                    if (rr == c) continue;
+                    const double f = Am[rr * W + c] * ri;
+                    if (f != 0.0) for (int b = c; b <= n; b++) Am[rr * W + b] -= f * Am[c * W + b];
+                }
             }
+            if (sing) break;
+            int worst = -1; double wv = -1.0e-12;
+            if (!soc && p > 1)
+                for (int a = 0; a < p; a++) { const double za = Am[a * W + n] / Am[a * W + a]; if (za < wv) { wv = za; worst = a; } }
+            if (worst < 0) {
+                for (int e = 0; e < MASTER_PACT + 2; e++) zf[e] = 0.0;
+                for (int a = 0; a < p; a++) zf[map[a]] = Am[a * W + n] / Am[a * W + a];
+                zf[MASTER_PACT] = Am[p * W + n] / Am[p * W + p];
+                zf[MASTER_PACT + 1] = Am[(p + 1) * W + n] / Am[(p + 1) * W + p + 1];
+                ok = true;
+                break;
+            }
+            alive[map[worst]] = 0;
         }
-        if (sing) break;
-        for (int a = 0; a < n; a++) z[a] = Am[a * W + n] / Am[a * W + a];
-        int worst = -1; double wv = -1.0e-12;
-        if (!soc && p > 1) for (int a = 0; a < p; a++) if (z[a] < wv) { wv = z[a]; worst = a; }
-        if (worst < 0) { ok = true; break; }
-        alive[map[worst]] = 0;
+        okflag = ok ? 1 : 0;
+        if (ok && !soc) {
+            L.scal[SC_LAM] = zf[MASTER_PACT]; L.scal[SC_TAU] = zf[MASTER_PACT + 1];
+            double tot = 0.0;
+            for (int e = 0; e < nact; e++) tot += zf[e] > 0.0 ? zf[e] : 0.0;
+            for (int e = 0; e < nact; e++) L.scal[24 + e] = tot > 0.0 ? (zf[e] > 0.0 ? zf[e] : 0.0) / tot : 0.0;   // new multipliers, act order
+            int na = 0;
+            for (int e = 0; e < MASTER_PACT; e++) { L.istate[IS_ALIVE + e] = alive[e]; na += (e < nact && alive[e]) ? 1 : 0; }
+            L.istate[IS_NALIVE] = na;
+        }
+        L.istate[IS_OK] = okflag;
     }
-    if (!ok) { if (lane == 0) L.istate[IS_OK] = 0; wave_lds_sync(); return; }
-    double zf[MASTER_PACT + 2];
-    for (int e = 0; e < MASTER_PACT + 2; e++) zf[e] = 0.0;
-    for (int a = 0; a < p; a++) zf[map[a]] = z[a];
-    const double lam = z[p], tau = z[p + 1];
+    wave_lds_sync();
+    if (!okflag) return;
     double di = 0.0;
     if (lane < nf) {
         for (int e = 0; e < nact; e++) di = fma(L.M[lane * LDM + nf + e], zf[e], di);
-        di = fma(L.M[lane * LDM + nf + nact], lam, di);
+        di = fma(L.M[lane * LDM + nf + nact], zf[MASTER_PACT], di);
     }
     for (int j = lane; j < S; j += 64) outvec[j] = 0.0;
     wave_lds_sync();
     if (lane < nf) outvec[L.fi[lane]] = -di;
-    if (lane == 0 && !soc) {
-        L.scal[SC_LAM] = lam; L.scal[SC_TAU] = tau;
-        double tot = 0.0;
-        for (int e = 0; e < nact; e++) { zf[e] = zf[e] > 0.0 ? zf[e] : 0.0; tot += zf[e]; }
-        for (int e = 0; e < nact; e++) L.scal[24 + e] = tot > 0.0 ? zf[e] / tot : 0.0;     // new multipliers, act order
-        for (int e = 0; e < MASTER_PACT; e++) L.istate[IS_ALIVE + e] = alive[e];
-        int na = 0;
-        for (int e = 0; e < nact; e++) na += alive[e];
-        L.istate[IS_NALIVE] = na;
-    }
-    if (lane == 0) L.istate[IS_OK] = 1;
     wave_lds_sync();
 }
 
+template <int NT>
 __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
 {
     extern __shared__ __align__(16) unsigned char master_sm[];
@@ -306,6 +386,9 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
     const int N = A.N, n_out = A.n_out, S = A.S, KM = A.KM;
     master_carve(L, master_sm, N, n_out, S, KM);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef MASTER_TIMING
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
+#endif
     const int LDN = L.LDN, KE = L.KE;
     // ---- load the support ---------------------------------------------------------------------------
     for (int j = tid; j < S; j += MASTER_THREADS) { L.kk[j] = A.kk[j]; L.cc[j] = A.cc[j]; const double v = A.x[j]; L.x[j] = v > 0.0 ? v : 0.0; }
@@ -347,7 +430,9 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
     }
     if (tid == 0) { L.scal[SC_DAMP] = 1.0e-2; L.istate[IS_STATUS] = 0; }
     __syncthreads();
-    master_eval(A, L, L.x, L.r, tid);
+    TSTAMP(0);                                          // 0: load
+    master_eval<NT>(A, L, L.x, L.r, tid);
+    TSTAMP(1);                                          // 1: evaluations
     if (tid == 0) {
         L.istate[IS_EVALS] = 1;
         double F = 0.0;
@@ -430,6 +515,7 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
             L.scal[SC_QMAX] = qm;
         }
         __syncthreads();
+        TSTAMP(2);                                      // 2: active set + derivatives
         if (wave == 0) {   // reduced costs with the curvature weights -> free set
             double part = 0.0;
             for (int j = lane; j < S; j += 64) {
@@ -457,13 +543,16 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
             if (tid == 0) L.istate[IS_NACT] = L.istate[IS_NACT0];
             if (tid < MASTER_PACT) L.act[tid] = L.act[tid + MASTER_PACT];
             __syncthreads();
+            TSTAMP(3);                                  // 3: free set, KKT bookkeeping, step formation
             master_build_system(A, L, tid);
+            TSTAMP(4);                                  // 4: Hessian / system assembly
             if (wave == 0) {
                 master_factor_wave(A, L, lane);
                 if (L.istate[IS_OK]) master_small_solve(A, L, lane, false, L.d);
                 if (lane == 0) L.istate[IS_SOLVES] += 1;
             }
             __syncthreads();
+            TSTAMP(5);                                  // 5: factorisation + small system
             if (!L.istate[IS_OK]) {              // M not positive definite (or singular small system): more damping
                 __syncthreads();
                 if (tid == 0) L.scal[SC_DAMP] *= 10.0;
@@ -520,7 +609,9 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
                 for (int j = lane; j < S; j += 64) L.xt[j] = L.xt[j] / sx;
             }
             __syncthreads();
-            master_eval(A, L, L.xt, L.rt, tid);
+            TSTAMP(3);
+            master_eval<NT>(A, L, L.xt, L.rt, tid);
+            TSTAMP(1);
             // acceptance; near a tie of several outputs second-order errors split the tie and the exact max rejects a good SQP
             // step (the Maratos effect): one second-order correction -- the minimum-norm (in M) step c that re-equalises the
             // alive outputs at the trial point to first order, same K, another right-hand side -- gets a second evaluation
@@ -567,7 +658,7 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
                     if (tid == 0) L.scal[SC_DAMP] *= 10.0;
                     break;
                 }
-                master_eval(A, L, L.xt, L.rt, tid);
+                master_eval<NT>(A, L, L.xt, L.rt, tid);
             }
             __syncthreads();
             if (L.istate[IS_ACCEPT] || L.scal[SC_DAMP] > 1.0e12) break;
@@ -595,6 +686,9 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
         A.out[0] = L.scal[SC_F]; A.out[1] = L.scal[SC_LAM]; A.out[2] = L.scal[SC_KKT]; A.out[3] = L.scal[SC_SPREAD];
         A.out[4] = L.istate[IS_IT]; A.out[5] = L.istate[IS_EVALS]; A.out[6] = L.istate[IS_SOLVES]; A.out[7] = L.istate[IS_STATUS];
         A.out[8] = L.scal[SC_DAMP]; A.out[9] = L.scal[SC_LAMX];
+#ifdef MASTER_TIMING
+        for (int k = 0; k < 6; k++) A.out[10 + k] = (double)tacc[k] * 0.01;      // microseconds
+#endif
     }
 }
 
@@ -611,21 +705,32 @@ __global__ __launch_bounds__(256) void k_ma_update(int64_t L, int n_out, const d
                                                    const int32_t *__restrict__ invmap, const double *__restrict__ s,
                                                    const double *__restrict__ cc, double p, double *__restrict__ x, double *__restrict__ m)
 {
+    __shared__ double wgt[64], sden;                       // the n_out weights are the same for every group: once per workgroup
+    __shared__ int64_t sgo[64];                            // ... and so are the gradient offsets (a dependent load per output otherwise)
+    __shared__ int sok;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L) return;
-    double rmax = 0.0;
-    bool ok = true;
-    for (int o = 0; o < n_out; o++) { ok = ok && status[o] == BLUEST_EVAL_OK; rmax = fmax(rmax, var[o] / s[o]); }
-    if (!ok || !(rmax > 0.0) || !isfinite(rmax)) return;               // not evaluable: leave the iterate alone (uniform across the grid)
-    double num = 0.0, den = 0.0;
-    for (int o = 0; o < n_out; o++) {
-        const double ro = var[o] / s[o];
-        const double w = n_out == 1 ? 1.0 : pow(ro / rmax, p - 1.0);
-        den = fma(w, ro, den);
-        const int32_t li = invmap ? invmap[(int64_t)o * L + i] : (int32_t)i;
-        if (li >= 0) num = fma(w / s[o], -grad[goff[o] + li], num);
+    if (threadIdx.x == 0) {
+        double rmax = 0.0;
+        bool ok = true;
+        for (int o = 0; o < n_out; o++) { ok = ok && status[o] == BLUEST_EVAL_OK; rmax = fmax(rmax, var[o] / s[o]); }
+        ok = ok && rmax > 0.0 && isfinite(rmax);
+        double den = 0.0;
+        for (int o = 0; o < n_out && ok; o++) {
+            const double ro = var[o] / s[o];
+            const double w = n_out == 1 ? 1.0 : pow(ro / rmax, p - 1.0);
+            den = fma(w, ro, den);
+            if (o < 64) { wgt[o] = w / s[o]; sgo[o] = goff[o]; }
+        }
+        sden = den; sok = ok ? 1 : 0;
     }
-    const double xn = x[i] * cc[i] * num / den;
+    __syncthreads();
+    if (i >= L || !sok) return;                            // not evaluable: the iterate is left alone (uniform across the grid)
+    double num = 0.0;
+    for (int o = 0; o < n_out; o++) {
+        const int32_t li = invmap ? invmap[(int64_t)o * L + i] : (int32_t)i;
+        if (li >= 0) num = fma(wgt[o], -grad[sgo[o] + li], num);
+    }
+    const double xn = x[i] * cc[i] * num / sden;
     x[i] = xn;
     m[i] = cc[i] * xn;
 }
@@ -781,7 +886,7 @@ extern "C" int bluest_master_newton(bluest_plan_t plan, int S, const int64_t *su
         KM = std::max(KM, kk[j]);
     }
     const size_t lds = master_lds_bytes(N, n_out, S, KM);
-    if (lds > (size_t)master_lds_limit()) return fail(BLUEST_ERR_ARG, "master problem needs %zu bytes of LDS (limit %d)", lds, master_lds_limit());
+    if (lds > (size_t)master_lds_limit() - 1024) return fail(BLUEST_ERR_ARG, "master problem needs %zu bytes of LDS (limit %d)", lds, master_lds_limit() - 1024);
     idx.assign((size_t)S * KM, 0);
     for (int j = 0; j < S; j++) for (int l = 0; l < kk[j]; l++) idx[(size_t)j * KM + l] = (uint8_t)members[j][l];
     // one descriptor blob: [invcov pointers][boff][cc][kk][idx]
@@ -817,12 +922,23 @@ extern "C" int bluest_master_newton(bluest_plan_t plan, int S, const int64_t *su
     A.idx = (const uint8_t *)(d + b_ptr + b_off + b_cc + b_kk);
     A.s = s_dev; A.bg = eps_bg > 0.0 ? bg_dev : nullptr;
     A.x = x_dev; A.mu = mu_dev; A.out = out_dev;
-    static size_t granted = 0;
-    if (lds > granted) {
-        HIP_TRY(hipFuncSetAttribute((const void *)k_master_newton, hipFuncAttributeMaxDynamicSharedMemorySize, (int)master_lds_limit()));
-        granted = (size_t)master_lds_limit();
-    }
-    hipLaunchKernelGGL(k_master_newton, dim3(1), dim3(MASTER_THREADS), lds, st, A);
+    // register-resident inverses for the usual sizes, the LDS version beyond 32 models.  Dynamic LDS beyond the default needs the
+    // attribute (the kernel also has ~1 KB of static LDS: ask for what is needed, not for the whole limit)
+#define LAUNCH_MASTER(NT)                                                                                                     \
+    do {                                                                                                                      \
+        static size_t granted = 0;                                                                                            \
+        if (lds > granted) {                                                                                                  \
+            HIP_TRY(hipFuncSetAttribute((const void *)k_master_newton<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            granted = lds;                                                                                                    \
+        }                                                                                                                     \
+        hipLaunchKernelGGL((k_master_newton<NT>), dim3(1), dim3(MASTER_THREADS), lds, st, A);                                 \
+    } while (0)
+    if (N <= 12) LAUNCH_MASTER(12);
+    else if (N <= 20) LAUNCH_MASTER(20);
+    else if (N <= 26) LAUNCH_MASTER(26);
+    else if (N <= 32) LAUNCH_MASTER(32);
+    else LAUNCH_MASTER(0);
+#undef LAUNCH_MASTER
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }
@@ -833,6 +949,7 @@ extern "C" int bluest_ma_update(bluest_plan_t plan, const double *var_dev, const
     if (!plan || !var_dev || !status_dev || !grad_dev || !s_dev || !cc_dev || !x_dev || !m_dev) return fail(BLUEST_ERR_ARG, "null pointer");
     if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
     const int n_out = (int)plan->outs.size();
+    if (n_out > 64) return fail(BLUEST_ERR_ARG, "bluest_ma_update: more than 64 outputs");
     hipLaunchKernelGGL(k_ma_update, dim3((unsigned)((plan->L + 255) / 256)), dim3(256), 0, (hipStream_t)stream, plan->L, n_out, var_dev,
                        status_dev, grad_dev, plan->d_goff, plan->identity ? nullptr : plan->d_invmap, s_dev, cc_dev, p, x_dev, m_dev);
     HIP_TRY(hipGetLastError());

@@ -32,4 +32,4 @@ for rep in range(3):
         break
     m = prob["budget"] / prob["costs"] * x
     print("rep %d: %.4f s  max V %.12e  nnz %d  %s" % (rep, dt, max(mos.variances(m)), int((x > 0).sum()),
-                                                     {k: (float("%.4g" % v) if isinstance(v, float) else v) for k, v in info.items() if k != "mu"}))
+                                                     {k: (float("%.4g" % v) if isinstance(v, float) else v) for k, v in info.items() if k not in ("mu", "certificate")}))

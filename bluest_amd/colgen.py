@@ -59,8 +59,19 @@ def master_max_support(plan):
 
 def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
     """x (numpy, length L, on the unit simplex) minimising max_o V_o(B x / cost)/s_o, and an info dict with the certified gap.
-    Returns (None, reason) when the master problem does not fit the single-workgroup kernel (the caller falls back)."""
+    Returns (None, reason) when the master problem does not fit the single-workgroup kernel (the caller falls back).
+
+    plan: a plan.Plan, or a dist.ShardedPlan (COLLECTIVE: every rank of the group calls this with the same arguments).  Over a
+    sharded group set nothing of length K_tot ever crosses the fabric: the allocation, the gradient and the multiplicative
+    iterate stay sharded (every rank updates the entries of its own groups); per evaluation the ranks exchange the Phi records
+    (n_out (N^2 + 2N + 1) doubles, dist.ShardedPlan.reduce_records) and solve redundantly; per pricing round they gather
+    <= 1024 candidates and the blocks of the <= 64 support groups; the master problem is solved redundantly by every rank with
+    the same deterministic kernel, so all ranks take identical decisions and return identical bits."""
     prm = prm or {}
+    sharded = plan if hasattr(plan, "reduce_records") else None
+    if sharded is not None:
+        plan = sharded.plan
+    world = 1 if sharded is None else sharded.world
     ma_its = int(prm.get("ma_iterations", 200))
     ma_p = float(prm.get("ma_p", 32.0))
     init_mult = int(prm.get("support_init", 3))
@@ -87,13 +98,35 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
     var = torch.empty((1, n_out), dtype=torch.float64, device=dev)
     grad = torch.empty((1, plan.grad_len), dtype=torch.float64, device=dev)
     status = torch.empty((1, n_out), dtype=torch.int32, device=dev)
-    info = {"rounds": 0, "newton_it": 0, "master_evals": 0, "full_evals": 0, "ma_iterations": ma_its}
+    info = {"rounds": 0, "newton_it": 0, "master_evals": 0, "full_evals": 0, "ma_iterations": ma_its, "ranks": world}
+    var_view = bufs.buf[bufs.off["var"][0]:bufs.off["var"][0] + n_out].view(1, n_out)
+    rec = torch.empty((1, n_out, plan.reclen), dtype=torch.float64, device=dev) if sharded is not None else None
+
+    def gather(obj):
+        """list over ranks of `obj` (small host data)"""
+        if world == 1:
+            return [obj]
+        import torch.distributed as dist
+        got = [None] * world
+        dist.all_gather_object(got, obj, group=sharded.group)
+        return got
+
+    def evaluate(m_t, var_t):
+        """V and grad V of the allocation m_t for every output into (var_t, grad, status), on the stream"""
+        if sharded is None:
+            check(lib.bluest_plan_eval(plan._h, m_t.data_ptr(), 1, L, 0.0, var_t.data_ptr(), grad.data_ptr(), plan.grad_len, status.data_ptr(), _stream()))
+        else:
+            sharded.eval(m_t, rec=rec, out=(var_t, grad, status))       # Phi of the shard -> record exchange -> redundant solve + shard gradient
+
     with torch.cuda.device(dev):
         st = _stream()
         # ---- background: Phi_o(uniform allocation), one Phi pass -----------------------------------------------------
         u_m = to_dev(cc_h / L)
-        rec = plan.phi(u_m).cpu().numpy()[0]                     # (n_out, N*N + 2N + 1): the sums come first
-        phi_u = np.ascontiguousarray(rec[:, :N * N])
+        rec_u = plan.phi(u_m)
+        if sharded is not None:
+            sharded.reduce_records(rec_u)
+        rec_u = rec_u.cpu().numpy()[0]                           # (n_out, N*N + 2N + 1): the sums come first
+        phi_u = np.ascontiguousarray(rec_u[:, :N * N])
         info["full_evals"] += 1
         # ---- phase 1: multiplicative algorithm from the uniform point (or x0) ------------------------------------------------
         xh = np.full(L, 1.0 / L) if x0 is None else np.maximum(np.asarray(x0, dtype=np.float64), 0.0)
@@ -102,22 +135,49 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
             xh = (1.0 - 1.0e-3) * xh + 1.0e-3 / L                # the multiplicative update cannot leave a zero
         x_d, m_d = to_dev(xh), to_dev(cc_h * xh)
         for _ in range(ma_its):
-            check(lib.bluest_plan_eval(plan._h, m_d.data_ptr(), 1, L, 0.0, var.data_ptr(), grad.data_ptr(), plan.grad_len, status.data_ptr(), st))
+            evaluate(m_d, var)
             check(lib.bluest_ma_update(plan._h, var.data_ptr(), status.data_ptr(), grad.data_ptr(), s_d.data_ptr(), cc.data_ptr(), ma_p,
                                        x_d.data_ptr(), m_d.data_ptr(), st))
         info["full_evals"] += ma_its
         xh = x_d.cpu().numpy()
-        if not np.isfinite(xh).all() or xh.sum() <= 0.0:
-            return None, "multiplicative phase produced a non-finite iterate"
-        xh = np.maximum(xh, 0.0) / xh.sum()
-        # ---- initial support: the largest entries ---------------------------------------------------------------------------
         S0 = min(L, s_max, max(init_mult * N, N + 1))
-        keep = np.sort(np.argsort(-xh, kind="stable")[:S0])
-        xs = xh[keep] / xh[keep].sum()
+        if sharded is not None:
+            # every rank owns the entries of its groups; the others never moved (or were zeroed by the first update)
+            own = np.zeros(L, dtype=bool)
+            for o_ in sharded.local_outputs:
+                own[np.asarray(o_["mapping"], dtype=np.int64)] = True
+            xh = np.where(own, xh, 0.0)
+            top = np.argsort(-xh, kind="stable")[:S0]
+            parts = gather((top, xh[top]))
+            idx_all = np.concatenate([p_[0] for p_ in parts])
+            val_all = np.concatenate([p_[1] for p_ in parts])
+            if not np.isfinite(val_all).all() or val_all.sum() <= 0.0:
+                return None, "multiplicative phase produced a non-finite iterate"
+            order = np.lexsort((idx_all, -val_all))[:S0]       # largest first, ties by index: the same on every rank
+            keep = np.sort(idx_all[order])
+            xs = val_all[order][np.argsort(idx_all[order], kind="stable")]
+            xs = xs / xs.sum()
+        else:
+            if not np.isfinite(xh).all() or xh.sum() <= 0.0:
+                return None, "multiplicative phase produced a non-finite iterate"
+            xh = np.maximum(xh, 0.0) / xh.sum()
+            # ---- initial support: the largest entries -----------------------------------------------------------------------
+            keep = np.sort(np.argsort(-xh, kind="stable")[:S0])
+            xs = xh[keep] / xh[keep].sum()
         mu = np.full(n_out, 1.0 / n_out)
         best_lb, F_last, gap, cert = 0.0, np.inf, np.inf, None
         x_full = None
         sup_d = torch.empty(s_max, dtype=torch.int64, device=dev)
+
+        def master_plan(keep_idx):
+            """(plan holding the blocks of the support groups, their indices in that plan).  Sharded: the blocks live on the ranks
+            that own the groups, so a small plan over exactly the support is assembled identically on every rank (collective)"""
+            if sharded is None:
+                return plan, keep_idx
+            sub = sharded.replicated_subplan(keep_idx)            # raises on every rank alike if an output would be left empty
+            subs.append(sub)                                      # alive until the master kernel that reads it has run
+            return sub, np.arange(len(keep_idx), dtype=np.int64)
+        subs = []
         for stage, eps in enumerate(eps_list):
             bg_d = to_dev(eps * phi_u)
             mtol = 1.0e-2
@@ -127,14 +187,22 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
                 bufs.put("mu", mu)
                 keep_h = np.ascontiguousarray(keep, dtype=np.int64)
                 cc_keep = np.ascontiguousarray(cc_h[keep])
-                check(lib.bluest_master_newton(plan._h, S, keep_h.ctypes.data, cc_keep.ctypes.data, s_d.data_ptr(), bg_d.data_ptr(), float(eps),
+                mplan, msup = master_plan(keep_h)
+                check(lib.bluest_master_newton(mplan._h, S, msup.ctypes.data, cc_keep.ctypes.data, s_d.data_ptr(), bg_d.data_ptr(), float(eps),
                                                bufs.ptr("xs"), bufs.ptr("mu"), float(mtol), newton_maxit, bufs.ptr("out"), st))
                 sup_d[:S] = torch.from_numpy(keep_h)
                 check(lib.bluest_support_point(L, S, sup_d.data_ptr(), bufs.ptr("xs"), cc.data_ptr(), float(eps), m_d.data_ptr(), st))
-                check(lib.bluest_plan_eval(plan._h, m_d.data_ptr(), 1, L, 0.0, bufs.ptr("var"), grad.data_ptr(), plan.grad_len, status.data_ptr(), st))
+                evaluate(m_d, var_view)
                 check(lib.bluest_price(plan._h, grad.data_ptr(), bufs.ptr("mu"), s_d.data_ptr(), cc.data_ptr(), S, sup_d.data_ptr(),
                                        bufs.ptr("csup"), bufs.ptr("topv"), bufs.ptr("topi"), bufs.ptr("y0"), st))
                 h = bufs.fetch()                                  # the round's only synchronisation
+                if sharded is not None:
+                    # every rank priced its own groups: merge the candidates and the support's reduced costs (a rank reports 0
+                    # for groups it does not own; reduced costs are >= 0).  Same data, same order on every rank.
+                    parts = gather((h["topv"], h["topi"], h["csup"][:S]))
+                    h["topv"] = np.concatenate([p_[0] for p_ in parts])
+                    h["topi"] = np.concatenate([p_[1] for p_ in parts])
+                    h["csup"] = np.max(np.stack([p_[2] for p_ in parts]), axis=0)
                 out = h["out"]
                 info["rounds"] += 1
                 info["newton_it"] += int(out[4])
@@ -158,7 +226,7 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
                     cert = {"support": keep.copy(), "x": xs.copy(), "mu": mu.copy(), "background": float(eps), "lower_bound": lb}
                 gap = 1.0 - best_lb / F
                 level = float(h["csup"][:S][pos] @ xs[pos]) / float(xs[pos].sum())
-                order = np.argsort(-h["topv"], kind="stable")
+                order = np.lexsort((h["topi"], -h["topv"]))       # largest first, ties by index
                 cand_i, cand_v = h["topi"][order], h["topv"][order]
                 in_pos = set(keep[pos].tolist())
                 enter = []
@@ -194,7 +262,8 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
         bufs.put("mu", mu)
         keep_h = np.ascontiguousarray(keep, dtype=np.int64)
         cc_keep = np.ascontiguousarray(cc_h[keep])
-        check(lib.bluest_master_newton(plan._h, S, keep_h.ctypes.data, cc_keep.ctypes.data, s_d.data_ptr(), None, 0.0,
+        mplan, msup = master_plan(keep_h)
+        check(lib.bluest_master_newton(mplan._h, S, msup.ctypes.data, cc_keep.ctypes.data, s_d.data_ptr(), None, 0.0,
                                        bufs.ptr("xs"), bufs.ptr("mu"), 1.0e-10, newton_maxit, bufs.ptr("out"), st))
         h = bufs.fetch()
         out = h["out"]
@@ -204,7 +273,7 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
         def true_F(xv):
             mm = np.zeros(L)
             mm[keep] = cc_h[keep] * np.maximum(xv, 0.0) / max(float(np.maximum(xv, 0.0).sum()), 1e-300)
-            vv, _, stt = plan.eval(mm, want_grad=False)
+            vv, _, stt = (sharded if sharded is not None else plan).eval(mm, want_grad=False)
             if not (stt[0].cpu().numpy() == EVAL_OK).all():
                 return np.inf
             return float((vv[0].cpu().numpy() / s).max())

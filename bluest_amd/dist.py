@@ -320,12 +320,13 @@ class ShardedPlan(object):
 
 @in_host_section
 def sharded_spg(sharded, costs, budget=None, eps=None, x0=None, params=None):
-    """solver="spg" over a group-sharded plan: every rank runs the SAME deterministic iteration on replicated vectors (x, g, d
-    of length K_tot); an objective evaluation is one all-reduce of the Phi records, a gradient evaluation one more all-reduce of
-    the gradient (every rank contributes the entries of its groups).  On GPUs the loop is device-resident
-    (spg_device.ShardedDeviceSpg: nothing waits for the host between the collectives); params={"device_loop": False} selects
-    the host-driven driver (bluest_amd.spg.spg = bluest/spg.py:39-132, what CPU stand-in plans always use).  All ranks return
-    the same allocation.
+    """solver="spg" over a group-sharded plan (COLLECTIVE).  On GPUs: the second-order finish of bluest_amd/colgen.py -- the
+    multiplicative phase keeps the allocation, its gradient and the iterate SHARDED (each rank updates the entries of its own
+    groups from the all-reduced Phi record; nothing of length K_tot crosses the fabric), the column generation gathers <= 1024
+    pricing candidates and the blocks of the <= 64 support groups per round, and every rank solves the small master problem
+    redundantly with the same deterministic kernel: identical bits on all ranks.  params={"method": "spg"} selects the
+    first-order loop on replicated vectors (spg_device.ShardedDeviceSpg: one more all-reduce of the K_tot gradient per step);
+    CPU stand-in plans (tests under gloo) use the host-driven driver bluest_amd.spg.spg = bluest/spg.py:39-132.
     The reference runs its optimiser on one MPI rank (bluest/blue_models.py:508-526); this is the N-GPU counterpart of
     SAP.solve / MOSAP.solve(..., continuous_relaxation=True).  Returns (samples, solver info)."""
     from .sap import SpgAllocator
@@ -337,8 +338,7 @@ def sharded_spg(sharded, costs, budget=None, eps=None, x0=None, params=None):
         prm.update(params)
     if not on_gpu:
         prm["device_loop"] = False                                 # CPU stand-in plans (tests): the host-driven driver
-    # the working set of the last stages is small: it is built identically on every rank and solved redundantly, the pricing of
-    # the excluded groups in between is collective
-    alloc = SpgAllocator(sharded, costs, None, verbose=False, subplan=sharded.replicated_subplan if on_gpu else None)
+        prm["method"] = "spg"
+    alloc = SpgAllocator(sharded, costs, None, verbose=False)
     m = alloc.solve(budget=budget, eps=eps, x0=x0, params=prm)
     return m, alloc.info

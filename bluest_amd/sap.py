@@ -217,7 +217,7 @@ class SpgAllocator(object):
         if not np.isfinite(ratios(plan, scale_h * x)):
             raise BLUESTError("SPG: the initial allocation does not sample model 0 / is infeasible")
         tot = {"it": 0, "count": 0}
-        if prm["method"] == "newton" and isinstance(plan, Plan):
+        if prm["method"] == "newton" and type(getattr(plan, "plan", plan)).__name__ == "Plan":      # a HIP plan, or a ShardedPlan over HIP plans
             xn, ninfo = colgen_solve(plan, w, s, B, x0=None if x0 is None else x, prm=prm.get("newton"))
             if xn is not None:
                 m = scale_h * xn

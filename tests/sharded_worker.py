@@ -63,7 +63,7 @@ def main(out_path):
         res[tag + "_shard"] = [sp.lo, sp.hi]
         res[tag + "_exchange"] = sp.exchange_name
         # host-driven driver (collective callbacks) and the device-resident collective loop (the default on GPUs)
-        m_host, info_h = sharded_spg(sp, prob["costs"], budget=prob["budget"], params={"smoothing_p": 512.0, "device_loop": False})
+        m_host, info_h = sharded_spg(sp, prob["costs"], budget=prob["budget"], params={"smoothing_p": 512.0, "device_loop": False, "method": "spg"})
         vh, _, _ = full.eval(torch.from_numpy(m_host).to(dev), want_grad=False)
         res[tag + "_F_sharded_host_loop"] = float(vh.max())
         m_sh, info = sharded_spg(sp, prob["costs"], budget=prob["budget"])
@@ -75,6 +75,12 @@ def main(out_path):
         res[tag + "_cost_ratio"] = float(m_sh @ prob["costs"] / prob["budget"])
         res[tag + "_it"] = int(info["it"])
         res[tag + "_support"] = int((m_sh > 0).sum())
+        res[tag + "_method"] = info.get("method", "spg")
+        res[tag + "_gap"] = float(info.get("certified_gap", np.nan))
+        # the first-order loop on replicated vectors stays available
+        m_fo, info_fo = sharded_spg(sp, prob["costs"], budget=prob["budget"], params={"method": "spg"})
+        vf, _, _ = full.eval(torch.from_numpy(m_fo).to(dev), want_grad=False)
+        res[tag + "_F_sharded_first_order"] = float(vf.max())
     if rank == 0:
         json.dump(res, open(out_path, "w"))
     dist.destroy_process_group()

@@ -45,7 +45,10 @@ def main(out_path):
         res["peer_exchange_err"], res["peer_exchange_identical_on_all_ranks"], res["peer_exchange_timed_out"] = worst, same, ex.timed_out()
     # (the third problem is long enough, K_tot = 6884 > 4096, for the solver's working set: replicated restricted plans,
     # collective pricing)
-    for tag, (n, kmax, n_out) in (("n12_k4_o1", (12, 4, 1)), ("n10_k3_o3", (10, 3, 3)), ("n16_k5_o2", (16, 5, 2))):
+    cases = (("n12_k4_o1", (12, 4, 1)), ("n10_k3_o3", (10, 3, 3)), ("n16_k5_o2", (16, 5, 2)))
+    if os.environ.get("BLUEST_TEST_BIG"):          # BASELINE.json configs[4] across the process boundary (n = 25, K_tot = 245505)
+        cases = (("n25_k6_o1", (25, 6, 1)),)
+    for tag, (n, kmax, n_out) in cases:
         prob = synth.problem(n, kmax, n_out)
         sizes = [len(g) for g in prob["groups"]]
         outs = [{"K": kmax, "sizes": sizes, "groups": prob["groups"], "C": prob["C"][o], "mapping": None} for o in range(n_out)]
@@ -62,10 +65,12 @@ def main(out_path):
         res[tag + "_status_equal"] = bool(torch.equal(status, st_full))
         res[tag + "_shard"] = [sp.lo, sp.hi]
         res[tag + "_exchange"] = sp.exchange_name
+        big = n >= 25
         # host-driven driver (collective callbacks) and the device-resident collective loop (the default on GPUs)
-        m_host, info_h = sharded_spg(sp, prob["costs"], budget=prob["budget"], params={"smoothing_p": 512.0, "device_loop": False, "method": "spg"})
-        vh, _, _ = full.eval(torch.from_numpy(m_host).to(dev), want_grad=False)
-        res[tag + "_F_sharded_host_loop"] = float(vh.max())
+        m_host, info_h = (np.zeros(prob["K_tot"]), None) if big else sharded_spg(sp, prob["costs"], budget=prob["budget"], params={"smoothing_p": 512.0, "device_loop": False, "method": "spg"})
+        if not big:
+            vh, _, _ = full.eval(torch.from_numpy(m_host).to(dev), want_grad=False)
+            res[tag + "_F_sharded_host_loop"] = float(vh.max())
         m_sh, info = sharded_spg(sp, prob["costs"], budget=prob["budget"])
         all_m = [torch.empty(prob["K_tot"], dtype=torch.float64) for _ in range(world)]
         dist.all_gather(all_m, torch.from_numpy(np.ascontiguousarray(m_sh)))
@@ -77,10 +82,15 @@ def main(out_path):
         res[tag + "_support"] = int((m_sh > 0).sum())
         res[tag + "_method"] = info.get("method", "spg")
         res[tag + "_gap"] = float(info.get("certified_gap", np.nan))
-        # the first-order loop on replicated vectors stays available
-        m_fo, info_fo = sharded_spg(sp, prob["costs"], budget=prob["budget"], params={"method": "spg"})
-        vf, _, _ = full.eval(torch.from_numpy(m_fo).to(dev), want_grad=False)
-        res[tag + "_F_sharded_first_order"] = float(vf.max())
+        if not big:                                # the first-order loop on replicated vectors stays available
+            m_fo, info_fo = sharded_spg(sp, prob["costs"], budget=prob["budget"], params={"method": "spg"})
+            vf, _, _ = full.eval(torch.from_numpy(m_fo).to(dev), want_grad=False)
+            res[tag + "_F_sharded_first_order"] = float(vf.max())
+        else:                                      # single-GPU answer of the same problem, computed by rank 0's process too
+            from bluest_amd.colgen import colgen_solve
+            x1, i1 = colgen_solve(full, prob["costs"], np.ones(n_out), prob["budget"])
+            v1, _, _ = full.eval(torch.from_numpy(prob["budget"] / prob["costs"] * x1).to(dev), want_grad=False)
+            res[tag + "_F_single"] = float(v1.max())
     if rank == 0:
         json.dump(res, open(out_path, "w"))
     dist.destroy_process_group()

@@ -66,7 +66,9 @@ def sap_wallclock(prob, reps=4):
         t2 = time.perf_counter()
         row = {"setup_s": t1 - t0, "solve_s": t2 - t1, "total_s": t2 - t0, "spg_iterations": int(mos.solver_info["it"]),
                "objective_evaluations": int(mos.solver_info["count"]), "max_variance": float(max(mos.variances(m))),
-               "setup_phases_ms": {k: round(v, 3) for k, v in mos.setup_phases.items()}}
+               "setup_phases_ms": {k: round(v, 3) for k, v in mos.setup_phases.items()},
+               "method": mos.solver_info.get("method", "spg"), "certified_gap": float(mos.solver_info.get("certified_gap", float("nan"))),
+               "full_evaluations": int(mos.solver_info.get("fevals", 0)), "rounds": int(mos.solver_info.get("rounds", 0))}
         # everything the solve does (full-problem and working-set steps, restricted plans, pricing, host checks) per trial point
         row["solve_us_per_evaluation"] = row["solve_s"] / max(row["objective_evaluations"], 1) * 1e6
         t3 = time.perf_counter()
@@ -79,10 +81,12 @@ def sap_wallclock(prob, reps=4):
     med = sorted(warm, key=lambda r: r["total_s"])[len(warm) // 2]
     return {"cold_s": rows[0]["total_s"], "cold": rows[0], "warm_total_s": med["total_s"], "warm": med,
             "warm_all_total_s": [r["total_s"] for r in warm], "release_s_all": [r["release_s"] for r in rows],
-            "budget": float(prob["budget"]), "solver": "spg (scaled metric, device-resident loop), continuous relaxation",
+            "budget": float(prob["budget"]),
+            "solver": "solver=\"spg\" with the second-order finish: multiplicative phase on all groups, column generation with a "
+                      "single-workgroup Newton master, certified duality gap; continuous relaxation",
             "note": "total_s = set-up + solve; cold = first repetition of the process; warm = median of the following %d; release_s = "
-                    "dropping the problem afterwards + a full Python collection; one solver step is 4 launches (direction, Phi "
-                    "pass, solve+gradient+decision, update), kernel timeline in profiles/*_spg_step_timeline.txt" % len(warm)}
+                    "dropping the problem afterwards + a full Python collection; spg_iterations = Newton iterations of the masters, "
+                    "objective_evaluations = evaluations on all groups + inside the masters" % len(warm)}
 
 
 def pmc_traffic(kernel, cfg):
@@ -257,6 +261,23 @@ def chain_time(torch, fn, R=50, reps=20):
     return float(np.median(ts))
 
 
+def eager_time(torch, fn, R=50, reps=7):
+    """average duration of one call of fn() launched eagerly R times between two HIP events on the current stream (collectives
+    of RCCL are not captured into graphs here), median of `reps`"""
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(R):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3 / R)
+    return float(np.median(ts))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -397,8 +418,7 @@ def main():
         extra["single_gpu_ms_per_step"] = float(solo[0]) * 1e3
         del full
         if sharded is not None and not args.no_sap:
-            # the solve of the same configuration over the sharded plan: device-resident loop, two all-reduces per step (records:
-            # peer-write or RCCL; gradient K_tot f64: RCCL); collective, so every rank runs it -- outside the timed region
+            # the solve of the same configuration over the sharded plan (collective, so every rank runs it) -- outside the timed region
             try:
                 from bluest_amd.dist import sharded_spg
                 rows = []
@@ -409,19 +429,55 @@ def main():
                     barrier()
                     rows.append(time.perf_counter() - t0)
                 vs, _, _ = sharded.eval(torch.from_numpy(m_sh).to(dev), want_grad=False)
-                extra["sharded_solve"] = {"cold_s": rows[0], "warm_s": rows[1], "spg_iterations": int(info["it"]),
-                                          "objective_evaluations": int(info["count"]), "max_variance": float(vs.max()),
-                                          "loop": "device-resident SPG over the sharded plan (spg_device.ShardedDeviceSpg)",
+                extra["sharded_solve"] = {"cold_s": rows[0], "warm_s": rows[1], "newton_iterations": int(info["it"]),
+                                          "full_evaluations": int(info.get("fevals", 0)), "rounds": int(info.get("rounds", 0)),
+                                          "us_per_full_evaluation_all_in": rows[1] / max(int(info.get("fevals", 1)), 1) * 1e6,
+                                          "certified_gap": float(info.get("certified_gap", float("nan"))),
+                                          "max_variance": float(vs.max()), "method": info.get("method", "spg"),
+                                          "loop": "second-order finish over the sharded plan (colgen.colgen_solve): sharded multiplicative "
+                                                  "phase (one record exchange per evaluation, nothing of length K_tot exchanged), "
+                                                  "collective column generation, redundant bit-identical masters",
                                           "note": "set-up not included (the sharded plan is the one timed above); compare sap_wallclock of "
                                                   "the single-GPU run of this configuration: profiles/*_bench_n25_k6_o1.json"}
             except Exception as err:      # the headline line must not depend on this leg
                 extra["sharded_solve"] = {"error": repr(err)[:300]}
 
-    # ---- per-kernel durations with HIP events on the launch stream (single GPU) -----------------------
+    # ---- per-kernel durations with HIP events on the launch stream -----------------------------------
     roofline = None
     kern = {}
     batched = None
     ab = synth.algorithmic_bytes(n, kmax)
+    if world > 1 and sharded is not None:
+        # every rank times its own launches (collective: the exchange needs all ranks); rank 0 reports the MAX over ranks
+        from bluest_amd.plan import _stream
+        lib, h = plan.lib, plan._h
+        m0 = ring[0]
+        timer = chain_time if graphable and not args.no_graph else eager_time
+        t_chunks = timer(torch, lambda: lib.bluest_plan_phi_chunks(h, m0.data_ptr(), 1, L, _stream()))
+        t_phi = timer(torch, lambda: plan.phi(m0, out=rec))
+        t_xchg = timer(torch, lambda: sharded.reduce_records(rec))
+        plan.phi(m0, out=rec); sharded.reduce_records(rec)
+        t_sg = timer(torch, lambda: plan.solve_grad(rec, out=(var, grad, status)))
+        tt = torch.tensor([t_chunks, t_phi, t_xchg, t_sg], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_chunks, t_phi, t_xchg, t_sg = (float(v) for v in tt)
+        rec_bytes = int(n_out * plan.reclen * 8)
+        kern = {"method": ("hipGraph of 50 back-to-back launches" if timer is chain_time else "50 eager launches") + ", HIP events, median; max over ranks",
+                "k_phi_chunks_us(shard)": t_chunks * 1e6, "phi_pass_us(chunks + fold to record)": t_phi * 1e6,
+                "exchange_us": t_xchg * 1e6, "k_solve_grad_us(redundant solve + shard gradient)": t_sg * 1e6,
+                "exchange": {"algorithm": sharded.exchange_name, "bytes_per_rank_per_step": rec_bytes,
+                             "doubles": int(n_out * plan.reclen)}}
+        # roofline of the shard's dominant streaming kernel: algorithmic bytes of the shard (1/world of the pass: shards are
+        # balanced by sum k^2) over its launch time
+        if t_sg >= t_chunks:
+            kname, tk, abytes = "k_solve_grad", max(t_sg, 1e-9), ab["grad"] * n_out / world
+        else:
+            kname, tk, abytes = "k_phi_chunks", max(t_chunks, 1e-9), ab["phi"] * n_out / world
+        roofline = {"bound": "hbm", "kernel": kname + " (one shard)", "achieved": abytes / tk / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": abytes / tk / HBM_PEAK, "traffic": None, "algorithmic_bytes_per_launch": abytes, "avg_launch_us": tk * 1e6,
+                    "clocks": "this run, per GPU; one launch = kernel + dispatch gap to its successor",
+                    "step": {"algorithmic_bytes_all_gpus": ab["eval"] * n_out, "achieved_GBps_all_gpus": ab["eval"] * n_out / sec_per_step / 1e9,
+                             "frac_of_aggregate_peak": ab["eval"] * n_out / sec_per_step / (HBM_PEAK * world)}}
     if rank == 0 and world == 1:
         from bluest_amd.plan import _stream
         lib, h = plan.lib, plan._h

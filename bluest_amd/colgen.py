@@ -86,7 +86,7 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
     s = np.asarray(s, dtype=np.float64)
     s_max = master_max_support(plan)
     enter_per = int(prm.get("enter_per_round", N))
-    if s_max < min(L, 2 * N + 2):
+    if s_max < min(L, N + 8):
         return None, "master problem does not fit one workgroup (support limit %d)" % s_max
 
     def to_dev(a, dtype=np.float64):
@@ -286,6 +286,9 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
                 info["polished"] = True
     if not np.isfinite(F_true):
         return None, "final allocation not evaluable"
+    if 1.0 - best_lb / F_true > float(prm.get("give_up_gap", 1.0e-3)):
+        # e.g. the optimal support does not fit the master's 64 entries: let the caller fall back rather than return this
+        return None, "column generation ended with a certified gap of %.1e" % (1.0 - best_lb / F_true)
     x = np.zeros(L)
     x[keep] = np.maximum(xs, 0.0)
     x /= x.sum()

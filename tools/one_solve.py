@@ -12,4 +12,4 @@ for rep in range(int(sys.argv[4]) if len(sys.argv) > 4 else 2):
                 prob["costs"], [prob["costs"]] * o, verbose=False)
     m = mos.solve(budget=prob["budget"], solver="spg", continuous_relaxation=True)
     torch.cuda.synchronize()
-    print("rep %d: %.1f ms, %s" % (rep, (time.perf_counter() - t0) * 1e3, {k_: mos.solver_info[k_] for k_ in ("it", "count")}), flush=True)
+    print("rep %d: %.1f ms, %s" % (rep, (time.perf_counter() - t0) * 1e3, {k_: mos.solver_info.get(k_) for k_ in ("it", "count", "rounds", "certified_gap", "method")}), flush=True)

@@ -2,9 +2,9 @@
 # Round profile: (1) rocprofv3 --kernel-trace --stats of the bench command (without the SAP / CPU / batched legs, so the trace
 # holds the timed hot path), (2) separate --pmc passes for FETCH_SIZE and WRITE_SIZE (MI355X_MICROARCH.md, HBM section), (3) the
 # default bench, (4) the other BASELINE configurations (n=20 single output with its own kernel trace, n=12 all groups, n=25),
-# (5) kernel statistics of a whole SAP solve; summaries go to gpurun_out/profiles_<tag>/ (raw per-dispatch CSVs stay behind).
+# (5) kernel statistics of whole SAP solves, (6) the driver's command line, (7) step parts + quality sweep; summaries go to gpurun_out/profiles_<tag>/ (raw per-dispatch CSVs stay behind).
 #   on the GPU box:  bash tools/profile.sh r02
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 SUM=gpurun_out/profiles_$TAG
@@ -38,18 +38,25 @@ echo "n20 o1 done"
 python bench.py --n 12 --kmax 12 --n-out 1 > $SUM/${TAG}_bench_n12_k12_o1.json 2> $OUT/bench_n12.err
 python bench.py --n 25 --kmax 6 --n-out 1 > $SUM/${TAG}_bench_n25_k6_o1.json 2> $OUT/bench_n25.err
 echo "other configs done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_spg -- python tools/sap_wallclock.py 20 5 8 > $OUT/spg_out.json 2> $OUT/spg_err.txt
-python - > $SUM/${TAG}_spg_loop_kernel_stats.txt <<PY
+# (5) kernel statistics of whole SAP solves (set-up + second-order finish), headline and the other BASELINE sizes
+for cfg in "20 5 8" "20 5 1" "25 6 1"; do
+  tagc=$(echo $cfg | tr " " _)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_solve_$tagc -- python tools/one_solve.py $cfg 3 > $OUT/solve_$tagc.log 2> $OUT/solve_$tagc.err
+  python - > $SUM/${TAG}_solve_kernel_stats_$tagc.txt <<PY
 import csv, glob
-f = sorted(glob.glob("$OUT/prof_spg/*/*_kernel_stats.csv"))[-1]
-for r in list(csv.DictReader(open(f)))[:18]:
-    print("%-60s %8s %10.2f us avg  %6.2f%%" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+f = sorted(glob.glob("$OUT/prof_solve_$tagc/*/*_kernel_stats.csv"))[-1]
+print("# rocprofv3 --kernel-trace --stats of tools/one_solve.py $cfg 3 (three set-ups + solves); per-kernel totals over the run")
+for r in list(csv.DictReader(open(f)))[:16]:
+    print("%-60s %8s calls %10.2f us avg %9.2f ms total %6.2f%%" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, float(r["Percentage"])))
 PY
-tail -3 $OUT/spg_out.json >> $SUM/${TAG}_spg_loop_kernel_stats.txt
-# (6) average kernel timeline of one SPG step (full problem: anchor k_proj_fused; working set: anchor k_simplex)
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_step -o t -- python tools/one_solve.py 20 5 8 2 > $OUT/one_solve.log 2> $OUT/one_solve.err
-F=$(find $OUT/trace_step -name "*kernel_trace.csv" | head -1)
-{ echo "# full-problem steps (K_tot = 21699)"; python tools/iter_timeline.py $F k_proj_fused; echo; echo "# working-set steps"; python tools/iter_timeline.py $F k_simplex; grep rep $OUT/one_solve.log; } > $SUM/${TAG}_spg_step_timeline.txt 2>&1
-echo "step timeline done"
+  grep rep $OUT/solve_$tagc.log >> $SUM/${TAG}_solve_kernel_stats_$tagc.txt
+done
+echo "solve stats done"
+# (6) the driver's command line, verbatim
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $SUM/${TAG}_bench_driver_style.json 2> $OUT/bench_driver.err
+# (7) parts of a step on the chain clock, quality sweep
+python tools/step_parts.py > $SUM/${TAG}_step_parts.txt 2>/dev/null
+python tools/quality_sweep.py > $SUM/${TAG}_quality_sweep.txt 2>/dev/null
+echo "driver-style bench + sweeps done"
 rm -rf $OUT
 ls -la $SUM

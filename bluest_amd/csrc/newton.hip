@@ -709,17 +709,25 @@ __global__ __launch_bounds__(256) void k_ma_update(int64_t L, int n_out, const d
     __shared__ int64_t sgo[64];                            // ... and so are the gradient offsets (a dependent load per output otherwise)
     __shared__ int sok;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double sr[64];
+    __shared__ int sst[64];
+    if (threadIdx.x < n_out) {                             // the per-output scalars in parallel (one dependent round trip, not 3 n_out)
+        const int o = threadIdx.x;
+        const double so = s[o];
+        sr[o] = var[o] / so; sst[o] = status[o]; sgo[o] = goff[o]; wgt[o] = so;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         double rmax = 0.0;
         bool ok = true;
-        for (int o = 0; o < n_out; o++) { ok = ok && status[o] == BLUEST_EVAL_OK; rmax = fmax(rmax, var[o] / s[o]); }
+        for (int o = 0; o < n_out; o++) { ok = ok && sst[o] == BLUEST_EVAL_OK; rmax = fmax(rmax, sr[o]); }
         ok = ok && rmax > 0.0 && isfinite(rmax);
         double den = 0.0;
         for (int o = 0; o < n_out && ok; o++) {
-            const double ro = var[o] / s[o];
+            const double ro = sr[o];
             const double w = n_out == 1 ? 1.0 : pow(ro / rmax, p - 1.0);
             den = fma(w, ro, den);
-            if (o < 64) { wgt[o] = w / s[o]; sgo[o] = goff[o]; }
+            wgt[o] = w / wgt[o];
         }
         sden = den; sok = ok ? 1 : 0;
     }

@@ -89,7 +89,7 @@ class SupportProblem(object):
         return (r, G, Hs, vs) if want_derivatives else r
 
 
-def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floor=1.0e-6, verbose=False, fb=None):
+def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floor=1.0e-6, verbose=False, fb=None, caps=None, nu0=None):
     """active-set Newton (SQP) on the support with Levenberg-Marquardt damping.  Works on rho_o = -1 / r_o (convex as well:
     1 / V_o is the Schur complement of Phi_o, concave and homogeneous of degree +1 in x; same minimisers; Newton does not crawl
     on it far from the optimum the way it does on the degree -1 function r_o, where a step is x -> 1.5 x).
@@ -97,8 +97,16 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floo
     (mirror-descent like) step, damp -> 0 the Newton step; damp follows the ratio actual / predicted decrease, and a rejected
     trial point raises it and re-solves (no line search: an entering column sits at x_j = 0 where the quadratic model is only
     valid for steps of the size of the background, so step LENGTH, not step fraction, is what must adapt).
-    Returns dict(x, mu, lam, F, it, evals, kkt)"""
+    caps = (Acap (n_caps, S), bcap (n_caps,)): linear rows Acap x <= bcap (max_model_samples, bluest/sap.py:222-240, in the scaled
+    variable); x0 must satisfy them.  Caps at their bound (or carrying a multiplier) are equality rows of the SQP step, a cap
+    whose multiplier comes out negative leaves; a trial point that would violate a cap is pulled back along the segment from x.
+    Returns dict(x, mu, nu, lam, F, it, evals, kkt)"""
     S, n_out = prob.S, prob.n_out
+    Acap = np.zeros((0, S)) if caps is None else np.asarray(caps[0], dtype=np.float64).reshape(-1, S)
+    bcap = np.zeros(0) if caps is None else np.asarray(caps[1], dtype=np.float64)
+    ncap = len(bcap)
+    nu = np.zeros(ncap) if nu0 is None else np.maximum(np.asarray(nu0, dtype=np.float64), 0.0)
+    MCAP = 4
     if fb is None:
         fb = 0.0 if prob.eps_bg > 0.0 else 0.9     # without the background V has kinks where a model drops out: stay inside the face
     x = np.maximum(np.asarray(x0, dtype=np.float64), 0.0)
@@ -128,7 +136,10 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floo
         H = np.zeros((S, S))
         for o in act0:
             H += mu_h[o] * (Hs[o] / r[o] ** 2 - 2.0 * np.outer(G[:, o], G[:, o]) / r[o] ** 3)
-        gl = Gq @ mu_h
+        slack = bcap - Acap @ x
+        candc = np.flatnonzero((slack <= 1.0e-10 * np.maximum(np.abs(bcap), 1.0)) | (nu > 0.0))
+        actc0 = np.sort(candc[np.argsort(slack[candc], kind="stable")[:MCAP]])        # at most MCAP caps in the step at once
+        gl = Gq @ mu_h + Acap.T @ nu
         lam_est = -float(gl @ x)
         rc = gl + lam_est
         free = (x > 0.0) | (rc < 0.0)
@@ -137,7 +148,9 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floo
         accepted = False
         for attempt in range(40):
             act = act0.copy()
-            while True:                                            # drop outputs whose multiplier comes out negative
+            actc = actc0.copy()
+            locked = set()                                         # caps that came back: dropping them made the step violate them
+            while True:                                            # drop outputs / caps whose multiplier comes out negative
                 M = H[np.ix_(fi, fi)] + damp * abs(lam_est) * np.diag(D[fi])
                 try:
                     Lc = np.linalg.cholesky(M)
@@ -145,32 +158,46 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floo
                     damp *= 10.0
                     continue
                 info["solves"] += 1
-                E = np.column_stack([Gq[fi][:, act], np.ones(len(fi))])
+                E = np.column_stack([Gq[fi][:, act], Acap[actc][:, fi].T, np.ones(len(fi))])
                 Y = np.linalg.solve(Lc, E)
                 K = Y.T @ Y
-                p = len(act)
-                KK = np.zeros((p + 2, p + 2))
-                KK[:p + 1, :p + 1] = K
-                KK[:p, p + 1] = 1.0
-                KK[p + 1, :p] = 1.0
-                rhs = np.concatenate([q[act], [0.0, 1.0]])
+                p, pc = len(act), len(actc)
+                ne = p + pc + 1
+                KK = np.zeros((ne + 1, ne + 1))
+                KK[:ne, :ne] = K
+                KK[:p, ne] = 1.0
+                KK[ne, :p] = 1.0
+                rhs = np.concatenate([q[act], -slack[actc], [0.0, 1.0]])       # d = -M^-1 E z: (K z)_c = -(b_c - a_c.x)
                 try:
                     z = np.linalg.solve(KK, rhs)
                 except np.linalg.LinAlgError:
                     z = np.linalg.lstsq(KK, rhs, rcond=None)[0]
-                mu_new, lam, tau = z[:p], z[p], z[p + 1]
+                mu_new, nu_new, lam, tau = z[:p], z[p:p + pc], z[p + pc], z[ne]
                 if p > 1 and mu_new.min() < -1.0e-12:
                     act = np.delete(act, int(np.argmin(mu_new)))
                     continue
+                droppable = [j for j in range(pc) if nu_new[j] < -1.0e-12 and int(actc[j]) not in locked]
+                if droppable:
+                    actc = np.delete(actc, min(droppable, key=lambda j: nu_new[j]))
+                    continue
+                d = np.zeros(S)
+                d[fi] = -np.linalg.solve(Lc.T, Y @ z[:ne])
+                # a cap at its bound that was dropped must not be violated by the step it was dropped from
+                back = [int(c_) for c_ in actc0 if c_ not in actc and slack[c_] <= 1.0e-10 * max(abs(bcap[c_]), 1.0)
+                        and Acap[c_] @ d > 1.0e-12 * max(abs(bcap[c_]), 1.0)]
+                if back:
+                    locked.update(back)
+                    actc = np.sort(np.concatenate([actc, np.asarray(back, dtype=actc.dtype)]))
+                    continue
                 break
-            d = np.zeros(S)
-            d[fi] = -np.linalg.solve(Lc.T, Y @ z[:p + 1])
             mu_full = np.zeros(n_out)
             mu_full[act] = np.maximum(mu_new, 0.0)
+            nu_full = np.zeros(ncap)
+            nu_full[actc] = np.maximum(nu_new, 0.0) / mu_full.sum()
             mu_full /= mu_full.sum()
             if attempt == 0:
                 # KKT residual at x with the new multipliers, relative to the level lam
-                glx = Gq @ mu_full
+                glx = Gq @ mu_full + Acap.T @ nu_full
                 lam_x = -float(glx @ x)
                 rcx = glx + lam_x
                 pos = x > 1.0e-10                                  # entries below 1e-10 count as at the bound
@@ -186,8 +213,35 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floo
                 continue
             # projected step: entries that would turn negative become zero; fb > 0 (no background): every entry keeps at least
             # 1 - fb of its value, so that no model drops out of the information matrix inside the master (V has a kink there)
+            def pull_back(xv):
+                """make a trial point respect every cap (x does).  Clipping negative entries and renormalising moves mass between
+                capped and uncapped groups, so a cap the step kept at its bound can end slightly violated: first REPAIR -- scale
+                the entries of the most violated cap's groups down to its bound and hand the freed mass to the other entries in
+                proportion (a few rounds: caps overlap) --, then, if something is still violated, the furthest feasible point of
+                the segment x -> xv"""
+                if ncap == 0:
+                    return xv
+                xv = xv.copy()
+                for _ in range(8):
+                    ratio = (Acap @ xv) / np.where(bcap > 0, bcap, 1.0)
+                    c_ = int(np.argmax(ratio))
+                    if ratio[c_] <= 1.0 + 1.0e-13:
+                        break
+                    msk = Acap[c_] > 0.0
+                    rest = float(xv[~msk].sum())
+                    if rest <= 0.0:
+                        break
+                    freed = (1.0 - 1.0 / ratio[c_]) * float(xv[msk].sum())
+                    xv[msk] /= ratio[c_]
+                    xv[~msk] *= 1.0 + freed / rest
+                ax, axv = Acap @ x, Acap @ xv
+                bad = axv > bcap * (1.0 + 1.0e-12) + 1e-300
+                if not bad.any():
+                    return xv
+                theta = float(np.min((bcap - ax)[bad] / (axv - ax)[bad]))
+                return x + max(theta, 0.0) * (xv - x)
             xt = np.maximum(x + d, (1.0 - fb) * x if fb > 0.0 else 0.0)
-            xt = xt / xt.sum()
+            xt = pull_back(xt / xt.sum())
             rt = prob.evaluate(xt)
             info["evals"] += 1
             actual = rt.max() - F
@@ -197,16 +251,16 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floo
                 # Maratos effect).  Second-order correction: the minimum-norm (in M) step c that re-equalises the active outputs
                 # at the trial point to first order,  g_o.c - tau2 = -q_o(xt),  1.c = 0  -- the same K with another right-hand side
                 qt = -1.0 / rt[act]
-                rhs2 = np.concatenate([qt, [0.0, 0.0]])
+                rhs2 = np.concatenate([qt, np.zeros(pc), [0.0, 0.0]])            # the correction does not move along the active caps
                 try:
                     z2 = np.linalg.solve(KK, rhs2)
                 except np.linalg.LinAlgError:
                     z2 = None
                 if z2 is not None:
                     c = np.zeros(S)
-                    c[fi] = -np.linalg.solve(Lc.T, Y @ z2[:p + 1])
+                    c[fi] = -np.linalg.solve(Lc.T, Y @ z2[:ne])
                     xt2 = np.maximum(x + d + c, (1.0 - fb) * x if fb > 0.0 else 0.0)
-                    xt2 = xt2 / xt2.sum()
+                    xt2 = pull_back(xt2 / xt2.sum())
                     rt2 = prob.evaluate(xt2)
                     info["evals"] += 1
                     actual2 = rt2.max() - F
@@ -228,17 +282,17 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floo
             if damp > 1.0e12:
                 break
         if kkt <= tol and spread <= tol:
-            mu = mu_full
+            mu, nu = mu_full, nu_full
             break
         if not accepted:
             break
-        x, r, mu = xt, rt, mu_full
+        x, r, mu, nu = xt, rt, mu_full, nu_full
         info["it"] = it + 1
         # the objective cannot resolve the remaining improvement (the KKT residual left sits in entries of negligible mass)
         tiny_steps = tiny_steps + 1 if abs(actual) <= 1.0e-13 * F else 0
         if tiny_steps >= 2:
             break
-    info.update({"x": x, "mu": mu, "lam": lam, "F": float(r.max()), "r": r, "kkt": kkt})
+    info.update({"x": x, "mu": mu, "nu": nu, "lam": lam, "F": float(r.max()), "r": r, "kkt": kkt})
     return info
 
 

@@ -89,22 +89,6 @@ def test_host_section_limits_blas_and_pauses_the_collector():
     assert body.__name__ == "body"
 
 
-def test_support_multipliers_recover_the_kkt_weights():
-    """pricing of the working set: the multipliers of the active outputs are those that make the combined gradient constant on
-    the support (bluest_amd/sap.py: support_multipliers)"""
-    from bluest_amd.sap import support_multipliers
-    rng = np.random.RandomState(4)
-    n_act, S = 3, 40
-    mu_true = np.array([0.6, 0.3, 0.1])
-    G = rng.randn(n_act, S)
-    # make mu_true . G constant: fix the last row accordingly
-    G[2] = (1.7 - mu_true[0] * G[0] - mu_true[1] * G[1]) / mu_true[2]
-    x = rng.rand(S)
-    mu = support_multipliers(G, x)
-    assert mu.min() >= 0 and abs(mu.sum() - 1) < 1e-12 and np.abs(mu - mu_true).max() < 1e-6
-    assert np.array_equal(support_multipliers(G[:1], x), np.ones(1))
-
-
 def test_first_host_section_touches_no_file_and_imports_nothing():
     """round-2 driver run: `sap_wallclock.cold.setup_s` = 1.0 s on a freshly leased box whose image was still paging in, against
     12 ms on a warm one -- the first host_section imported threadpoolctl and scanned the loaded libraries inside the timed

@@ -380,3 +380,55 @@ def test_singular_phi_fixture(oracle):
     assert abs(V / float(G["Vgh_pinv"]) - 1) < 1e-9 and rel_err(g, G["grad_pinv"]) < 1e-9
     assert abs(float(G["eigmin"])) < 1e-14 and int(G["variance_asserted"]) == 0
     assert abs(float(G["variance_solve"]) / float(G["Vgh_pinv"]) - 1) > 0.5          # the reference disagrees with itself here
+
+
+def _support_problem_cpu(oracle, prob, keep, eps_bg, s):
+    from oracle.master_newton import SupportProblem
+    n, kmax, n_out = prob["n"], prob["kmax"], prob["n_out"]
+    saps = [oracle.SparseOracleSAP(C, kmax, prob["groups"]) for C in prob["C"]]
+    sp0 = saps[0]
+    flat = [g for gk in sp0.groups for g in gk]
+    c = prob["budget"] / prob["costs"]
+
+    def block(o, i):
+        k = int(np.searchsorted(sp0.cumsizes, i, side="right"))
+        return saps[o].invcovs[k - 1].reshape(-1, k, k)[i - sp0.cumsizes[k - 1]]
+    phi_u = np.array([q.get_phi(c / sp0.L) for q in saps])
+    return SupportProblem(n, [flat[i] for i in keep], [[block(o, i) for i in keep] for o in range(n_out)], c[keep], s, eps_bg * phi_u, eps_bg), flat, c
+
+
+@pytest.mark.parametrize("n,kmax,n_out,S", [(8, 3, 1, 20), (10, 4, 2, 30)])
+def test_master_newton_restatement_against_slsqp(oracle, n, kmax, n_out, S):
+    """oracle/master_newton.py (the numpy restatement of the GPU master, csrc/newton.hip): on a random support it reaches the
+    optimum scipy's SLSQP finds for the same smooth problem, without and with per-model sample caps (max_model_samples)"""
+    from scipy.optimize import minimize
+    from oracle.master_newton import master_newton
+    prob = synth.problem(n, kmax, n_out)
+    rng = np.random.RandomState(5)
+    keep = np.sort(np.concatenate([[0], 1 + rng.choice(prob["K_tot"] - 1, S - 1, replace=False)]))
+    eps_bg = 1e-3
+    sp, flat, cc = _support_problem_cpu(oracle, prob, keep, eps_bg, np.ones(n_out))
+    x0 = np.full(S, 1.0 / S)
+    ref = master_newton(sp, x0, tol=1e-10)
+    assert ref["kkt"] <= 1e-6 and abs(ref["x"].sum() - 1) < 1e-12 and ref["x"].min() >= 0
+    fun = lambda z: sp.evaluate(np.maximum(z, 0) / np.maximum(z, 0).sum()).max() * 1e3       # noqa: E731
+    sol = minimize(fun, 0.9 * ref["x"] + 0.1 * x0, method="SLSQP", bounds=[(0, 1)] * S, constraints=[{"type": "eq", "fun": lambda z: z.sum() - 1}],
+                   options={"ftol": 1e-15, "maxiter": 500})
+    assert ref["F"] <= sol.fun / 1e3 * (1 + 1e-7)
+    # caps on models 0 and 1 at 60 % of what the unconstrained optimum samples
+    A = np.array([[cc[i] * (1 - eps_bg) if mdl in flat[i] else 0.0 for i in keep] for mdl in (0, 1)])
+    b = 0.6 * (A @ ref["x"])
+    x = x0.copy()
+    for _ in range(200):                                    # a feasible start: shrink the capped groups
+        viol = A @ x - b
+        if (viol <= 0).all():
+            break
+        c_ = int(np.argmax(viol / b))
+        msk = A[c_] > 0
+        x[msk] *= 0.95 * b[c_] / (A[c_] @ x)
+        x[~msk] += (1 - x.sum()) * x[~msk] / x[~msk].sum()
+    capped = master_newton(sp, x, tol=1e-10, caps=(A, b))
+    assert (A @ capped["x"] <= b * (1 + 1e-9)).all() and capped["nu"].min() >= 0 and capped["F"] > ref["F"]
+    cons = [{"type": "eq", "fun": lambda z: z.sum() - 1}, {"type": "ineq", "fun": lambda z: b - A @ z}]
+    sol = minimize(fun, 0.9 * capped["x"] + 0.1 * x, method="SLSQP", bounds=[(0, 1)] * S, constraints=cons, options={"ftol": 1e-15, "maxiter": 500})
+    assert capped["F"] <= sol.fun / 1e3 * (1 + 1e-6), (capped["F"], sol.fun / 1e3)

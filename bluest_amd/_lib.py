@@ -74,9 +74,11 @@ SIGNATURES = {
     "bluest_xchg_destroy": [c_vp],
     "bluest_master_max_support": [c_vp, ctypes.POINTER(c_int)],
     "bluest_master_newton": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp, c_f64, c_int, c_vp, c_vp],
+    "bluest_master_newton_capped": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp, c_f64, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp],
     "bluest_ma_update": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp, c_vp],
     "bluest_support_point": [c_i64, c_int, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp],
     "bluest_price": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "bluest_price_capped": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "bluest_simplex_workspace_doubles": [c_i64, c_i64p],
     "bluest_simplex_project": [c_vp, c_vp, c_f64, c_f64, c_f64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
 }

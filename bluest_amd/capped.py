@@ -210,16 +210,26 @@ def solve_budget_capped(plan, costs, cap_rows, cap_rhs, budget, s_norm, prm, x0=
     return m, info
 
 
-def solve_capped(plan, costs, cap_rows, cap_rhs, budget=None, eps=None, x0=None, prm=None, unconstrained_cost=None):
+def solve_capped(plan, costs, cap_rows, cap_rhs, budget=None, eps=None, x0=None, prm=None, unconstrained_cost=None, budget_solver=None):
     """budget mode: one capped solve.  eps mode (min cost s.t. V_o <= eps_o^2): V's homogeneity no longer turns it into a budget
     problem (the caps are absolute), so the smallest budget whose capped optimum meets the tolerances is bracketed and bisected."""
     n_out = plan.n_out
+
+    def one_budget(B, s_norm_, start):
+        """one capped solve at budget B: the second-order finish with the caps in its master problem when the caller supplied it
+        (budget_solver) and it succeeds, else the first-order loop over the capped set below"""
+        if budget_solver is not None:
+            got = budget_solver(B, s_norm_, start)
+            if got is not None:
+                return got
+        return solve_budget_capped(plan, costs, cap_rows, cap_rhs, B, s_norm_, prm, x0=start)
+
     if budget is not None:
-        return solve_budget_capped(plan, costs, cap_rows, cap_rhs, budget, np.ones(n_out), prm, x0=x0)
+        return one_budget(budget, np.ones(n_out), x0)
     s_norm = np.asarray(eps, dtype=np.float64) ** 2
 
     def attempt(B, start):
-        m, info = solve_budget_capped(plan, costs, cap_rows, cap_rhs, B, s_norm, prm, x0=start)
+        m, info = one_budget(B, s_norm, start)
         return m, info, (np.inf if m is None else info["f"])          # f = max_o V_o/eps_o^2 (p-norm for smooth stages)
 
     def true_ratio(m):

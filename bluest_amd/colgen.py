@@ -57,7 +57,27 @@ def master_max_support(plan):
     return int(s.value)
 
 
-def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
+def cap_feasible_start(x, Acap, b):
+    """a point of the simplex that respects Acap x <= b, made from x by scaling the entries of the most violated cap's groups down
+    (with 5 % room) and handing the freed mass to the entries outside that cap; None if that does not terminate (e.g. every
+    entry is capped)"""
+    x = np.maximum(np.asarray(x, dtype=np.float64), 0.0)
+    x = x / x.sum()
+    for _ in range(500):
+        viol = Acap @ x - b
+        if (viol <= 0.0).all():
+            return x
+        c = int(np.argmax(viol / np.maximum(b, 1e-300)))
+        msk = Acap[c] > 0.0
+        rest = float(x[~msk].sum())
+        if rest <= 0.0 or b[c] <= 0.0:
+            return None
+        x[msk] *= 0.95 * b[c] / float(Acap[c] @ x)
+        x[~msk] *= (1.0 - float(x[msk].sum())) / rest
+    return None
+
+
+def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
     """x (numpy, length L, on the unit simplex) minimising max_o V_o(B x / cost)/s_o, and an info dict with the certified gap.
     Returns (None, reason) when the master problem does not fit the single-workgroup kernel (the caller falls back).
 
@@ -66,9 +86,17 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
     iterate stay sharded (every rank updates the entries of its own groups); per evaluation the ranks exchange the Phi records
     (n_out (N^2 + 2N + 1) doubles, dist.ShardedPlan.reduce_records) and solve redundantly; per pricing round they gather
     <= 1024 candidates and the blocks of the <= 64 support groups; the master problem is solved redundantly by every rank with
-    the same deterministic kernel, so all ranks take identical decisions and return identical bits."""
+    the same deterministic kernel, so all ranks take identical decisions and return identical bits.
+
+    caps (single GPU): {"models": int array (n_caps), "rows": (n_caps, L) 0/1 indicator of the groups containing each capped model,
+    "rhs": (n_caps) maximal numbers of samples} -- max_model_samples (bluest/sap.py:222-240, bluest/mosap.py:326-344):
+    sum_i rows[c, i] m_i <= rhs[c].  The caps are linear rows of the master's KKT system (bluest_master_newton_capped), the pricing
+    subtracts their multipliers (bluest_price_capped) and the bound becomes  A - max_i c^_i - sum_c nu'_c rhs_c  (Lagrangian
+    relaxation of the caps, multipliers nu' = F^2 nu of the problem as posed)."""
     prm = prm or {}
     sharded = plan if hasattr(plan, "reduce_records") else None
+    if sharded is not None and caps is not None:
+        return None, "sample caps over a sharded plan are not supported"
     if sharded is not None:
         plan = sharded.plan
     world = 1 if sharded is None else sharded.world
@@ -94,6 +122,24 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
 
     cc_h = B / w
     cc, s_d = to_dev(cc_h), to_dev(s)
+    ncap = 0
+    if caps is not None:
+        cap_models = np.ascontiguousarray(caps["models"], dtype=np.int32)
+        cap_rows = np.asarray(caps["rows"]) != 0
+        cap_rhs = np.ascontiguousarray(caps["rhs"], dtype=np.float64)
+        ncap = len(cap_models)
+        if ncap > 64 or cap_rows.shape != (ncap, L):
+            return None, "more than 64 sample caps"
+        cap_asum = np.array([float(cc_h[cap_rows[c]].sum()) for c in range(ncap)])      # cap c of the uniform allocation is asum / L
+        mask = np.zeros(L, dtype=np.uint64)
+        for c in range(ncap):
+            mask[cap_rows[c]] |= np.uint64(1) << np.uint64(c)
+        capmask_d = torch.from_numpy(mask.view(np.int64)).to(dev)
+        nu_d = torch.zeros(64, dtype=torch.float64, device=dev)
+
+        def cap_system(keep_idx, eps_):
+            """(rows of the caps on the support in the master's variable, right-hand sides with the background's share taken off)"""
+            return (1.0 - eps_) * cc_h[keep_idx][None, :] * cap_rows[:, keep_idx], cap_rhs - eps_ * cap_asum / L
     bufs = _Buffers(dev, n_out, s_max)
     var = torch.empty((1, n_out), dtype=torch.float64, device=dev)
     grad = torch.empty((1, plan.grad_len), dtype=torch.float64, device=dev)
@@ -183,19 +229,37 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
             mtol = 1.0e-2
             for rnd in range(max_rounds):
                 S = len(keep)
+                if ncap:
+                    Acap_S, b_eps = cap_system(keep, eps)
+                    if (Acap_S @ xs > b_eps).any():            # first round of a stage (the background's share changed) or a fresh support
+                        xs = cap_feasible_start(xs, Acap_S, b_eps)
+                        if xs is None:
+                            return None, "no allocation on the support respects the sample caps"
                 bufs.put("xs", xs)
                 bufs.put("mu", mu)
                 keep_h = np.ascontiguousarray(keep, dtype=np.int64)
                 cc_keep = np.ascontiguousarray(cc_h[keep])
                 mplan, msup = master_plan(keep_h)
-                check(lib.bluest_master_newton(mplan._h, S, msup.ctypes.data, cc_keep.ctypes.data, s_d.data_ptr(), bg_d.data_ptr(), float(eps),
-                                               bufs.ptr("xs"), bufs.ptr("mu"), float(mtol), newton_maxit, bufs.ptr("out"), st))
+                if ncap:
+                    b_host = np.ascontiguousarray(b_eps)
+                    check(lib.bluest_master_newton_capped(mplan._h, S, msup.ctypes.data, cc_keep.ctypes.data, s_d.data_ptr(), bg_d.data_ptr(),
+                                                          float(eps), bufs.ptr("xs"), bufs.ptr("mu"), float(mtol), newton_maxit, bufs.ptr("out"),
+                                                          ncap, cap_models.ctypes.data, b_host.ctypes.data, nu_d.data_ptr(), st))
+                else:
+                    check(lib.bluest_master_newton(mplan._h, S, msup.ctypes.data, cc_keep.ctypes.data, s_d.data_ptr(), bg_d.data_ptr(), float(eps),
+                                                   bufs.ptr("xs"), bufs.ptr("mu"), float(mtol), newton_maxit, bufs.ptr("out"), st))
                 sup_d[:S] = torch.from_numpy(keep_h)
                 check(lib.bluest_support_point(L, S, sup_d.data_ptr(), bufs.ptr("xs"), cc.data_ptr(), float(eps), m_d.data_ptr(), st))
                 evaluate(m_d, var_view)
-                check(lib.bluest_price(plan._h, grad.data_ptr(), bufs.ptr("mu"), s_d.data_ptr(), cc.data_ptr(), S, sup_d.data_ptr(),
-                                       bufs.ptr("csup"), bufs.ptr("topv"), bufs.ptr("topi"), bufs.ptr("y0"), st))
+                if ncap:
+                    check(lib.bluest_price_capped(plan._h, grad.data_ptr(), bufs.ptr("mu"), s_d.data_ptr(), cc.data_ptr(), S, sup_d.data_ptr(),
+                                                  bufs.ptr("csup"), bufs.ptr("topv"), bufs.ptr("topi"), bufs.ptr("y0"),
+                                                  capmask_d.data_ptr(), nu_d.data_ptr(), bufs.ptr("out"), st))
+                else:
+                    check(lib.bluest_price(plan._h, grad.data_ptr(), bufs.ptr("mu"), s_d.data_ptr(), cc.data_ptr(), S, sup_d.data_ptr(),
+                                           bufs.ptr("csup"), bufs.ptr("topv"), bufs.ptr("topi"), bufs.ptr("y0"), st))
                 h = bufs.fetch()                                  # the round's only synchronisation
+                nu_h = nu_d.cpu().numpy()[:ncap] if ncap else None
                 if sharded is not None:
                     # every rank priced its own groups: merge the candidates and the support's reduced costs (a rank reports 0
                     # for groups it does not own; reduced costs are >= 0).  Same data, same order on every rank.
@@ -221,9 +285,13 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
                 A = 2.0 * float(a @ h["y0"])                      # y_{o,0} of the vectors the c_i were taken with (NOT V: see k_price)
                 cmax = max(float(h["topv"].max()), float(h["csup"][:S].max()))
                 lb = A * A / (4.0 * cmax) if cmax > 0.0 else 0.0
+                if ncap:                                          # Lagrangian relaxation of the caps (multipliers F^2 nu >= 0: any are valid)
+                    lb = max(A - cmax - float(out[0]) ** 2 * float(nu_h @ cap_rhs), 0.0)
                 if lb > best_lb:                                  # the point + multipliers the bound was obtained at: a certificate
                     best_lb = lb                                  # anybody can re-evaluate (tests do, with the CPU checker)
                     cert = {"support": keep.copy(), "x": xs.copy(), "mu": mu.copy(), "background": float(eps), "lower_bound": lb}
+                    if ncap:
+                        cert["cap_multipliers"] = float(out[0]) ** 2 * nu_h
                 gap = 1.0 - best_lb / F
                 level = float(h["csup"][:S][pos] @ xs[pos]) / float(xs[pos].sum())
                 order = np.lexsort((h["topi"], -h["topv"]))       # largest first, ties by index
@@ -263,8 +331,20 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
         keep_h = np.ascontiguousarray(keep, dtype=np.int64)
         cc_keep = np.ascontiguousarray(cc_h[keep])
         mplan, msup = master_plan(keep_h)
-        check(lib.bluest_master_newton(mplan._h, S, msup.ctypes.data, cc_keep.ctypes.data, s_d.data_ptr(), None, 0.0,
-                                       bufs.ptr("xs"), bufs.ptr("mu"), 1.0e-10, newton_maxit, bufs.ptr("out"), st))
+        if ncap:
+            Acap_S, b0 = cap_system(keep, 0.0)
+            start = cap_feasible_start(xs, Acap_S, b0) if (Acap_S @ xs > b0).any() else xs
+            if start is None:
+                return None, "no allocation on the final support respects the sample caps"
+            xs = start
+            bufs.put("xs", xs)
+            b_host = np.ascontiguousarray(b0)
+            check(lib.bluest_master_newton_capped(mplan._h, S, msup.ctypes.data, cc_keep.ctypes.data, s_d.data_ptr(), None, 0.0, bufs.ptr("xs"),
+                                                  bufs.ptr("mu"), 1.0e-10, newton_maxit, bufs.ptr("out"), ncap, cap_models.ctypes.data,
+                                                  b_host.ctypes.data, nu_d.data_ptr(), st))
+        else:
+            check(lib.bluest_master_newton(mplan._h, S, msup.ctypes.data, cc_keep.ctypes.data, s_d.data_ptr(), None, 0.0,
+                                           bufs.ptr("xs"), bufs.ptr("mu"), 1.0e-10, newton_maxit, bufs.ptr("out"), st))
         h = bufs.fetch()
         out = h["out"]
         info["newton_it"] += int(out[4])
@@ -281,6 +361,8 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
         info["polished"] = False
         if int(out[7]) != 2 and np.isfinite(out[0]):
             F_pol = true_F(h["xs"][:S])
+            if ncap and (cap_system(keep, 0.0)[0] @ np.maximum(h["xs"][:S], 0.0) > cap_rhs * (1.0 + 1.0e-9)).any():
+                F_pol = np.inf
             if F_pol < F_true:
                 xs, mu, F_true = h["xs"][:S].copy(), h["mu"].copy(), F_pol
                 info["polished"] = True
@@ -292,6 +374,11 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None):
     x = np.zeros(L)
     x[keep] = np.maximum(xs, 0.0)
     x /= x.sum()
+    if ncap:
+        used = cap_system(keep, 0.0)[0] @ (np.maximum(xs, 0.0) / max(float(np.maximum(xs, 0.0).sum()), 1e-300))
+        if (used > cap_rhs * (1.0 + 1.0e-9)).any():
+            return None, "the final allocation violates a sample cap"
+        info["cap_usage"] = used / cap_rhs
     info.update({"F": F_true, "F_background": F_last, "lower_bound": best_lb, "gap": 1.0 - best_lb / F_true, "mu": mu,
                  "support": int((x > 0).sum()), "kkt": float(out[2]), "certificate": cert})
     return x, info

@@ -19,6 +19,8 @@
 #define MASTER_THREADS 512
 #define MASTER_SMAX 64
 #define MASTER_PACT 4      // outputs that can be active (tie at the maximum) at once inside the master
+#define MASTER_MCAP 4      // sample caps (max_model_samples rows) that can be in the step as equality rows at once
+#define MASTER_NE (MASTER_PACT + MASTER_MCAP + 1)      // columns of E: active outputs, active caps, the simplex row
 #define MASTER_OUT 16      // doubles in front of r[] in the result record
 
 struct MasterArgs {
@@ -36,12 +38,16 @@ struct MasterArgs {
     double *x;                         // [S] in: start (>= 0), out: solution (sum 1)
     double *mu;                        // [n_out] in: multipliers of the previous master (or < 0: none), out: multipliers
     double *out;                       // [MASTER_OUT + n_out]: F, lam, kkt, spread, it, evals, solves, status, damp, ..., r[n_out]
+    int ncap;                          // per-model sample caps (bluest/sap.py:222-240): sum_{j: model in group j} (1-eps) cc_j x_j <= cap_b
+    const int32_t *cap_model;          // [ncap] the capped model
+    const double *cap_b;               // [ncap] right-hand side in the scaled variable (the background's share already taken off)
+    double *nu;                        // [ncap] out: cap multipliers (>= 0)
 };
 
 struct MasterLds {                     // carved out of dynamic LDS by master_carve()
     double *PHI, *TACT, *BLK, *M, *AAC, *GQ;
-    double *x, *xt, *d, *cc, *Dm, *glv, *mvec, *r, *rt, *mu, *muh, *scal;
-    int *kk, *fi, *act, *istate;
+    double *x, *xt, *d, *cc, *Dm, *glv, *mvec, *r, *rt, *mu, *muh, *scal, *capb, *capslack, *nu;
+    int *kk, *fi, *act, *istate, *capmodel, *actc;
     signed char *pos;
     unsigned char *idx;
     unsigned long long *memb;          // [N] bit j: support group j contains the model
@@ -50,16 +56,16 @@ struct MasterLds {                     // carved out of dynamic LDS by master_ca
 
 __host__ __device__ inline size_t master_lds_bytes(int N, int n_out, int S, int KM)
 {
-    const size_t LDN = N + 1, LDM = (S + MASTER_PACT + 2) | 1, KE = (size_t)KM * (KM + 1) / 2;
+    const size_t LDN = N + 1, LDM = (S + MASTER_NE + 1) | 1, KE = (size_t)KM * (KM + 1) / 2;
     size_t d = (size_t)n_out * N * LDN + (size_t)MASTER_PACT * N * LDN + (size_t)S * n_out * KE + (size_t)S * LDM +
-               (size_t)MASTER_PACT * S * KM + (size_t)S * MASTER_PACT + 7 * (size_t)S + 4 * (size_t)n_out + 64 + (size_t)N;
-    size_t bytes = d * sizeof(double) + (3 * (size_t)S + 2 * MASTER_PACT + 24) * sizeof(int) + (size_t)S * N + (size_t)S * KM + 64;
+               (size_t)MASTER_PACT * S * KM + (size_t)S * MASTER_PACT + 7 * (size_t)S + 4 * (size_t)n_out + 256 + 3 * 64 + (size_t)N;
+    size_t bytes = d * sizeof(double) + (3 * (size_t)S + 2 * MASTER_PACT + 32 + 64 + 2 * MASTER_MCAP) * sizeof(int) + (size_t)S * N + (size_t)S * KM + 64;
     return (bytes + 15) & ~(size_t)15;
 }
 
 __device__ inline void master_carve(MasterLds &L, unsigned char *base, int N, int n_out, int S, int KM)
 {
-    L.LDN = N + 1; L.LDM = (S + MASTER_PACT + 2) | 1; L.KE = KM * (KM + 1) / 2;
+    L.LDN = N + 1; L.LDM = (S + MASTER_NE + 1) | 1; L.KE = KM * (KM + 1) / 2;
     double *p = reinterpret_cast<double *>(base);
     L.PHI = p;  p += (size_t)n_out * N * L.LDN;
     L.TACT = p; p += (size_t)MASTER_PACT * N * L.LDN;
@@ -69,10 +75,12 @@ __device__ inline void master_carve(MasterLds &L, unsigned char *base, int N, in
     L.GQ = p;   p += (size_t)S * MASTER_PACT;
     L.x = p; p += S; L.xt = p; p += S; L.d = p; p += S; L.cc = p; p += S; L.Dm = p; p += S; L.glv = p; p += S; L.mvec = p; p += S;
     L.r = p; p += n_out; L.rt = p; p += n_out; L.mu = p; p += n_out; L.muh = p; p += n_out;
-    L.scal = p; p += 64;
+    L.scal = p; p += 256;
+    L.capb = p; p += 64; L.capslack = p; p += 64; L.nu = p; p += 64;
     L.memb = reinterpret_cast<unsigned long long *>(p); p += N;
     int *q = reinterpret_cast<int *>(p);
-    L.kk = q; q += S; L.fi = q; q += S; L.act = q; q += 2 * MASTER_PACT; L.istate = q; q += 24;      // act: current list, then the iteration's list (act0)
+    L.kk = q; q += S; L.fi = q; q += S; L.act = q; q += 2 * MASTER_PACT; L.istate = q; q += 32;      // act: current list, then the iteration's list (act0)
+    L.capmodel = q; q += 64; L.actc = q; q += 2 * MASTER_MCAP;                                       // actc: current caps of the step, then the iteration's (actc0)
     q += S;     // spare
     L.pos = reinterpret_cast<signed char *>(q);
     L.idx = reinterpret_cast<unsigned char *>(L.pos + (size_t)S * N);
@@ -81,7 +89,17 @@ __device__ inline void master_carve(MasterLds &L, unsigned char *base, int N, in
 // scal[] slots
 enum { SC_F = 0, SC_LAMEST, SC_DAMP, SC_TAU, SC_LAM, SC_PRED, SC_KKT, SC_SPREAD, SC_QMAX, SC_FT, SC_LAMX };
 // istate[] slots
-enum { IS_NACT = 0, IS_NF, IS_OK, IS_DONE, IS_ACCEPT, IS_IT, IS_EVALS, IS_SOLVES, IS_STATUS, IS_NACT0, IS_TINY, IS_NALIVE, IS_ALIVE /* .. +PACT */ };
+enum { IS_NACT = 0, IS_NF, IS_OK, IS_DONE, IS_ACCEPT, IS_IT, IS_EVALS, IS_SOLVES, IS_STATUS, IS_NACT0, IS_TINY, IS_NALIVE, IS_ALIVE /* .. +PACT */,
+       IS_NCACT0 = IS_ALIVE + MASTER_PACT, IS_NCALIVE, IS_CALIVE /* .. +MCAP */, IS_CLOCK = IS_CALIVE + MASTER_MCAP /* .. +MCAP */ };
+// scal[] blocks: 16.. q of the act0 outputs, 20.. q at the trial point, 24.. new multipliers (act0 order), 28.. new cap multipliers
+// (actc0 order), 64.. K = E^T M^-1 E (MASTER_NE x MASTER_NE)
+#define SCK 64
+
+// coefficient of support entry j in cap c: (1 - eps) cc_j if the capped model is in group j
+__device__ __forceinline__ double cap_a(const MasterArgs &A, const MasterLds &L, int c, int j)
+{
+    return L.pos[j * A.N + L.capmodel[c]] >= 0 ? (1.0 - A.eps_bg) * L.cc[j] : 0.0;
+}
 
 // packed symmetric index of (l, l2), l <= l2, in a k x k block
 __device__ __forceinline__ int sym_e(int l, int l2, int k) { return l * k - l * (l - 1) / 2 + (l2 - l); }
@@ -235,15 +253,14 @@ __device__ void master_build_system(const MasterArgs &A, MasterLds &L, int tid)
         L.M[fa * LDM + fb] = h;
         L.M[fb * LDM + fa] = h;
     }
-    // E = [GQ columns of the CURRENT active outputs, 1]
-    for (int t = tid; t < nf * (nact + 1); t += MASTER_THREADS) {
-        const int fa = t / (nact + 1), e = t % (nact + 1);
+    // E = [GQ columns of the active outputs (act0 order), rows of the iteration's caps (actc0 order), 1]
+    const int ncact = L.istate[IS_NCACT0], ne = nact + ncact + 1;
+    (void)nact0;
+    for (int t = tid; t < nf * ne; t += MASTER_THREADS) {
+        const int fa = t / ne, e = t % ne;
         double v = 1.0;
-        if (e < nact) {
-            int a0 = 0;                                 // position of this output in the act0 list (GQ columns follow act0)
-            for (int q = 0; q < nact0; q++) if (L.act[q + MASTER_PACT] == L.act[e]) a0 = q;
-            v = L.GQ[L.fi[fa] * MASTER_PACT + a0];
-        }
+        if (e < nact) v = L.GQ[L.fi[fa] * MASTER_PACT + e];
+        else if (e < nact + ncact) v = cap_a(A, L, L.actc[MASTER_MCAP + e - nact], L.fi[fa]);
         L.M[fa * LDM + nf + e] = v;
     }
     __syncthreads();
@@ -253,8 +270,8 @@ __device__ void master_build_system(const MasterArgs &A, MasterLds &L, int tid)
 __device__ void master_factor_wave(const MasterArgs &A, MasterLds &L, int lane)
 {
     const int LDM = L.LDM;
-    const int nf = L.istate[IS_NF], nact = L.istate[IS_NACT];
-    const int ne = nact + 1;
+    const int nf = L.istate[IS_NF], nact = L.istate[IS_NACT], ncact = L.istate[IS_NCACT0];
+    const int ne = nact + ncact + 1;
     bool ok = true;
     for (int p = 0; p < nf; p++) {
         const double piv = L.M[p * LDM + p];
@@ -274,58 +291,68 @@ __device__ void master_factor_wave(const MasterArgs &A, MasterLds &L, int lane)
         wave_lds_sync();
     }
     if (!ok) { if (lane == 0) L.istate[IS_OK] = 0; wave_lds_sync(); return; }
-    double Y[MASTER_PACT + 1], Eo[MASTER_PACT + 1];        // static loop bounds + guards: the arrays stay in registers
+    double Y[MASTER_NE], Eo[MASTER_NE];                    // static loop bounds + guards: the arrays stay in registers
     const double dinv = lane < nf ? 1.0 / L.M[lane * LDM + lane] : 0.0;
 #pragma unroll
-    for (int e = 0; e < MASTER_PACT + 1; e++) {
+    for (int e = 0; e < MASTER_NE; e++) {
         Y[e] = 0.0; Eo[e] = 0.0;
         if (e < ne && lane < nf) {
             Y[e] = L.M[lane * LDM + nf + e] * dinv;
             L.M[lane * LDM + nf + e] = Y[e];
-            Eo[e] = e < nact ? L.GQ[L.fi[lane] * MASTER_PACT + e] : 1.0;      // act == act0 order: GQ column e
+            Eo[e] = e < nact ? L.GQ[L.fi[lane] * MASTER_PACT + e]
+                  : (e < nact + ncact ? cap_a(A, L, L.actc[MASTER_MCAP + e - nact], L.fi[lane]) : 1.0);
         }
     }
 #pragma unroll
-    for (int e = 0; e < MASTER_PACT + 1; e++)
+    for (int e = 0; e < MASTER_NE; e++)
 #pragma unroll
-        for (int e2 = 0; e2 < MASTER_PACT + 1; e2++) {
+        for (int e2 = 0; e2 < MASTER_NE; e2++) {
             if (e < ne && e2 < ne) {                       // wave-uniform
                 const double k = wave_sum(Eo[e] * Y[e2]);
-                if (lane == 0) L.scal[32 + e * (MASTER_PACT + 1) + e2] = k;
+                if (lane == 0) L.scal[SCK + e * MASTER_NE + e2] = k;
             }
         }
-    if (lane == 0) { L.istate[IS_OK] = 1; for (int e = 0; e < MASTER_PACT; e++) L.istate[IS_ALIVE + e] = e < nact; }
+    if (lane == 0) {
+        L.istate[IS_OK] = 1;
+        for (int e = 0; e < MASTER_PACT; e++) L.istate[IS_ALIVE + e] = e < nact;
+        for (int e = 0; e < MASTER_MCAP; e++) { L.istate[IS_CALIVE + e] = e < ncact; L.istate[IS_CLOCK + e] = 0; }
+    }
     wave_lds_sync();
 }
 
-// wave 0: the small KKT system  K z + [1_p; 0] tau = rhs_q,  sum z[0..p) = rhs_sum  over the alive outputs, then the step
-// out_j = -Y z on the free rows.  soc = false: the SQP step (rhs_q = q at x, rhs_sum = 1): outputs whose multiplier comes out
-// negative leave the alive set, multipliers / lam / tau are published.  soc = true: the second-order correction (rhs_q = q at
-// the trial point, rhs_sum = 0) with the alive set as the step left it.  Every lane solves redundantly (identical inputs).
+// wave 0: the small KKT system over the alive outputs (p), alive caps (pc), the simplex row and tau:
+//     K z + [1_p; 0; 0] tau = [rhs_q; rhs_c; 0],   sum z[0..p) = rhs_sum,
+// then the step out_j = -Y z on the free rows.  soc = false: the SQP step (rhs_q = q at x, rhs_c = -(b_c - a_c.x), rhs_sum = 1):
+// outputs / caps whose multiplier comes out negative leave the alive sets; a cap AT its bound that was dropped comes back (and
+// stays) if the step would violate it; multipliers / lam / tau are published.  soc = true: the second-order correction (rhs_q = q
+// at the trial point, rhs_c = 0, rhs_sum = 0) with the alive sets as the step left them.  The (<= 10 x 10) system is eliminated
+// by lane 0 out of LDS (run-time indexed private arrays would live in scratch memory); results are broadcast through LDS.
 __device__ void master_small_solve(const MasterArgs &A, MasterLds &L, int lane, bool soc, double *outvec)
 {
-    // the (<= 6 x 6) system is eliminated by lane 0 out of LDS (run-time indexed private arrays would live in scratch memory,
-    // a global round trip per access); the result is broadcast through LDS
-    __shared__ double Am[(MASTER_PACT + 2) * (MASTER_PACT + 3)];
-    __shared__ double zf[MASTER_PACT + 2];                 // multipliers in act order, then lam, tau at [PACT], [PACT+1]
-    __shared__ int alive[MASTER_PACT], map[MASTER_PACT + 1], okflag;
+    constexpr int NU = MASTER_PACT + MASTER_MCAP + 2, W = NU + 1;
+    __shared__ double Am[NU * W];
+    __shared__ double zf[MASTER_PACT], nuf[MASTER_MCAP], zlt[2];      // multipliers (act0 / actc0 order), lam, tau
+    __shared__ int alive[MASTER_PACT], calive[MASTER_MCAP], clock[MASTER_MCAP], map[NU], okflag, redo;
     const int S = A.S, LDM = L.LDM;
-    const int nf = L.istate[IS_NF], nact = L.istate[IS_NACT];
-    const int W = MASTER_PACT + 3;
+    const int nf = L.istate[IS_NF], nact = L.istate[IS_NACT], ncact = L.istate[IS_NCACT0];
     if (lane == 0) {
         for (int e = 0; e < MASTER_PACT; e++) alive[e] = L.istate[IS_ALIVE + e];
-        bool ok = false;
-        int p = 0;
-        for (int round = 0; round <= MASTER_PACT; round++) {
-            p = 0;
+        for (int e = 0; e < MASTER_MCAP; e++) { calive[e] = L.istate[IS_CALIVE + e]; clock[e] = L.istate[IS_CLOCK + e]; }
+    }
+    wave_lds_sync();
+    for (int round = 0; round < 4 * (MASTER_PACT + MASTER_MCAP) + 4; round++) {
+        if (lane == 0) {
+            int p = 0, pc = 0;
             for (int e = 0; e < nact; e++) if (alive[e]) map[p++] = e;
-            map[p] = nact;                                                   // the "ones" column (index nact in K)
-            const int n = p + 2;
+            for (int e = 0; e < ncact; e++) if (calive[e]) map[p + pc++] = nact + e;
+            map[p + pc] = nact + ncact;                                      // the simplex column of K
+            const int nk = p + pc + 1, n = nk + 1;
             for (int a = 0; a < n; a++) for (int b = 0; b <= n; b++) Am[a * W + b] = 0.0;
-            for (int a = 0; a <= p; a++)
-                for (int b = 0; b <= p; b++) Am[a * W + b] = L.scal[32 + map[a] * (MASTER_PACT + 1) + map[b]];
-            for (int a = 0; a < p; a++) { Am[a * W + p + 1] = 1.0; Am[(p + 1) * W + a] = 1.0; Am[a * W + n] = L.scal[(soc ? 20 : 16) + map[a]]; }
-            Am[(p + 1) * W + n] = soc ? 0.0 : 1.0;
+            for (int a = 0; a < nk; a++)
+                for (int b = 0; b < nk; b++) Am[a * W + b] = L.scal[SCK + map[a] * MASTER_NE + map[b]];
+            for (int a = 0; a < p; a++) { Am[a * W + nk] = 1.0; Am[nk * W + a] = 1.0; Am[a * W + n] = L.scal[(soc ? 20 : 16) + map[a]]; }
+            for (int a = 0; a < pc; a++) Am[(p + a) * W + n] = soc ? 0.0 : -L.capslack[L.actc[MASTER_MCAP + map[p + a] - nact]];
+            Am[nk * W + n] = soc ? 0.0 : 1.0;
             bool sing = false;                                               // Gaussian elimination with partial pivoting
             for (int c = 0; c < n; c++) {
                 int pr = c; double best = fabs(Am[c * W + c]);
@@ -339,42 +366,122 @@ __device__ void master_small_solve(const MasterArgs &A, MasterLds &L, int lane, 
                     if (f != 0.0) for (int b = c; b <= n; b++) Am[rr * W + b] -= f * Am[c * W + b];
                 }
             }
-            if (sing) break;
-            int worst = -1; double wv = -1.0e-12;
-            if (!soc && p > 1)
-                for (int a = 0; a < p; a++) { const double za = Am[a * W + n] / Am[a * W + a]; if (za < wv) { wv = za; worst = a; } }
-            if (worst < 0) {
-                for (int e = 0; e < MASTER_PACT + 2; e++) zf[e] = 0.0;
-                for (int a = 0; a < p; a++) zf[map[a]] = Am[a * W + n] / Am[a * W + a];
-                zf[MASTER_PACT] = Am[p * W + n] / Am[p * W + p];
-                zf[MASTER_PACT + 1] = Am[(p + 1) * W + n] / Am[(p + 1) * W + p + 1];
-                ok = true;
-                break;
+            okflag = sing ? 0 : 1;
+            redo = 0;
+            if (!sing) {
+                int worst = -1; double wv = -1.0e-12;
+                if (!soc && p > 1)
+                    for (int a = 0; a < p; a++) { const double za = Am[a * W + n] / Am[a * W + a]; if (za < wv) { wv = za; worst = a; } }
+                if (worst >= 0) { alive[map[worst]] = 0; redo = 1; }
+                else if (!soc) {                                             // most negative droppable cap multiplier
+                    int wc = -1; double wcv = -1.0e-12;
+                    for (int a = 0; a < pc; a++) {
+                        const int ec = map[p + a] - nact;
+                        const double za = Am[(p + a) * W + n] / Am[(p + a) * W + p + a];
+                        if (za < wcv && !clock[ec]) { wcv = za; wc = ec; }
+                    }
+                    if (wc >= 0) { calive[wc] = 0; redo = 1; }
+                }
+                if (!redo) {
+                    for (int e = 0; e < MASTER_PACT; e++) zf[e] = 0.0;
+                    for (int e = 0; e < MASTER_MCAP; e++) nuf[e] = 0.0;
+                    for (int a = 0; a < p; a++) zf[map[a]] = Am[a * W + n] / Am[a * W + a];
+                    for (int a = 0; a < pc; a++) nuf[map[p + a] - nact] = Am[(p + a) * W + n] / Am[(p + a) * W + p + a];
+                    zlt[0] = Am[(nk - 1) * W + n] / Am[(nk - 1) * W + nk - 1];
+                    zlt[1] = Am[nk * W + n] / Am[nk * W + nk];
+                }
             }
-            alive[map[worst]] = 0;
         }
-        okflag = ok ? 1 : 0;
-        if (ok && !soc) {
-            L.scal[SC_LAM] = zf[MASTER_PACT]; L.scal[SC_TAU] = zf[MASTER_PACT + 1];
+        wave_lds_sync();
+        if (!okflag) { if (lane == 0) L.istate[IS_OK] = 0; wave_lds_sync(); return; }
+        if (redo) continue;
+        double di = 0.0;
+        if (lane < nf) {
+            for (int e = 0; e < nact; e++) di = fma(L.M[lane * LDM + nf + e], zf[e], di);
+            for (int e = 0; e < ncact; e++) di = fma(L.M[lane * LDM + nf + nact + e], nuf[e], di);
+            di = fma(L.M[lane * LDM + nf + nact + ncact], zlt[0], di);
+        }
+        for (int j = lane; j < S; j += 64) outvec[j] = 0.0;
+        wave_lds_sync();
+        if (lane < nf) outvec[L.fi[lane]] = -di;
+        wave_lds_sync();
+        // a cap at its bound that was dropped must not be violated by the step it was dropped from: it comes back, locked
+        int back = 0;
+        if (!soc)
+            for (int e = 0; e < ncact; e++) {
+                if (calive[e]) continue;                                     // uniform (LDS)
+                const int c = L.actc[MASTER_MCAP + e];
+                const double bc = L.capb[c];
+                if (!(L.capslack[c] <= 1.0e-10 * fmax(fabs(bc), 1.0))) continue;
+                double part = 0.0;
+                for (int j = lane; j < S; j += 64) part = fma(cap_a(A, L, c, j), outvec[j], part);
+                part = wave_sum(part);
+                if (part > 1.0e-12 * fmax(fabs(bc), 1.0)) { if (lane == 0) { calive[e] = 1; clock[e] = 1; } back = 1; }
+            }
+        wave_lds_sync();
+        if (back) continue;
+        break;
+    }
+    if (lane == 0) {
+        if (!soc) {
+            L.scal[SC_LAM] = zlt[0]; L.scal[SC_TAU] = zlt[1];
             double tot = 0.0;
             for (int e = 0; e < nact; e++) tot += zf[e] > 0.0 ? zf[e] : 0.0;
             for (int e = 0; e < nact; e++) L.scal[24 + e] = tot > 0.0 ? (zf[e] > 0.0 ? zf[e] : 0.0) / tot : 0.0;   // new multipliers, act order
+            for (int e = 0; e < MASTER_MCAP; e++) L.scal[28 + e] = (e < ncact && tot > 0.0 && nuf[e] > 0.0) ? nuf[e] / tot : 0.0;
             int na = 0;
             for (int e = 0; e < MASTER_PACT; e++) { L.istate[IS_ALIVE + e] = alive[e]; na += (e < nact && alive[e]) ? 1 : 0; }
+            for (int e = 0; e < MASTER_MCAP; e++) { L.istate[IS_CALIVE + e] = calive[e]; L.istate[IS_CLOCK + e] = clock[e]; }
             L.istate[IS_NALIVE] = na;
         }
-        L.istate[IS_OK] = okflag;
+        L.istate[IS_OK] = 1;
     }
     wave_lds_sync();
-    if (!okflag) return;
-    double di = 0.0;
-    if (lane < nf) {
-        for (int e = 0; e < nact; e++) di = fma(L.M[lane * LDM + nf + e], zf[e], di);
-        di = fma(L.M[lane * LDM + nf + nact], zf[MASTER_PACT], di);
+}
+
+// wave 0: make the trial point L.xt respect every cap (L.x does).  Clipping negative entries and renormalising moves mass
+// between capped and uncapped groups, so a cap the step kept at its bound can end slightly violated.  First REPAIR -- scale the
+// entries of the most violated cap's groups down to its bound and hand the freed mass to the other entries in proportion (a few
+// rounds: caps overlap) --, then, if something is still violated, the furthest feasible point of the segment x -> xt.
+__device__ void master_cap_feasible(const MasterArgs &A, MasterLds &L, int lane)
+{
+    const int S = A.S, ncap = A.ncap;
+    for (int round = 0; round < 8; round++) {
+        double ratio = 0.0;
+        if (lane < ncap) {
+            double ax = 0.0;
+            for (int j = 0; j < S; j++) ax = fma(cap_a(A, L, lane, j), L.xt[j], ax);
+            ratio = ax / (L.capb[lane] > 0.0 ? L.capb[lane] : 1.0);
+        }
+        // argmax over the caps (ties: smaller index), wave-uniform
+        double best = ratio; int who = lane;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double b2 = __shfl_xor(best, off, 64);
+            const int w2 = __shfl_xor(who, off, 64);
+            if (b2 > best || (b2 == best && w2 < who)) { best = b2; who = w2; }
+        }
+        if (!(best > 1.0 + 1.0e-13)) break;
+        const bool msk = lane < S && cap_a(A, L, who, lane) > 0.0;
+        const double xv = lane < S ? L.xt[lane] : 0.0;
+        const double capped = wave_sum(msk ? xv : 0.0), rest = wave_sum(msk ? 0.0 : xv);
+        if (!(rest > 0.0)) break;
+        const double freed = (1.0 - 1.0 / best) * capped;
+        if (lane < S) L.xt[lane] = msk ? xv / best : xv * (1.0 + freed / rest);
+        wave_lds_sync();
     }
-    for (int j = lane; j < S; j += 64) outvec[j] = 0.0;
-    wave_lds_sync();
-    if (lane < nf) outvec[L.fi[lane]] = -di;
+    double theta = INFINITY;
+    if (lane < ncap) {
+        double axt = 0.0;
+        for (int j = 0; j < S; j++) axt = fma(cap_a(A, L, lane, j), L.xt[j], axt);
+        const double ax = L.capb[lane] - L.capslack[lane];
+        if (axt > L.capb[lane] * (1.0 + 1.0e-12) + 1.0e-300) theta = L.capslack[lane] / (axt - ax);
+    }
+    theta = -wave_max(-theta);
+    if (theta < INFINITY) {
+        theta = fmax(theta, 0.0);
+        if (lane < S) L.xt[lane] = fma(theta, L.xt[lane] - L.x[lane], L.x[lane]);
+    }
     wave_lds_sync();
 }
 
@@ -395,8 +502,9 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
     for (int t = tid; t < S * KM; t += MASTER_THREADS) L.idx[t] = A.idx[t];
     for (int t = tid; t < S * N; t += MASTER_THREADS) L.pos[t] = -1;
     for (int o = tid; o < n_out; o += MASTER_THREADS) L.mu[o] = A.mu[o];
-    if (tid < 24) L.istate[tid] = 0;
-    if (tid < 64) L.scal[tid] = 0.0;
+    if (tid < 32) L.istate[tid] = 0;
+    for (int t = tid; t < 256; t += MASTER_THREADS) L.scal[t] = 0.0;
+    if (tid < 64) { L.capmodel[tid] = tid < A.ncap ? A.cap_model[tid] : 0; L.capb[tid] = tid < A.ncap ? A.cap_b[tid] : 0.0; L.nu[tid] = 0.0; L.capslack[tid] = 0.0; }
     __syncthreads();
     for (int t = tid; t < S * KM; t += MASTER_THREADS) {
         const int j = t / KM, l = t % KM;
@@ -444,6 +552,35 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
     __syncthreads();
 
     for (int it = 0; it < A.maxit && !L.istate[IS_DONE]; it++) {
+        if (A.ncap > 0) {   // slack of every cap at x (lane = cap), then the caps of this iteration's step: at their bound or carrying
+            if (wave == 0) {   // a multiplier, at most MASTER_MCAP, smallest slack first
+                if (lane < A.ncap) {
+                    double ax = 0.0;
+                    for (int j = 0; j < S; j++) ax = fma(cap_a(A, L, lane, j), L.x[j], ax);
+                    L.capslack[lane] = L.capb[lane] - ax;
+                }
+                wave_lds_sync();
+                if (lane == 0) {
+                    int n0 = 0;
+                    for (int pick = 0; pick < MASTER_MCAP; pick++) {
+                        int best = -1;
+                        for (int c = 0; c < A.ncap; c++) {
+                            bool taken = false;
+                            for (int q = 0; q < n0; q++) if (L.actc[MASTER_MCAP + q] == c) taken = true;
+                            if (taken) continue;
+                            if (!(L.capslack[c] <= 1.0e-10 * fmax(fabs(L.capb[c]), 1.0) || L.nu[c] > 0.0)) continue;
+                            if (best < 0 || L.capslack[c] < L.capslack[best]) best = c;
+                        }
+                        if (best < 0) break;
+                        L.actc[MASTER_MCAP + n0++] = best;
+                    }
+                    for (int a = 0; a < n0; a++) for (int b = a + 1; b < n0; b++)      // ascending cap index
+                        if (L.actc[MASTER_MCAP + b] < L.actc[MASTER_MCAP + a]) { const int t = L.actc[MASTER_MCAP + a]; L.actc[MASTER_MCAP + a] = L.actc[MASTER_MCAP + b]; L.actc[MASTER_MCAP + b] = t; }
+                    L.istate[IS_NCACT0] = n0;
+                }
+            }
+            __syncthreads();
+        }
         // ---- active outputs and their curvature weights (thread 0) -------------------------------------
         if (tid == 0) {
             const double F = L.scal[SC_F];
@@ -521,6 +658,7 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
             for (int j = lane; j < S; j += 64) {
                 double g = 0.0;
                 for (int a = 0; a < nact0; a++) g = fma(L.muh[L.act[a + MASTER_PACT]], L.GQ[j * MASTER_PACT + a], g);
+                for (int c = 0; c < A.ncap; c++) if (L.nu[c] > 0.0) g = fma(L.nu[c], cap_a(A, L, c, j), g);
                 L.glv[j] = g;
                 part = fma(g, L.x[j], part);
             }
@@ -568,6 +706,8 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
                     for (int j = lane; j < S; j += 64) {
                         double g = 0.0;
                         for (int a = 0; a < nact; a++) g = fma(L.scal[24 + a], L.GQ[j * MASTER_PACT + a], g);
+                        for (int e = 0; e < L.istate[IS_NCACT0]; e++)
+                            if (L.scal[28 + e] > 0.0) g = fma(L.scal[28 + e], cap_a(A, L, L.actc[MASTER_MCAP + e], j), g);
                         L.xt[j] = g;                    // scratch
                         part = fma(g, L.x[j], part);
                     }
@@ -607,6 +747,7 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
                 }
                 sx = wave_sum(sx);
                 for (int j = lane; j < S; j += 64) L.xt[j] = L.xt[j] / sx;
+                if (A.ncap > 0) { wave_lds_sync(); master_cap_feasible(A, L, lane); }
             }
             __syncthreads();
             TSTAMP(3);
@@ -650,6 +791,7 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
                         }
                         sx = wave_sum(sx);
                         for (int j = lane; j < S; j += 64) L.xt[j] = L.xt[j] / sx;
+                        if (A.ncap > 0) { wave_lds_sync(); master_cap_feasible(A, L, lane); }
                     }
                 }
                 __syncthreads();
@@ -669,6 +811,8 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
             if (tid == 0) {
                 for (int o = 0; o < n_out; o++) L.mu[o] = 0.0;
                 for (int a = 0; a < L.istate[IS_NACT0]; a++) L.mu[L.act[a + MASTER_PACT]] = L.scal[24 + a];
+                for (int c = 0; c < A.ncap; c++) L.nu[c] = 0.0;
+                for (int e = 0; e < L.istate[IS_NCACT0]; e++) L.nu[L.actc[MASTER_MCAP + e]] = L.scal[28 + e];
             }
         }
         if (converged) { if (tid == 0) L.istate[IS_DONE] = 1; __syncthreads(); break; }
@@ -682,6 +826,7 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
     // ---- results ------------------------------------------------------------------------------------------------------
     for (int j = tid; j < S; j += MASTER_THREADS) A.x[j] = L.x[j];
     for (int o = tid; o < n_out; o += MASTER_THREADS) { A.mu[o] = L.mu[o]; A.out[MASTER_OUT + o] = L.r[o]; }
+    for (int c = tid; c < A.ncap; c += MASTER_THREADS) A.nu[c] = L.nu[c];
     if (tid == 0) {
         A.out[0] = L.scal[SC_F]; A.out[1] = L.scal[SC_LAM]; A.out[2] = L.scal[SC_KKT]; A.out[3] = L.scal[SC_SPREAD];
         A.out[4] = L.istate[IS_IT]; A.out[5] = L.istate[IS_EVALS]; A.out[6] = L.istate[IS_SOLVES]; A.out[7] = L.istate[IS_STATUS];
@@ -763,13 +908,18 @@ __global__ __launch_bounds__(256) void k_price(int64_t L, int n_out, const doubl
                                                const double *__restrict__ s, const double *__restrict__ cc, int S,
                                                const int64_t *__restrict__ sup, double *__restrict__ c_sup,
                                                double *__restrict__ top_val, int64_t *__restrict__ top_idx,
-                                               const double *__restrict__ v_ws, int N, double *__restrict__ y0)
+                                               const double *__restrict__ v_ws, int N, double *__restrict__ y0,
+                                               const unsigned long long *__restrict__ capmask, const double *__restrict__ nu,
+                                               const double *__restrict__ master_out)
 {
+    // sample caps: c_i - cc_i F^2 sum_{caps c whose model is in group i} nu_c  (the master's multipliers are those of its
+    // reciprocal form; F^2 nu_c are the multipliers of the caps in the problem as posed).  capmask: bit c of entry i.
+    const double F2 = capmask ? master_out[0] * master_out[0] : 0.0;
     __shared__ double wv[4];
     __shared__ int64_t wi[4];
     __shared__ int wt[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double best = -1.0;
+    double best = -INFINITY;                               // (with caps a corrected reduced cost can be negative)
     int64_t besti = -1;
     for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < L; i += (int64_t)gridDim.x * 256) {
         double c = 0.0;
@@ -778,6 +928,12 @@ __global__ __launch_bounds__(256) void k_price(int64_t L, int n_out, const doubl
             if (li >= 0 && mu[o] > 0.0) c = fma(mu[o] / s[o], -grad[goff[o] + li], c);
         }
         c *= cc[i];
+        if (capmask) {
+            unsigned long long mk = capmask[i];
+            double corr = 0.0;
+            while (mk) { const int b = __ffsll((long long)mk) - 1; mk &= mk - 1ull; corr += nu[b]; }
+            c = fma(-cc[i] * F2, corr, c);
+        }
         if (c > best) { best = c; besti = i; }             // ascending scan: ties keep the smaller index
     }
     // y_{o,0}: component 0 of the vector the quadratic forms were taken with (row 0 of the inverse of the WHOLE information
@@ -792,7 +948,14 @@ __global__ __launch_bounds__(256) void k_price(int64_t L, int n_out, const doubl
                 const int32_t li = invmap ? invmap[(int64_t)o * L + i] : (int32_t)i;
                 if (li >= 0 && mu[o] > 0.0) c = fma(mu[o] / s[o], -grad[goff[o] + li], c);
             }
-            c_sup[j] = c * cc[i];
+            c *= cc[i];
+            if (capmask) {
+                unsigned long long mk = capmask[i];
+                double corr = 0.0;
+                while (mk) { const int b = __ffsll((long long)mk) - 1; mk &= mk - 1ull; corr += nu[b]; }
+                c = fma(-cc[i] * F2, corr, c);
+            }
+            c_sup[j] = c;
         }
     for (int r = 0; r < PRICE_TOP; r++) {
         // block argmax (ties: smaller index), fixed order
@@ -810,7 +973,7 @@ __global__ __launch_bounds__(256) void k_price(int64_t L, int n_out, const doubl
         for (int w = 1; w < 4; w++)
             if (wv[w] > bv || (wv[w] == bv && wi[w] >= 0 && (bi < 0 || wi[w] < bi))) { bv = wv[w]; bi = wi[w]; bt = wt[w]; }
         if (tid == 0) { top_val[blockIdx.x * PRICE_TOP + r] = bv; top_idx[blockIdx.x * PRICE_TOP + r] = bi; }
-        if (tid == bt) { best = -1.0; besti = -1; }
+        if (tid == bt) { best = -INFINITY; besti = -1; }
         __syncthreads();
     }
 }
@@ -845,9 +1008,31 @@ extern "C" int bluest_master_max_support(bluest_plan_t plan, int *s_max)
     return BLUEST_OK;
 }
 
+static int master_launch(bluest_plan_t plan, int S, const int64_t *support_host, const double *cc_host, const double *s_dev,
+                         const double *bg_dev, double eps_bg, double *x_dev, double *mu_dev, double tol, int maxit,
+                         double *out_dev, int ncap, const int32_t *cap_model_host, const double *cap_b_host, double *nu_dev, void *stream);
+
 extern "C" int bluest_master_newton(bluest_plan_t plan, int S, const int64_t *support_host, const double *cc_host, const double *s_dev,
                                     const double *bg_dev, double eps_bg, double *x_dev, double *mu_dev, double tol, int maxit,
                                     double *out_dev, void *stream)
+{
+    return master_launch(plan, S, support_host, cc_host, s_dev, bg_dev, eps_bg, x_dev, mu_dev, tol, maxit, out_dev, 0, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int bluest_master_newton_capped(bluest_plan_t plan, int S, const int64_t *support_host, const double *cc_host, const double *s_dev,
+                                           const double *bg_dev, double eps_bg, double *x_dev, double *mu_dev, double tol, int maxit,
+                                           double *out_dev, int ncap, const int32_t *cap_model_host, const double *cap_b_host,
+                                           double *nu_dev, void *stream)
+{
+    if (ncap < 0 || ncap > 64) return fail(BLUEST_ERR_ARG, "ncap=%d out of range (0..64)", ncap);
+    if (ncap > 0 && (!cap_model_host || !cap_b_host || !nu_dev)) return fail(BLUEST_ERR_ARG, "null pointer");
+    return master_launch(plan, S, support_host, cc_host, s_dev, bg_dev, eps_bg, x_dev, mu_dev, tol, maxit, out_dev, ncap, cap_model_host,
+                         cap_b_host, nu_dev, stream);
+}
+
+static int master_launch(bluest_plan_t plan, int S, const int64_t *support_host, const double *cc_host, const double *s_dev,
+                         const double *bg_dev, double eps_bg, double *x_dev, double *mu_dev, double tol, int maxit,
+                         double *out_dev, int ncap, const int32_t *cap_model_host, const double *cap_b_host, double *nu_dev, void *stream)
 {
     if (!plan || !support_host || !cc_host || !s_dev || !x_dev || !mu_dev || !out_dev) return fail(BLUEST_ERR_ARG, "null pointer");
     if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
@@ -900,7 +1085,10 @@ extern "C" int bluest_master_newton(bluest_plan_t plan, int S, const int64_t *su
     // one descriptor blob: [invcov pointers][boff][cc][kk][idx]
     const size_t b_ptr = (size_t)n_out * sizeof(void *), b_off = (size_t)n_out * S * sizeof(int64_t), b_cc = (size_t)S * sizeof(double),
                  b_kk = (((size_t)S * sizeof(int32_t)) + 7) & ~(size_t)7, b_idx = ((size_t)S * KM + 7) & ~(size_t)7;
-    const size_t total = b_ptr + b_off + b_cc + b_kk + b_idx;
+    for (int c = 0; c < ncap; c++)
+        if (cap_model_host[c] < 0 || cap_model_host[c] >= N) return fail(BLUEST_ERR_ARG, "capped model %d out of range", cap_model_host[c]);
+    const size_t b_cm = (((size_t)ncap * sizeof(int32_t)) + 7) & ~(size_t)7, b_cb = (size_t)ncap * sizeof(double);
+    const size_t total = b_ptr + b_off + b_cc + b_kk + b_idx + b_cm + b_cb;
     std::vector<unsigned char> blob(total);
     unsigned char *h = blob.data();
     for (int o = 0; o < n_out; o++) { const double *p = plan->outs[o].d_invcov; memcpy(h + o * sizeof(void *), &p, sizeof(void *)); }
@@ -908,6 +1096,10 @@ extern "C" int bluest_master_newton(bluest_plan_t plan, int S, const int64_t *su
     memcpy(h + b_ptr + b_off, cc_host, b_cc);
     memcpy(h + b_ptr + b_off + b_cc, kk.data(), (size_t)S * sizeof(int32_t));
     memcpy(h + b_ptr + b_off + b_cc + b_kk, idx.data(), (size_t)S * KM);
+    if (ncap > 0) {
+        memcpy(h + b_ptr + b_off + b_cc + b_kk + b_idx, cap_model_host, (size_t)ncap * sizeof(int32_t));
+        memcpy(h + b_ptr + b_off + b_cc + b_kk + b_idx + b_cm, cap_b_host, b_cb);
+    }
     DeviceScopeN scope(plan->device);
     if (plan->master_bytes < total) {
         if (plan->d_master) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(plan->d_master); plan->d_master = nullptr; }
@@ -930,6 +1122,10 @@ extern "C" int bluest_master_newton(bluest_plan_t plan, int S, const int64_t *su
     A.idx = (const uint8_t *)(d + b_ptr + b_off + b_cc + b_kk);
     A.s = s_dev; A.bg = eps_bg > 0.0 ? bg_dev : nullptr;
     A.x = x_dev; A.mu = mu_dev; A.out = out_dev;
+    A.ncap = ncap;
+    A.cap_model = (const int32_t *)(d + b_ptr + b_off + b_cc + b_kk + b_idx);
+    A.cap_b = (const double *)(d + b_ptr + b_off + b_cc + b_kk + b_idx + b_cm);
+    A.nu = nu_dev;
     // register-resident inverses for the usual sizes, the LDS version beyond 32 models.  Dynamic LDS beyond the default needs the
     // attribute (the kernel also has ~1 KB of static LDS: ask for what is needed, not for the whole limit)
 #define LAUNCH_MASTER(NT)                                                                                                     \
@@ -975,15 +1171,29 @@ extern "C" int bluest_support_point(int64_t L, int S, const int64_t *sup_dev, co
     return BLUEST_OK;
 }
 
+extern "C" int bluest_price_capped(bluest_plan_t plan, const double *grad_dev, const double *mu_dev, const double *s_dev, const double *cc_dev,
+                                   int S, const int64_t *sup_dev, double *c_sup_dev, double *top_val_dev, int64_t *top_idx_dev, double *y0_dev,
+                                   const uint64_t *capmask_dev, const double *nu_dev, const double *master_out_dev, void *stream);
+
 extern "C" int bluest_price(bluest_plan_t plan, const double *grad_dev, const double *mu_dev, const double *s_dev, const double *cc_dev,
                             int S, const int64_t *sup_dev, double *c_sup_dev, double *top_val_dev, int64_t *top_idx_dev, double *y0_dev,
                             void *stream)
 {
+    return bluest_price_capped(plan, grad_dev, mu_dev, s_dev, cc_dev, S, sup_dev, c_sup_dev, top_val_dev, top_idx_dev, y0_dev, nullptr, nullptr,
+                               nullptr, stream);
+}
+
+extern "C" int bluest_price_capped(bluest_plan_t plan, const double *grad_dev, const double *mu_dev, const double *s_dev, const double *cc_dev,
+                                   int S, const int64_t *sup_dev, double *c_sup_dev, double *top_val_dev, int64_t *top_idx_dev, double *y0_dev,
+                                   const uint64_t *capmask_dev, const double *nu_dev, const double *master_out_dev, void *stream)
+{
+    if (capmask_dev && (!nu_dev || !master_out_dev)) return fail(BLUEST_ERR_ARG, "null pointer");
     if (!plan || !grad_dev || !mu_dev || !s_dev || !cc_dev || !sup_dev || !c_sup_dev || !top_val_dev || !top_idx_dev || !y0_dev) return fail(BLUEST_ERR_ARG, "null pointer");
     if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
     const int n_out = (int)plan->outs.size();
     hipLaunchKernelGGL(k_price, dim3(PRICE_BLOCKS), dim3(256), 0, (hipStream_t)stream, plan->L, n_out, grad_dev, plan->d_goff,
-                       plan->identity ? nullptr : plan->d_invmap, mu_dev, s_dev, cc_dev, S, sup_dev, c_sup_dev, top_val_dev, top_idx_dev, plan->d_v, plan->N, y0_dev);
+                       plan->identity ? nullptr : plan->d_invmap, mu_dev, s_dev, cc_dev, S, sup_dev, c_sup_dev, top_val_dev, top_idx_dev, plan->d_v, plan->N, y0_dev,
+                       (const unsigned long long *)capmask_dev, nu_dev, master_out_dev);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }

@@ -427,7 +427,9 @@ class MOSAP(object):
         try:
             samples = alloc.solve(budget=budget, eps=eps, x0=x0, params=solver_params)
             self.solver_info = alloc.info
-            samples = enforce_sample_caps(self.plan, self.costs, cap_rows, cap_rhs, samples, budget, eps, solver_params, self)
+            cap_models = None if max_model_samples is None else [i for i in range(self.N) if np.isfinite(max_model_samples[i])]
+            samples = enforce_sample_caps(self.plan, self.costs, cap_rows, cap_rhs, samples, budget, eps, solver_params, self,
+                                          cap_models=cap_models)
         except BLUESTError as err:
             if self.verbose: print(str(err))
             self.samples = None

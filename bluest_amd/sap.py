@@ -125,7 +125,7 @@ def status_to_python(status, where):
         raise AssertionError("%s: information matrix is singular on the sampled models (bluest/misc.py:473-474)" % where)
 
 
-def enforce_sample_caps(plan, costs, es, rhs, samples, budget, eps, solver_params, owner):
+def enforce_sample_caps(plan, costs, es, rhs, samples, budget, eps, solver_params, owner, cap_models=None):
     """max_model_samples (bluest/sap.py:222-240): if the unconstrained optimum already respects the caps it is the answer;
     otherwise solve again over the capped set (bluest_amd/capped.py), started from the unconstrained allocation"""
     if len(es) == 0 or samples is None:
@@ -141,8 +141,22 @@ def enforce_sample_caps(plan, costs, es, rhs, samples, budget, eps, solver_param
         tot = float(np.asarray(ee, dtype=np.float64) @ clipped)
         if tot > rr:
             clipped[np.asarray(ee) > 0] *= rr / tot
+    budget_solver = None
+    if prm["method"] == "newton" and cap_models is not None and type(plan).__name__ == "Plan" and len(es) <= 64:
+        cap = {"models": np.asarray(cap_models, dtype=np.int32), "rows": np.stack([np.asarray(ee) for ee in es]), "rhs": np.asarray(rhs, dtype=np.float64)}
+        w_h = np.asarray(costs, dtype=np.float64)
+
+        def budget_solver(B, s_norm, start):
+            """the second-order finish with the caps inside its master problem (colgen.colgen_solve); None -> first-order fall-back"""
+            xn, ninfo = colgen_solve(plan, w_h, s_norm, float(B), prm=prm.get("newton"), caps=cap)
+            if xn is None:
+                return None
+            return (float(B) / w_h) * xn, {"it": ninfo["newton_it"], "count": ninfo["full_evals"] + ninfo["master_evals"], "gpmax": ninfo["kkt"],
+                                           "f": ninfo["F"], "solver_info": 0, "fevals": ninfo["full_evals"], "gevals": ninfo["full_evals"],
+                                           "pruned": int(len(xn) - ninfo["support"]), "method": "newton", "certified_gap": ninfo["gap"],
+                                           "rounds": ninfo["rounds"], "cap_usage": ninfo["cap_usage"], "multipliers": ninfo["mu"]}
     m, info = solve_capped(plan, costs, es, rhs, budget=budget, eps=eps, x0=clipped, prm=prm,
-                           unconstrained_cost=float(np.asarray(costs) @ samples))
+                           unconstrained_cost=float(np.asarray(costs) @ samples), budget_solver=budget_solver)
     if m is None:
         raise BLUESTError("SPG with max_model_samples: %s" % info.get("reason", "no feasible allocation"))
     owner.solver_info = info
@@ -683,8 +697,9 @@ class SAP(object):
         try:
             samples = alloc.solve(budget=budget, eps=None if eps is None else [eps], x0=x0, params=solver_params)
             self.solver_info = alloc.info
+            cap_models = None if max_model_samples is None else [i for i in range(self.N) if np.isfinite(max_model_samples[i])]
             samples = enforce_sample_caps(self.plan, self.costs, es, rhs, samples, budget, None if eps is None else [eps],
-                                          solver_params, self)
+                                          solver_params, self, cap_models=cap_models)
         except BLUESTError as err:
             if self.verbose: print(str(err))
             self.samples = None

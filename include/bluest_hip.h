@@ -335,6 +335,14 @@ int bluest_master_max_support(bluest_plan_t plan, int *s_max);
 int bluest_master_newton(bluest_plan_t plan, int S, const int64_t *support_host, const double *cc_host, const double *s_dev,
                          const double *bg_dev, double eps_bg, double *x_dev, double *mu_dev, double tol, int maxit,
                          double *out_dev, void *stream);
+/* the same master problem with per-model sample caps (max_model_samples, bluest/sap.py:222-240, bluest/mosap.py:326-344):
+ * sum over the support groups j containing model cap_model[c] of (1 - eps_bg) cc_j x_j <= cap_b[c]  (ncap <= 64; host arrays;
+ * the start x must satisfy them).  Caps at their bound are equality rows of the SQP step, a cap whose multiplier comes out
+ * negative leaves, trial points are repaired / pulled back onto the feasible set.  nu_dev (ncap): cap multipliers out. */
+int bluest_master_newton_capped(bluest_plan_t plan, int S, const int64_t *support_host, const double *cc_host, const double *s_dev,
+                                const double *bg_dev, double eps_bg, double *x_dev, double *mu_dev, double tol, int maxit,
+                                double *out_dev, int ncap, const int32_t *cap_model_host, const double *cap_b_host, double *nu_dev,
+                                void *stream);
 /* x_i <- x_i * cc_i * sum_o wgt_o q_{o,i}/s_o / sum_o wgt_o r_o,  m_i = cc_i x_i;  var/status/grad as bluest_plan_eval left them
  * for the allocation m; wgt_o ~ r_o^(p-1) (p-norm surrogate of the max) */
 int bluest_ma_update(bluest_plan_t plan, const double *var_dev, const int32_t *status_dev, const double *grad_dev,
@@ -349,6 +357,13 @@ int bluest_support_point(int64_t L, int S, const int64_t *sup_dev, const double 
 int bluest_price(bluest_plan_t plan, const double *grad_dev, const double *mu_dev, const double *s_dev, const double *cc_dev,
                  int S, const int64_t *sup_dev, double *c_sup_dev, double *top_val_dev, int64_t *top_idx_dev, double *y0_dev,
                  void *stream);
+
+/* bluest_price with sample caps: capmask_dev (L_global x uint64, bit c: the model of cap c is in the group), nu_dev (cap
+ * multipliers of bluest_master_newton_capped), master_out_dev (its result record: F at [0]); the reduced costs become
+ * c_i - (B/cost_i) F^2 sum_{c in mask_i} nu_c */
+int bluest_price_capped(bluest_plan_t plan, const double *grad_dev, const double *mu_dev, const double *s_dev, const double *cc_dev,
+                        int S, const int64_t *sup_dev, double *c_sup_dev, double *top_val_dev, int64_t *top_idx_dev, double *y0_dev,
+                        const uint64_t *capmask_dev, const double *nu_dev, const double *master_out_dev, void *stream);
 
 #ifdef __cplusplus
 }

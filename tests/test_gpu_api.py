@@ -482,6 +482,8 @@ def test_max_model_samples_under_spg(oracle):
     with pytest.raises(ValueError):
         sap.solve(budget=B, solver="spg", max_model_samples=caps[:-1])            # wrong length (sap.py:226-227)
     m_cap = sap.solve(budget=B, solver="spg", continuous_relaxation=True, max_model_samples=caps)
+    print("capped solve:", {k_: sap.solver_info.get(k_) for k_ in ("method", "it", "rounds", "certified_gap", "cap_usage")})
+    assert sap.solver_info.get("method") == "newton"        # the caps are rows of the master problem's KKT system (csrc/newton.hip)
     es, rhs = sap.get_max_sample_constraints(caps)
     assert m_cap is not None and (m_cap >= 0).all() and m_cap @ w <= B * (1 + 1e-9) and m_cap @ sap.e >= 1
     assert all(e @ m_cap <= r * (1 + 1e-9) for e, r in zip(es, rhs))              # the reference's check (sap.py:495)
@@ -524,6 +526,7 @@ def test_max_model_samples_under_spg(oracle):
     busy = int(np.argmax(per_model[1:])) + 1
     caps[busy] = max(1.0, np.floor(0.5 * per_model[busy]))
     m_cap = mos.solve(eps=eps, solver="spg", continuous_relaxation=True, max_model_samples=caps)
+    print("capped eps-mode solve:", {k_: mos.solver_info.get(k_) for k_ in ("method", "it", "rounds", "certified_gap", "cap_usage")})
     es, rhs = mos.get_max_sample_constraints(caps)
     assert m_cap is not None and all(e @ m_cap <= r * (1 + 1e-9) for e, r in zip(es, rhs))
     assert (np.array(mos.variances(m_cap)) <= eps ** 2 * (1 + 1e-6)).all()

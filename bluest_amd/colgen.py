@@ -309,6 +309,9 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
                         % (eps, rnd, F, gap, S, int(pos.sum()), int(out[4]), int(out[5]), len(enter), out[2], int(out[7])))
                 x_full = (keep[pos], xs[pos] / xs[pos].sum())
                 F_last = F
+                if int(out[7]) == 1 and int(out[4]) == 0 and rnd > 0:
+                    break                                          # the master cannot move from here (stalled): pricing again would
+                                                                   # offer the same columns; the certified gap says how far this is
                 if len(enter) == 0:
                     if mtol > 1.0e-9:
                         mtol = 1.0e-9                              # the support is priced out at a loose master: tighten once

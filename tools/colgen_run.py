@@ -17,14 +17,23 @@ for kv in sys.argv[4:]:
     k, v = kv.split("=")
     prm[k] = eval(v)
 verbose = prm.pop("verbose", False)
+ncaps = prm.pop("caps", 0)
 prob = synth.problem(n, kmax, n_out)
 groups = prob["groups"]
 mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in groups] for _ in range(n_out)],
             prob["costs"], [prob["costs"]] * n_out, verbose=False)
+caps = None
+if ncaps:        # the ncaps most sampled models capped at half of what the free optimum gives them
+    x_free, _ = colgen_solve(mos.plan, prob["costs"], np.ones(n_out), prob["budget"], prm=prm)
+    m_free = prob["budget"] / prob["costs"] * x_free
+    usage = np.array([float(mos.ES[i] @ m_free) for i in range(n)])
+    models = np.sort(np.argsort(-usage)[:ncaps])
+    caps = {"models": models, "rows": np.stack([mos.ES[i] for i in models]), "rhs": np.array([max(1.0, np.floor(0.5 * usage[i])) for i in models])}
+    print("caps:", models, caps["rhs"])
 for rep in range(3):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    x, info = colgen_solve(mos.plan, prob["costs"], np.ones(n_out), prob["budget"], prm=prm, log=print if (verbose and rep == 0) else None)
+    x, info = colgen_solve(mos.plan, prob["costs"], np.ones(n_out), prob["budget"], prm=prm, log=print if (verbose and rep == 0) else None, caps=caps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if x is None:
@@ -32,4 +41,4 @@ for rep in range(3):
         break
     m = prob["budget"] / prob["costs"] * x
     print("rep %d: %.4f s  max V %.12e  nnz %d  %s" % (rep, dt, max(mos.variances(m)), int((x > 0).sum()),
-                                                     {k: (float("%.4g" % v) if isinstance(v, float) else v) for k, v in info.items() if k not in ("mu", "certificate")}))
+                                                     {k: (float("%.4g" % v) if isinstance(v, float) else v) for k, v in info.items() if k not in ("mu", "certificate", "cap_usage")}))

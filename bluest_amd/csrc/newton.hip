@@ -18,7 +18,7 @@
 #endif
 #define MASTER_THREADS 512
 #define MASTER_SMAX 64
-#define MASTER_PACT 4      // outputs that can be active (tie at the maximum) at once inside the master
+#define MASTER_PACT 6      // candidate outputs (within act_tol of the maximum) of one step of the master
 #define MASTER_MCAP 4      // sample caps (max_model_samples rows) that can be in the step as equality rows at once
 #define MASTER_NE (MASTER_PACT + MASTER_MCAP + 1)      // columns of E: active outputs, active caps, the simplex row
 #define MASTER_OUT 16      // doubles in front of r[] in the result record
@@ -59,7 +59,7 @@ __host__ __device__ inline size_t master_lds_bytes(int N, int n_out, int S, int 
     const size_t LDN = N + 1, LDM = (S + MASTER_NE + 1) | 1, KE = (size_t)KM * (KM + 1) / 2;
     size_t d = (size_t)n_out * N * LDN + (size_t)MASTER_PACT * N * LDN + (size_t)S * n_out * KE + (size_t)S * LDM +
                (size_t)MASTER_PACT * S * KM + (size_t)S * MASTER_PACT + 7 * (size_t)S + 4 * (size_t)n_out + 256 + 3 * 64 + (size_t)N;
-    size_t bytes = d * sizeof(double) + (3 * (size_t)S + 2 * MASTER_PACT + 32 + 64 + 2 * MASTER_MCAP) * sizeof(int) + (size_t)S * N + (size_t)S * KM + 64;
+    size_t bytes = d * sizeof(double) + (3 * (size_t)S + 2 * MASTER_PACT + 48 + 64 + 2 * MASTER_MCAP) * sizeof(int) + (size_t)S * N + (size_t)S * KM + 64;
     return (bytes + 15) & ~(size_t)15;
 }
 
@@ -79,7 +79,7 @@ __device__ inline void master_carve(MasterLds &L, unsigned char *base, int N, in
     L.capb = p; p += 64; L.capslack = p; p += 64; L.nu = p; p += 64;
     L.memb = reinterpret_cast<unsigned long long *>(p); p += N;
     int *q = reinterpret_cast<int *>(p);
-    L.kk = q; q += S; L.fi = q; q += S; L.act = q; q += 2 * MASTER_PACT; L.istate = q; q += 32;      // act: current list, then the iteration's list (act0)
+    L.kk = q; q += S; L.fi = q; q += S; L.act = q; q += 2 * MASTER_PACT; L.istate = q; q += 48;      // act: current list, then the iteration's list (act0)
     L.capmodel = q; q += 64; L.actc = q; q += 2 * MASTER_MCAP;                                       // actc: current caps of the step, then the iteration's (actc0)
     q += S;     // spare
     L.pos = reinterpret_cast<signed char *>(q);
@@ -90,9 +90,14 @@ __device__ inline void master_carve(MasterLds &L, unsigned char *base, int N, in
 enum { SC_F = 0, SC_LAMEST, SC_DAMP, SC_TAU, SC_LAM, SC_PRED, SC_KKT, SC_SPREAD, SC_QMAX, SC_FT, SC_LAMX };
 // istate[] slots
 enum { IS_NACT = 0, IS_NF, IS_OK, IS_DONE, IS_ACCEPT, IS_IT, IS_EVALS, IS_SOLVES, IS_STATUS, IS_NACT0, IS_TINY, IS_NALIVE, IS_ALIVE /* .. +PACT */,
-       IS_NCACT0 = IS_ALIVE + MASTER_PACT, IS_NCALIVE, IS_CALIVE /* .. +MCAP */, IS_CLOCK = IS_CALIVE + MASTER_MCAP /* .. +MCAP */ };
-// scal[] blocks: 16.. q of the act0 outputs, 20.. q at the trial point, 24.. new multipliers (act0 order), 28.. new cap multipliers
-// (actc0 order), 64.. K = E^T M^-1 E (MASTER_NE x MASTER_NE)
+       IS_NCACT0 = IS_ALIVE + MASTER_PACT, IS_NCALIVE, IS_CALIVE /* .. +MCAP */, IS_CLOCK = IS_CALIVE + MASTER_MCAP /* .. +MCAP */,
+       IS_OLOCK = IS_CLOCK + MASTER_MCAP /* .. +PACT */, IS_COUNT = IS_OLOCK + MASTER_PACT };
+// scal[] blocks: SQ.. q of the act0 outputs, SQT.. q at the trial point, SMU.. new multipliers (act0 order), SNU.. new cap
+// multipliers (actc0 order), SCK.. K = E^T M^-1 E (MASTER_NE x MASTER_NE)
+#define SQ 16
+#define SQT 24
+#define SMU 32
+#define SNU 40
 #define SCK 64
 
 // coefficient of support entry j in cap c: (1 - eps) cc_j if the capped model is in group j
@@ -316,6 +321,7 @@ __device__ void master_factor_wave(const MasterArgs &A, MasterLds &L, int lane)
         L.istate[IS_OK] = 1;
         for (int e = 0; e < MASTER_PACT; e++) L.istate[IS_ALIVE + e] = e < nact;
         for (int e = 0; e < MASTER_MCAP; e++) { L.istate[IS_CALIVE + e] = e < ncact; L.istate[IS_CLOCK + e] = 0; }
+        for (int e = 0; e < MASTER_PACT; e++) L.istate[IS_OLOCK + e] = 0;
     }
     wave_lds_sync();
 }
@@ -332,15 +338,15 @@ __device__ void master_small_solve(const MasterArgs &A, MasterLds &L, int lane, 
     constexpr int NU = MASTER_PACT + MASTER_MCAP + 2, W = NU + 1;
     __shared__ double Am[NU * W];
     __shared__ double zf[MASTER_PACT], nuf[MASTER_MCAP], zlt[2];      // multipliers (act0 / actc0 order), lam, tau
-    __shared__ int alive[MASTER_PACT], calive[MASTER_MCAP], clock[MASTER_MCAP], map[NU], okflag, redo;
+    __shared__ int alive[MASTER_PACT], olock[MASTER_PACT], calive[MASTER_MCAP], clock[MASTER_MCAP], map[NU], okflag, redo;
     const int S = A.S, LDM = L.LDM;
     const int nf = L.istate[IS_NF], nact = L.istate[IS_NACT], ncact = L.istate[IS_NCACT0];
     if (lane == 0) {
-        for (int e = 0; e < MASTER_PACT; e++) alive[e] = L.istate[IS_ALIVE + e];
+        for (int e = 0; e < MASTER_PACT; e++) { alive[e] = L.istate[IS_ALIVE + e]; olock[e] = L.istate[IS_OLOCK + e]; }
         for (int e = 0; e < MASTER_MCAP; e++) { calive[e] = L.istate[IS_CALIVE + e]; clock[e] = L.istate[IS_CLOCK + e]; }
     }
     wave_lds_sync();
-    for (int round = 0; round < 4 * (MASTER_PACT + MASTER_MCAP) + 4; round++) {
+    for (int round = 0; round < 6 * (MASTER_PACT + MASTER_MCAP) + 6; round++) {
         if (lane == 0) {
             int p = 0, pc = 0;
             for (int e = 0; e < nact; e++) if (alive[e]) map[p++] = e;
@@ -350,7 +356,7 @@ __device__ void master_small_solve(const MasterArgs &A, MasterLds &L, int lane, 
             for (int a = 0; a < n; a++) for (int b = 0; b <= n; b++) Am[a * W + b] = 0.0;
             for (int a = 0; a < nk; a++)
                 for (int b = 0; b < nk; b++) Am[a * W + b] = L.scal[SCK + map[a] * MASTER_NE + map[b]];
-            for (int a = 0; a < p; a++) { Am[a * W + nk] = 1.0; Am[nk * W + a] = 1.0; Am[a * W + n] = L.scal[(soc ? 20 : 16) + map[a]]; }
+            for (int a = 0; a < p; a++) { Am[a * W + nk] = 1.0; Am[nk * W + a] = 1.0; Am[a * W + n] = L.scal[(soc ? SQT : SQ) + map[a]]; }
             for (int a = 0; a < pc; a++) Am[(p + a) * W + n] = soc ? 0.0 : -L.capslack[L.actc[MASTER_MCAP + map[p + a] - nact]];
             Am[nk * W + n] = soc ? 0.0 : 1.0;
             bool sing = false;                                               // Gaussian elimination with partial pivoting
@@ -371,7 +377,7 @@ __device__ void master_small_solve(const MasterArgs &A, MasterLds &L, int lane, 
             if (!sing) {
                 int worst = -1; double wv = -1.0e-12;
                 if (!soc && p > 1)
-                    for (int a = 0; a < p; a++) { const double za = Am[a * W + n] / Am[a * W + a]; if (za < wv) { wv = za; worst = a; } }
+                    for (int a = 0; a < p; a++) { const double za = Am[a * W + n] / Am[a * W + a]; if (za < wv && !olock[map[a]]) { wv = za; worst = a; } }
                 if (worst >= 0) { alive[map[worst]] = 0; redo = 1; }
                 else if (!soc) {                                             // most negative droppable cap multiplier
                     int wc = -1; double wcv = -1.0e-12;
@@ -418,6 +424,16 @@ __device__ void master_small_solve(const MasterArgs &A, MasterLds &L, int lane, 
                 part = wave_sum(part);
                 if (part > 1.0e-12 * fmax(fabs(bc), 1.0)) { if (lane == 0) { calive[e] = 1; clock[e] = 1; } back = 1; }
             }
+        // ... and a candidate output that was dropped must not rise above the level tau of the others to first order
+        if (!soc)
+            for (int e = 0; e < nact; e++) {
+                if (alive[e]) continue;                                      // uniform (LDS)
+                double part = 0.0;
+                for (int j = lane; j < S; j += 64) part = fma(L.GQ[j * MASTER_PACT + e], outvec[j], part);
+                part = wave_sum(part);
+                const double tau = zlt[1];
+                if (L.scal[SQ + e] + part > tau + 1.0e-10 * fabs(tau)) { if (lane == 0) { alive[e] = 1; olock[e] = 1; } back = 1; }
+            }
         wave_lds_sync();
         if (back) continue;
         break;
@@ -427,10 +443,10 @@ __device__ void master_small_solve(const MasterArgs &A, MasterLds &L, int lane, 
             L.scal[SC_LAM] = zlt[0]; L.scal[SC_TAU] = zlt[1];
             double tot = 0.0;
             for (int e = 0; e < nact; e++) tot += zf[e] > 0.0 ? zf[e] : 0.0;
-            for (int e = 0; e < nact; e++) L.scal[24 + e] = tot > 0.0 ? (zf[e] > 0.0 ? zf[e] : 0.0) / tot : 0.0;   // new multipliers, act order
-            for (int e = 0; e < MASTER_MCAP; e++) L.scal[28 + e] = (e < ncact && tot > 0.0 && nuf[e] > 0.0) ? nuf[e] / tot : 0.0;
+            for (int e = 0; e < nact; e++) L.scal[SMU + e] = tot > 0.0 ? (zf[e] > 0.0 ? zf[e] : 0.0) / tot : 0.0;   // new multipliers, act order
+            for (int e = 0; e < MASTER_MCAP; e++) L.scal[SNU + e] = (e < ncact && tot > 0.0 && nuf[e] > 0.0) ? nuf[e] / tot : 0.0;
             int na = 0;
-            for (int e = 0; e < MASTER_PACT; e++) { L.istate[IS_ALIVE + e] = alive[e]; na += (e < nact && alive[e]) ? 1 : 0; }
+            for (int e = 0; e < MASTER_PACT; e++) { L.istate[IS_ALIVE + e] = alive[e]; L.istate[IS_OLOCK + e] = olock[e]; na += (e < nact && alive[e]) ? 1 : 0; }
             for (int e = 0; e < MASTER_MCAP; e++) { L.istate[IS_CALIVE + e] = calive[e]; L.istate[IS_CLOCK + e] = clock[e]; }
             L.istate[IS_NALIVE] = na;
         }
@@ -502,7 +518,7 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
     for (int t = tid; t < S * KM; t += MASTER_THREADS) L.idx[t] = A.idx[t];
     for (int t = tid; t < S * N; t += MASTER_THREADS) L.pos[t] = -1;
     for (int o = tid; o < n_out; o += MASTER_THREADS) L.mu[o] = A.mu[o];
-    if (tid < 32) L.istate[tid] = 0;
+    if (tid < 48) L.istate[tid] = 0;
     for (int t = tid; t < 256; t += MASTER_THREADS) L.scal[t] = 0.0;
     if (tid < 64) { L.capmodel[tid] = tid < A.ncap ? A.cap_model[tid] : 0; L.capb[tid] = tid < A.ncap ? A.cap_b[tid] : 0.0; L.nu[tid] = 0.0; L.capslack[tid] = 0.0; }
     __syncthreads();
@@ -585,18 +601,16 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
         if (tid == 0) {
             const double F = L.scal[SC_F];
             int nact = 0;
-            // candidates: within act_tol of the maximum, or carrying a multiplier; keep the MASTER_PACT largest by (mu, r)
+            // candidates: within act_tol of the maximum, or carrying a multiplier; the MASTER_PACT largest r (ties: smaller index)
             for (int o = 0; o < n_out; o++) L.muh[o] = 0.0;
             for (int pick = 0; pick < MASTER_PACT; pick++) {
-                int best = -1; double bm = -1.0, br = -1.0;
+                int best = -1;
                 for (int o = 0; o < n_out; o++) {
                     bool taken = false;
                     for (int q = 0; q < nact; q++) if (L.act[q] == o) taken = true;
                     if (taken) continue;
-                    const bool cand = (L.r[o] >= F * (1.0 - A.act_tol)) || (L.mu[o] > 1.0e-12);
-                    if (!cand) continue;
-                    const double m_o = L.mu[o] > 0.0 ? L.mu[o] : 0.0;
-                    if (m_o > bm || (m_o == bm && L.r[o] > br)) { best = o; bm = m_o; br = L.r[o]; }
+                    if (!((L.r[o] >= F * (1.0 - A.act_tol)) || (L.mu[o] > 1.0e-12))) continue;
+                    if (best < 0 || L.r[o] > L.r[best]) best = o;
                 }
                 if (best < 0) break;
                 L.act[nact++] = best;
@@ -646,7 +660,7 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
             L.GQ[j * MASTER_PACT + a] = -(1.0 - A.eps_bg) * L.cc[j] * acc / A.s[o] / (ro * ro);
         }
         if (tid == 0) {
-            for (int a = 0; a < nact0; a++) L.scal[16 + a] = -1.0 / L.r[L.act[a + MASTER_PACT]];      // q of the act0 outputs
+            for (int a = 0; a < nact0; a++) L.scal[SQ + a] = -1.0 / L.r[L.act[a + MASTER_PACT]];      // q of the act0 outputs
             double qm = -INFINITY;
             for (int o = 0; o < n_out; o++) qm = fmax(qm, -1.0 / L.r[o]);
             L.scal[SC_QMAX] = qm;
@@ -705,9 +719,9 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
                     double part = 0.0;
                     for (int j = lane; j < S; j += 64) {
                         double g = 0.0;
-                        for (int a = 0; a < nact; a++) g = fma(L.scal[24 + a], L.GQ[j * MASTER_PACT + a], g);
+                        for (int a = 0; a < nact; a++) g = fma(L.scal[SMU + a], L.GQ[j * MASTER_PACT + a], g);
                         for (int e = 0; e < L.istate[IS_NCACT0]; e++)
-                            if (L.scal[28 + e] > 0.0) g = fma(L.scal[28 + e], cap_a(A, L, L.actc[MASTER_MCAP + e], j), g);
+                            if (L.scal[SNU + e] > 0.0) g = fma(L.scal[SNU + e], cap_a(A, L, L.actc[MASTER_MCAP + e], j), g);
                         L.xt[j] = g;                    // scratch
                         part = fma(g, L.x[j], part);
                     }
@@ -721,7 +735,7 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
                     if (lane == 0) {
                         double sp = 0.0;
                         const double F = L.scal[SC_F];
-                        for (int a = 0; a < nact; a++) if (L.scal[24 + a] > 0.0) sp = fmax(sp, (F - L.r[L.act[a + MASTER_PACT]]) / F);
+                        for (int a = 0; a < nact; a++) if (L.scal[SMU + a] > 0.0) sp = fmax(sp, (F - L.r[L.act[a + MASTER_PACT]]) / F);
                         L.scal[SC_KKT] = worst; L.scal[SC_SPREAD] = sp; L.scal[SC_LAMX] = lam_x;
                     }
                 }
@@ -772,7 +786,7 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
                         // the objective cannot resolve the remaining improvement (the KKT residual left sits in entries of negligible mass)
                         L.istate[IS_TINY] = fabs(actual) <= 1.0e-13 * F ? L.istate[IS_TINY] + 1 : 0;
                     } else if (pass == 0 && isfinite(Ft) && L.istate[IS_NALIVE] > 1) {
-                        for (int a = 0; a < L.istate[IS_NACT0]; a++) L.scal[20 + a] = -1.0 / L.rt[L.act[a + MASTER_PACT]];
+                        for (int a = 0; a < L.istate[IS_NACT0]; a++) L.scal[SQT + a] = -1.0 / L.rt[L.act[a + MASTER_PACT]];
                         L.istate[IS_OK] = 1;
                     } else {
                         L.scal[SC_DAMP] *= 10.0;
@@ -810,9 +824,9 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
         if (converged || L.istate[IS_ACCEPT]) {
             if (tid == 0) {
                 for (int o = 0; o < n_out; o++) L.mu[o] = 0.0;
-                for (int a = 0; a < L.istate[IS_NACT0]; a++) L.mu[L.act[a + MASTER_PACT]] = L.scal[24 + a];
+                for (int a = 0; a < L.istate[IS_NACT0]; a++) L.mu[L.act[a + MASTER_PACT]] = L.scal[SMU + a];
                 for (int c = 0; c < A.ncap; c++) L.nu[c] = 0.0;
-                for (int e = 0; e < L.istate[IS_NCACT0]; e++) L.nu[L.actc[MASTER_MCAP + e]] = L.scal[28 + e];
+                for (int e = 0; e < L.istate[IS_NCACT0]; e++) L.nu[L.actc[MASTER_MCAP + e]] = L.scal[SNU + e];
             }
         }
         if (converged) { if (tid == 0) L.istate[IS_DONE] = 1; __syncthreads(); break; }
@@ -1113,7 +1127,7 @@ static int master_launch(bluest_plan_t plan, int S, const int64_t *support_host,
     unsigned char *d = (unsigned char *)plan->d_master;
     MasterArgs A;
     A.N = N; A.n_out = n_out; A.S = S; A.KM = KM;
-    A.eps_bg = eps_bg; A.tol = tol; A.act_tol = 1.0e-6; A.floor_x = 1.0e-6; A.maxit = maxit;
+    A.eps_bg = eps_bg; A.tol = tol; A.act_tol = 1.0e-3; A.floor_x = 1.0e-6; A.maxit = maxit;
     A.fb = eps_bg > 0.0 ? 0.0 : 0.9;       // without the background V has kinks where a model drops out: stay inside the face
     A.invcov = (const double *const *)d;
     A.boff = (const int64_t *)(d + b_ptr);

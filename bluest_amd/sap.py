@@ -250,6 +250,11 @@ class SpgAllocator(object):
                     self.info["certificate"] = {"allocation": mc, "multipliers": cert["mu"], "background": cert["background"],
                                                 "lower_bound": cert["lower_bound"], "budget": B, "scales": s.copy()}
                 return m
+            ex = getattr(plan, "exchange", None)
+            if ex is not None and ex.timed_out():
+                # (collective: a time-out poisons the record with NaN on the ranks that saw it; every rank ends here because the
+                # non-finite iterate is detected on gathered data)
+                raise BLUESTError("sharded solve: the peer-write exchange of the Phi records timed out (a rank is missing or stalled)")
             if self.verbose:
                 print("second-order finish unavailable (%s); first-order SPG only" % ninfo)
 

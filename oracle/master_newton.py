@@ -89,7 +89,7 @@ class SupportProblem(object):
         return (r, G, Hs, vs) if want_derivatives else r
 
 
-def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floor=1.0e-6, verbose=False, fb=None, caps=None, nu0=None):
+def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-3, floor=1.0e-6, verbose=False, fb=None, caps=None, nu0=None):
     """active-set Newton (SQP) on the support with Levenberg-Marquardt damping.  Works on rho_o = -1 / r_o (convex as well:
     1 / V_o is the Schur complement of Phi_o, concave and homogeneous of degree +1 in x; same minimisers; Newton does not crawl
     on it far from the optimum the way it does on the degree -1 function r_o, where a step is x -> 1.5 x).
@@ -106,7 +106,7 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floo
     bcap = np.zeros(0) if caps is None else np.asarray(caps[1], dtype=np.float64)
     ncap = len(bcap)
     nu = np.zeros(ncap) if nu0 is None else np.maximum(np.asarray(nu0, dtype=np.float64), 0.0)
-    MCAP = 4
+    MCAP, PACT = 4, 6
     if fb is None:
         fb = 0.0 if prob.eps_bg > 0.0 else 0.9     # without the background V has kinks where a model drops out: stay inside the face
     x = np.maximum(np.asarray(x0, dtype=np.float64), 0.0)
@@ -122,7 +122,11 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floo
     tiny_steps = 0
     for it in range(maxit):
         F = r.max()
-        act0 = np.flatnonzero((r >= F * (1.0 - act_tol)) | (mu > 1.0e-12))
+        # candidate outputs of the step: within act_tol of the maximum or carrying a multiplier, at most PACT (largest first).  They
+        # enter the step as equality rows; one whose multiplier comes out negative leaves, and comes back (locked) if the step it
+        # was dropped from would lift it above the others to first order -- an active-set solve of the step's QP over the candidates
+        cand = np.flatnonzero((r >= F * (1.0 - act_tol)) | (mu > 1.0e-12))
+        act0 = np.sort(cand[np.argsort(-r[cand], kind="stable")[:PACT]])
         mu_h = np.zeros(n_out)
         mu_h[act0] = np.maximum(mu[act0], 0.0)
         mu_h = mu_h / mu_h.sum() if mu_h.sum() > 0 else np.where(np.isin(np.arange(n_out), act0), 1.0 / len(act0), 0.0)
@@ -150,6 +154,7 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floo
             act = act0.copy()
             actc = actc0.copy()
             locked = set()                                         # caps that came back: dropping them made the step violate them
+            olocked = set()                                        # outputs that came back
             while True:                                            # drop outputs / caps whose multiplier comes out negative
                 M = H[np.ix_(fi, fi)] + damp * abs(lam_est) * np.diag(D[fi])
                 try:
@@ -173,8 +178,9 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floo
                 except np.linalg.LinAlgError:
                     z = np.linalg.lstsq(KK, rhs, rcond=None)[0]
                 mu_new, nu_new, lam, tau = z[:p], z[p:p + pc], z[p + pc], z[ne]
-                if p > 1 and mu_new.min() < -1.0e-12:
-                    act = np.delete(act, int(np.argmin(mu_new)))
+                odrop = [j for j in range(p) if mu_new[j] < -1.0e-12 and int(act[j]) not in olocked]
+                if p > 1 and odrop:
+                    act = np.delete(act, min(odrop, key=lambda j: mu_new[j]))
                     continue
                 droppable = [j for j in range(pc) if nu_new[j] < -1.0e-12 and int(actc[j]) not in locked]
                 if droppable:
@@ -188,6 +194,12 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-6, floo
                 if back:
                     locked.update(back)
                     actc = np.sort(np.concatenate([actc, np.asarray(back, dtype=actc.dtype)]))
+                    continue
+                # a candidate output that was dropped must not rise above the level tau of the others to first order
+                oback = [int(o_) for o_ in act0 if o_ not in act and q[o_] + Gq[:, o_] @ d > tau + 1.0e-10 * abs(tau)]
+                if oback:
+                    olocked.update(oback)
+                    act = np.sort(np.concatenate([act, np.asarray(oback, dtype=act.dtype)]))
                     continue
                 break
             mu_full = np.zeros(n_out)

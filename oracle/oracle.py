@@ -429,6 +429,35 @@ def multiplier_certificate(saps, m, costs, mu, s=None, eps_in=1.0e-3):
     return (F - lb) / F, F, lb
 
 
+def multiplier_certificate_ragged(saps, maps, m, costs, mu, s=None, eps_in=1.0e-3):
+    """multiplier_certificate for outputs with their OWN group lists (bluest/mosap.py:54-67): saps[o] is built on output o's groups,
+    maps[o][j] is the position of its j-th group in the global list that m and costs refer to.  Same bound: a group that output o
+    does not use contributes nothing to c_i for that output.  Returns (relative gap, F, LB)."""
+    O = len(saps)
+    m = np.asarray(m, dtype=np.float64)
+    w = np.asarray(costs, dtype=np.float64)
+    s = np.ones(O) if s is None else np.asarray(s, dtype=np.float64)
+    mu = np.maximum(np.asarray(mu, dtype=np.float64), 0.0)
+    mu = mu / mu.sum()
+    B = float(w @ m)
+    F = max(q.variance(m[mp]) / so for q, mp, so in zip(saps, maps, s))
+    mi = (1.0 - eps_in) * m + eps_in * (B / w / len(m))
+    a = mu / s
+    A, ci = 0.0, np.zeros(len(m))
+    for o, (q, mp) in enumerate(zip(saps, maps)):
+        if a[o] == 0.0:
+            continue
+        PHI = q.get_phi(mi[mp])
+        dsc = 1.0 / np.sqrt(np.diag(PHI))
+        y = dsc * np.linalg.solve(PHI * np.outer(dsc, dsc), dsc * np.eye(q.N, 1).ravel())
+        quad = np.concatenate([gradK(k, q.sizes[k], q.groups[k - 1], q.invcovs[k - 1], y[None, :])
+                               for k in range(1, q.K + 1) if q.sizes[k]])
+        A += 2.0 * a[o] * y[0]
+        ci[mp] += a[o] * quad / w[mp]
+    lb = A * A / (4.0 * B * float(ci.max()))
+    return (F - lb) / F, F, lb
+
+
 def optimality_certificate(saps, m, costs, s=None, tol=1.0e-7, max_rounds=60, verbose=False, max_seconds=None):
     """Duality certificate for  min_m F(m) = max_o V_o(m)/s_o  s.t.  costs.m = B, m >= 0  (the problem bluest/sap.py:387-418
     and bluest/mosap.py:578-605 hand to scipy) at a candidate allocation m, B = costs.m.  saps: one SparseOracleSAP per

@@ -415,6 +415,36 @@ def test_ns_paper_eps_mode_end_to_end_is_certified(oracle):
     assert gap <= 1e-6, (gap, p.MOSAP.solver_info)
 
 
+def test_ns_paper_ragged_outputs_end_to_end_is_certified(oracle):
+    """real covariances with a DIFFERENT group set per output (the `ragged` case of the Navier-Stokes fixture: the union / mapping
+    logic of bluest/blue_models.py:491-501 and bluest/mosap.py:54-67): MOSAP.solve in eps mode goes through the second-order
+    finish with non-identity mappings (absent blocks in the master, inverse maps in the multiplicative update and the pricing);
+    every tolerance is met and the solver's certificate, re-evaluated with oracle arithmetic on each output's own groups, closes"""
+    from bluest_amd.mosap import MOSAP
+    from conftest import golden
+    from test_oracle import _ns_case
+    G = golden("ns_paper_known_answer.npz")
+    n_out, kmax = int(G["n_out"]), int(G["kmax"])
+    groups, maps, multi = _ns_case(G, "ragged")
+    Cs = [G["C%d" % o] for o in range(n_out)]
+    costs = synth.group_costs(groups, G["costs"])
+    mos = MOSAP(Cs, kmax, [kmax] * n_out, [g.tolist() for g in groups], [[g.tolist() for g in mg] for mg in multi], costs,
+                [synth.group_costs(mg, G["costs"]) for mg in multi], verbose=False)
+    eps = G["eps"]
+    m = mos.solve(eps=list(eps), solver="spg", continuous_relaxation=True)
+    assert m is not None and mos.solver_info.get("method") == "newton", mos.solver_info
+    ratios = np.array(mos.variances(m)) / eps ** 2
+    assert ratios.max() <= 1 + 1e-9 and abs(ratios.max() - 1) < 1e-9
+    cert = mos.solver_info["certificate"]
+    saps = [oracle.SparseOracleSAP(C, kmax, mg) for C, mg in zip(Cs, multi)]
+    _, _, lb = oracle.multiplier_certificate_ragged(saps, maps, cert["allocation"], costs, cert["multipliers"], s=cert["scales"], eps_in=cert["background"])
+    assert abs(lb / cert["lower_bound"] - 1) < 1e-6, (lb, cert["lower_bound"])
+    F_m = max(q.variance(m[mp]) / so for q, mp, so in zip(saps, maps, cert["scales"])) * float(costs @ m) / cert["budget"]
+    gap = 1.0 - lb / F_m
+    print("ragged NS, eps mode: oracle-evaluated gap %.3e (solver %.3e), cost %.6g, support %d" % (gap, mos.solver_info["certified_gap"], m @ costs, int((m > 0).sum())))
+    assert -1e-9 <= gap <= 1e-6, (gap, mos.solver_info)
+
+
 def test_plan_dropped_during_capture_does_not_invalidate_it():
     """a plan whose last reference disappears while a hipGraph is being captured (reference count, not only the cyclic
     collector) is parked by the library and released after the capture: the capture survives and replays correctly"""

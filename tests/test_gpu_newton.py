@@ -147,3 +147,49 @@ def test_capped_master_kernel_equals_numpy_restatement(gpu, oracle, n, kmax, n_o
     # only to ~1e-4; the column generation keeps iterating from there)
     tol = 1e-7 if (out[2] <= 1e-6 and ref["kkt"] <= 1e-6) else 2e-4
     assert abs(out[0] / ref["F"] - 1) < tol, (out[0], ref["F"], out[:10], ref["kkt"])
+
+
+def test_master_kernel_with_ragged_outputs(gpu, oracle):
+    """outputs with their own group subsets (non-identity mappings, bluest/mosap.py:54-67): a support group that an output does not
+    use has no block for it (boff = -1 in the kernel, None in the restatement); same optimum"""
+    from oracle.master_newton import SupportProblem, master_newton
+    from bluest_amd.plan import Plan
+    n, kmax, n_out, S, eps_bg = 9, 3, 3, 28, 1e-3
+    prob = synth.problem(n, kmax, n_out)
+    groups = prob["groups"]
+    L = prob["K_tot"]
+    sizes = [len(g) for g in groups]
+    rng = np.random.RandomState(11)
+    cum = np.cumsum([0] + sizes)
+    outs, keeps = [], []
+    for o in range(n_out):
+        keep_o = [np.ones(len(g), dtype=bool) if o == 0 else rng.rand(len(g)) < 0.6 for g in groups]
+        for kp in keep_o:
+            kp[0] = True
+        keeps.append(np.concatenate(keep_o))
+        outs.append({"K": kmax, "sizes": [int(kp.sum()) for kp in keep_o], "groups": [g[kp] for g, kp in zip(groups, keep_o)], "C": prob["C"][o],
+                     "mapping": None if o == 0 else np.flatnonzero(keeps[-1])})
+    plan = Plan(n, L, outs)
+    keep = np.sort(np.concatenate([[0], 1 + rng.choice(L - 1, S - 1, replace=False)]))
+    s = np.ones(n_out)
+    saps = [oracle.SparseOracleSAP(C, kmax, groups) for C in prob["C"]]            # blocks of every group; masked below
+    sp0 = saps[0]
+    flat = [g for gk in sp0.groups for g in gk]
+    cc = prob["budget"] / prob["costs"]
+
+    def block(o, i):
+        if not keeps[o][i]:
+            return None
+        k = int(np.searchsorted(sp0.cumsizes, i, side="right"))
+        return saps[o].invcovs[k - 1].reshape(-1, k, k)[i - sp0.cumsizes[k - 1]]
+    u = cc / L
+    phi_u = plan.phi(u).cpu().numpy()[0][:, :n * n].reshape(n_out, n, n)           # each output's own groups only
+    for o in range(n_out):                                                       # ... which the oracle reproduces with masked m
+        assert np.abs(phi_u[o] - saps[o].get_phi(np.where(keeps[o], u, 0.0))).max() < 1e-12 * np.abs(phi_u[o]).max()
+    sp = SupportProblem(n, [flat[i] for i in keep], [[block(o, i) for i in keep] for o in range(n_out)], cc[keep], s, eps_bg * phi_u, eps_bg)
+    x0 = rng.rand(S) + 0.1
+    x0 /= x0.sum()
+    ref = master_newton(sp, x0, tol=1e-10)
+    x, mu, out = _gpu_master(gpu, plan, keep, cc[keep], s, eps_bg * phi_u, eps_bg, x0, np.full(n_out, 1.0 / n_out))
+    print("ragged master: kernel F %.12e kkt %.1e it %d status %d | numpy F %.12e kkt %.1e it %d" % (out[0], out[2], out[4], out[7], ref["F"], ref["kkt"], ref["it"]))
+    assert int(out[7]) == 0 and abs(out[0] / ref["F"] - 1) < 1e-9 and np.abs(x - ref["x"]).max() < 1e-5

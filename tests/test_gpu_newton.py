@@ -193,3 +193,40 @@ def test_master_kernel_with_ragged_outputs(gpu, oracle):
     x, mu, out = _gpu_master(gpu, plan, keep, cc[keep], s, eps_bg * phi_u, eps_bg, x0, np.full(n_out, 1.0 / n_out))
     print("ragged master: kernel F %.12e kkt %.1e it %d status %d | numpy F %.12e kkt %.1e it %d" % (out[0], out[2], out[4], out[7], ref["F"], ref["kkt"], ref["it"]))
     assert int(out[7]) == 0 and abs(out[0] / ref["F"] - 1) < 1e-9 and np.abs(x - ref["x"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("n,kmax,n_out", [(2, 2, 1), (3, 1, 1), (3, 3, 2), (4, 2, 3), (5, 5, 1), (7, 1, 2)])
+def test_second_order_finish_on_tiny_problems(gpu, oracle, n, kmax, n_out):
+    """edge sizes of the column generation: fewer groups than the initial support, singletons only (k_max = 1: the optimum is a
+    closed form only for one output, but the certificate must close anyway), more outputs than models.  Budget and eps mode;
+    the result is compared with scipy's SLSQP on the ORACLE objective where the problem is small enough for it."""
+    from scipy.optimize import minimize
+    from bluest_amd.mosap import MOSAP
+    prob = synth.problem(n, kmax, n_out)
+    groups, w, B = prob["groups"], prob["costs"], prob["budget"]
+    mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in groups] for _ in range(n_out)], w, [w] * n_out,
+                verbose=False)
+    m = mos.solve(budget=B, solver="spg", continuous_relaxation=True)
+    info = dict(mos.solver_info)
+    assert m is not None and info.get("method") == "newton" and info["certified_gap"] <= 1e-6, info
+    assert (m >= 0).all() and abs(m @ w / B - 1) < 1e-9
+    refs = [oracle.OracleSAP(C, kmax, groups, w) for C in prob["C"]]
+    F = max(r.variance(m) for r in refs)
+    assert abs(max(mos.variances(m)) / F - 1) < 1e-10
+    scale = B / w
+    L = len(w)
+
+    def fun(z):                                            # epigraph form for SLSQP: variables (x, t)
+        return z[-1]
+    cons = [{"type": "eq", "fun": lambda z: z[:-1].sum() - 1.0}]
+    for r in refs:
+        cons.append({"type": "ineq", "fun": lambda z, r=r: z[-1] - r.variance(scale * np.maximum(z[:-1], 0.0) + 1e-300) / F})
+    z0 = np.concatenate([m / scale * 0.9 + 0.1 / L, [1.1]])
+    sol = minimize(fun, z0, method="SLSQP", bounds=[(1e-9, 1.0)] * L + [(0.0, 10.0)], constraints=cons, options={"ftol": 1e-14, "maxiter": 300})
+    if sol.status == 0:
+        assert sol.fun >= 1.0 - 1e-5, (sol.fun, info)       # SLSQP cannot do better than the certified optimum
+    # eps mode: every tolerance met, the binding one exactly
+    eps = np.array([np.sqrt(C[0, 0]) / 15.0 for C in prob["C"]])
+    m2 = mos.solve(eps=eps, solver="spg", continuous_relaxation=True)
+    ratios = np.array(mos.variances(m2)) / eps ** 2
+    assert m2 is not None and ratios.max() <= 1 + 1e-9 and abs(ratios.max() - 1) < 1e-9 and mos.solver_info["certified_gap"] <= 1e-6

@@ -28,6 +28,7 @@ struct SolveLds {
     double phi[NT * LDP];       // reversed symmetric Phi (no delta); rows / columns of the pads are zero
     double amax[NT];            // per model: max |m_i| over groups containing it
     double vout[NT];            // row 0 of pinv(Phi) for the fused gradient pass
+    double scratch[NT <= 32 && NT > 16 ? 16 * (NT - 15) : 1];   // back-substitution of the DPP elimination (GjMap::scratch_doubles)
     int status;
     __device__ __forceinline__ double &at(int a, int b) { return phi[(NT - 1 - a) * LDP + (NT - 1 - b)]; }
 };
@@ -141,6 +142,160 @@ __device__ __forceinline__ void gj_regs(double (&a)[NT], int lane, double diag0,
     bad |= (__ballot(flag && lane < NT) != 0ull || !isfinite(last_pivot)) ? 1 : 0;
 }
 
+// ---- the same elimination with DPP broadcasts (NT <= 32) ------------------------------------------------------------------
+// The Schur complement of a symmetric matrix stays symmetric, so the pivot row's entry a_jc is also entry j of row c: it sits
+// in register a[j] of the LANE that holds row c.  `v_fmac_f64_dpp ... row_newbcast:l` takes one operand from lane l of the
+// 16-lane DPP row: ONE instruction per column update instead of two v_readlane + FMA.  A DPP row has 16 lanes, so
+//   * positions E .. NT-1 (E = max(NT-16, 0)), the MAIN rows, are held by lanes 0 .. 15 (DPP row 0);
+//   * positions 0 .. E-1, the EXTRA rows, are pivoted first.  Lanes 16 .. 16+E-1 hold them, but only their leading E x E
+//     block A11 is ever used: the rest of an extra row is, by symmetry, column e of the main rows -- registers a[e] of
+//     lanes 0..15, which nobody touches after step e.  Step j < E therefore updates the main rows with DPP for the columns
+//     c >= E (source a[j] of lane c-E) and with a v_readlane broadcast of the A11 entry for the few columns j < c < E; the
+//     extra rows below j take the same v_readlane update (forward elimination only, a pivoted extra row stays frozen);
+//   * steps E .. NT-1 are Gauss-Jordan on the main rows with DPP only (row_mask 1: DPP row 0 is written);
+//   * the extra unknowns follow by back-substitution: r_e = sum_l a_l[e] x_l over the main rows through a small LDS
+//     scratch, then x_e = -(r_e + sum_{e<c<E} u_ec x_c) / p_e down the extra rows with DPP broadcasts inside DPP row 1.
+// Hazards (inline assembly is opaque to the compiler's hazard recogniser): a DPP operand must have been written >= 2 wait
+// states earlier -- a[j] is written by the first column update of step j-1 and read again only after the reciprocal chain
+// of step j; the broadcasts that read a just-written register carry their own s_nop; EXEC does not change inside the
+// straight-line code (selects only) and the DPP phases start with s_nop 4.
+template <int NT> struct GjMap {
+    static constexpr bool dpp = NT <= 32;
+    static constexpr int E = (dpp && NT > 16) ? NT - 16 : 0;
+    static constexpr int lane_of(int pos) { return !dpp ? pos : (pos < E ? 16 + pos : pos - E); }
+    static constexpr int n_lanes = dpp ? (E > 0 ? 16 + E : NT) : NT;      // lanes [0, n_lanes) hold a position
+    static constexpr int scratch_doubles = E > 0 ? 16 * (E + 1) : 1;      // LDS scratch of the back-substitution
+    // position held by a lane; lanes without one shadow the last position (results unused)
+    static __device__ __forceinline__ int pos_of(int lane)
+    {
+        if (!dpp) return lane < NT ? lane : NT - 1;
+        const int p = lane < 16 ? lane + E : lane - 16;
+        return (lane < n_lanes && p < NT) ? p : NT - 1;
+    }
+};
+
+template <int L>
+__device__ __forceinline__ void fmac_row0_bcast(double &acc, double src, double mul)
+{   // lanes 0..15: acc += (src of lane L) * mul; the other lanes keep acc
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0x1 bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(L));
+}
+template <int L>
+__device__ __forceinline__ void fmac_row1_bcast_nop(double &acc, double src, double mul)
+{   // lanes 16..31: acc += (src of lane 16+L) * mul; src may have been written by the previous instruction
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0x2 bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(L));
+}
+template <int L>
+__device__ __forceinline__ double mov_bcast(double src)
+{   // every lane: src of lane L of its own 16-lane row
+    double out;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(src), "n"(L));
+    return out;
+}
+
+template <int NT, int J, int C>
+struct GjDppCols {     // main rows: column updates C .. NT-1 (C >= E) of step J
+    static __device__ __forceinline__ void run(double (&a)[NT], double f)
+    {
+        if constexpr (C < NT) {
+            fmac_row0_bcast<C - GjMap<NT>::E>(a[C], a[J], f);
+            GjDppCols<NT, J, C + 1>::run(a, f);
+        }
+    }
+};
+template <int NT, int J>
+struct GjDppStep {     // steps J .. NT-1 (positions held by lanes 0..15)
+    static __device__ __forceinline__ void run(double (&a)[NT], int lane, double &rinv_mine, double &last_pivot)
+    {
+        constexpr int LJ = J - GjMap<NT>::E;
+        const double piv = mov_bcast<LJ>(a[J]);
+        const bool is = lane == LJ;
+        const double rinv = rcp_f64(piv);
+        rinv_mine = is ? rinv : rinv_mine;
+        if constexpr (J == NT - 1) { last_pivot = piv; }
+        else {
+            const double f = is ? 0.0 : -a[J] * rinv;
+            GjDppCols<NT, J, J + 1>::run(a, f);
+            GjDppStep<NT, J + 1>::run(a, lane, rinv_mine, last_pivot);
+        }
+    }
+};
+template <int NT, int J>
+struct GjExtraStep {   // steps J .. E-1: pivots of the extra rows (lanes 16 ..)
+    static __device__ __forceinline__ void run(double (&a)[NT], int lane, double &rinv_mine)
+    {
+        constexpr int E = GjMap<NT>::E;
+        if constexpr (J < E) {
+            const double piv = readlane_f64(a[J], 16 + J);
+            const double rinv = rcp_f64(piv);
+            rinv_mine = (lane == 16 + J) ? rinv : rinv_mine;
+            const double f = (lane >= 16 && lane <= 16 + J) ? 0.0 : -a[J] * rinv;      // pivoted extra rows stay frozen
+            double u[E];
+#pragma unroll
+            for (int c = J + 1; c < E; c++) u[c] = readlane_f64(a[c], 16 + J);
+#pragma unroll
+            for (int c = J + 1; c < E; c++) a[c] = fma(f, u[c], a[c]);
+            GjDppCols<NT, J, E>::run(a, f);
+            GjExtraStep<NT, J + 1>::run(a, lane, rinv_mine);
+        }
+    }
+};
+template <int NT, int Ei>
+struct GjBackSub {     // extra unknowns Ei-1, Ei-2, .., 0 (lanes 16 ..): acc holds r_e plus the terms of the unknowns already known
+    static __device__ __forceinline__ void run(const double (&a)[NT], int lane, double rinv_mine, double &acc, double &xe)
+    {
+        if constexpr (Ei > 0) {
+            constexpr int e = Ei - 1;
+            xe = (lane == 16 + e) ? -acc * rinv_mine : xe;
+            if constexpr (e > 0) fmac_row1_bcast_nop<e>(acc, xe, a[e]);      // rows e' < e: acc += x_e * u_e'e
+            GjBackSub<NT, Ei - 1>::run(a, lane, rinv_mine, acc, xe);
+        }
+    }
+};
+
+// Elimination + solution: returns x = (A^-1 e_last) at the position this lane holds (GjMap); last_pivot = 1 / (A^-1)_last,last
+// (wave-uniform).  scratch: GjMap<NT>::scratch_doubles doubles of LDS private to this wavefront.  "Not positive definite" as in
+// gj_regs, judged from the reciprocals: a pivot p passes when 1/p is positive and (1/p) * floor < 1.
+template <int NT>
+__device__ __forceinline__ double gj_solve_last(double (&a)[NT], int lane, double diag0, double *scratch, double &last_pivot, int &bad)
+{
+    using M = GjMap<NT>;
+    double rinv_mine = 0.0;
+    if constexpr (!M::dpp) {
+        gj_regs<NT>(a, lane, diag0, rinv_mine, last_pivot, bad);
+        const double rl = readlane_f64(rinv_mine, NT - 1);
+        return (lane == NT - 1) ? rl : -a[NT - 1] * rinv_mine * rl;
+    } else {
+        constexpr int E = M::E;
+        asm volatile("s_nop 4" ::: "memory");
+        GjExtraStep<NT, 0>::run(a, lane, rinv_mine);
+        GjDppStep<NT, E>::run(a, lane, rinv_mine, last_pivot);
+        last_pivot = readlane_f64(last_pivot, 0);
+        const bool ok = rinv_mine > 0.0 && rinv_mine * (BLUEST_PIVOT_TOL * diag0) < 1.0;     // false for NaN as well
+        bad |= (__ballot(!ok && lane < M::n_lanes) != 0ull || !isfinite(last_pivot)) ? 1 : 0;
+        const double rl = readlane_f64(rinv_mine, M::lane_of(NT - 1));
+        double x = (lane == M::lane_of(NT - 1)) ? rl : -a[NT - 1] * rinv_mine * rl;
+        if constexpr (E > 0) {
+            // r_e = sum over the main rows l of a_l[e] x_l: lane l leaves (a_l[0..E), x_l) in the scratch, lane 16+e sums column e
+            if (lane < 16) {
+#pragma unroll
+                for (int e = 0; e < E; e++) scratch[lane * (E + 1) + e] = a[e];
+                scratch[lane * (E + 1) + E] = x;
+            }
+            wave_lds_sync();
+            const int e_mine = (lane >= 16 && lane < 16 + E) ? lane - 16 : 0;
+            double acc = 0.0;
+#pragma unroll
+            for (int l = 0; l < 16; l++) acc = fma(scratch[l * (E + 1) + e_mine], scratch[l * (E + 1) + E], acc);
+            wave_lds_sync();
+            double xe = 0.0;
+            asm volatile("s_nop 4" ::: "memory");
+            GjBackSub<NT, E>::run(a, lane, rinv_mine, acc, xe);
+            x = (lane >= 16) ? xe : x;
+        }
+        return x;
+    }
+}
+
 // One (candidate, output): masks -> identity-padded restricted matrix in registers (static order) -> Gauss-Jordan -> V (-> v).
 // Called by ONE wavefront (lane = 0..63); lds.phi is ready.  s1 / s2 (lane = model): model touched by a group with
 // |m| > 1e-6 (misc.py:453-457, the rows of V's restricted system) / by a group with m != 0 (support of Phi, for v).
@@ -160,7 +315,7 @@ __device__ __forceinline__ void solve_wave(SolveLds<NT> &lds, int N, double delt
     double vmine = 0.0;                     // value of v for the model this lane's POSITION holds
     unsigned long long vmask = 0ull;        // models for which vmine is meaningful
     int vswap = 0;
-    const int p = lane < NT ? lane : NT - 1;          // lanes beyond NT shadow the last row (results unused)
+    const int p = GjMap<NT>::pos_of(lane);            // position of the elimination this lane holds (lanes without one shadow the last)
     if (__builtin_expect(!big, 0)) {
         status = BLUEST_EVAL_INF;
         V = INFINITY;
@@ -210,10 +365,10 @@ __device__ __forceinline__ void solve_wave(SolveLds<NT> &lds, int N, double delt
                 a[c] = (c == p) ? a[c] + diag : a[c];
                 diag0 = (c == p) ? a[c] : diag0;
             }
-            double last_pivot = 1.0, rinv_mine = 0.0;
+            double last_pivot = 1.0;
             int bad = 0;
             PHASE(5);
-            gj_regs<NT>(a, lane, diag0, rinv_mine, last_pivot, bad);
+            const double x = gj_solve_last<NT>(a, lane, diag0, lds.scratch, last_pivot, bad);      // x = A^-1 e_last at position p
             PHASE(6);
             if (__builtin_expect(uniform_i(bad) != 0, 0)) {
                 if (status == BLUEST_EVAL_OK) status = BLUEST_EVAL_SINGULAR;
@@ -223,8 +378,6 @@ __device__ __forceinline__ void solve_wave(SolveLds<NT> &lds, int N, double delt
             }
             if (pass == 0) V = 1.0 / last_pivot;     // = (A^-1)_{target,target}
             if (want_v && pass == npass - 1) {
-                const double rl = readlane_f64(rinv_mine, NT - 1);
-                const double x = (lane == NT - 1) ? rl : -a[NT - 1] * rinv_mine * rl;   // x = A^-1 e_last at position `lane`
                 // row 0 of pinv(Phi) is zero when model 0 is not in the support; otherwise x on the support, 0 elsewhere
                 const bool have = (mask2 & 1ull) != 0ull || delta != 0.0;
                 vmine = (have && mine) ? x : 0.0;
@@ -237,7 +390,7 @@ __device__ __forceinline__ void solve_wave(SolveLds<NT> &lds, int N, double delt
     if (want_v) {   // position p holds model NT-1-p (0 <-> vswap exchanged)
         int mp = NT - 1 - p;
         if (vswap != 0) mp = (mp == 0) ? vswap : (mp == vswap ? 0 : mp);
-        if (lane < NT && mp < N) v_out[mp] = vmask ? vmine : 0.0;
+        if (lane < GjMap<NT>::n_lanes && mp < N) v_out[mp] = vmask ? vmine : 0.0;
         wave_lds_sync();
     }
     if (lane == 0) { *var_out = V; *status_out = status; }

@@ -40,7 +40,7 @@ __device__ __forceinline__ double fmac_bcast(double acc, double src, double mul)
     return acc;
 }
 template <int J>
-__device__ __forceinline__ double mov_bcast(double src)
+__device__ __forceinline__ double hb_mov_bcast(double src)
 {
     double out;
     asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(src), "n"(J));
@@ -56,7 +56,7 @@ struct GjDpp {
         else {
             const double f = ((lane & 15) == J) ? 0.0 : -a[J] * rinv;
             a[J + 1] = fmac_bcast<J>(a[J + 1], a[J + 1], f);
-            const double pivn = mov_bcast<J + 1>(a[J + 1]);
+            const double pivn = hb_mov_bcast<J + 1>(a[J + 1]);
             const double rinvn = rcp_f64(pivn);
 #pragma unroll
             for (int c = J + 2; c < NT; c++) a[c] = fmac_bcast<J>(a[c], a[c], f);
@@ -67,7 +67,7 @@ struct GjDpp {
 template <int NT>
 __device__ __forceinline__ void gj_dpp(double (&a)[NT], int lane, double &rinv_mine, double &last_pivot, int &bad)
 {
-    const double piv = mov_bcast<0>(a[0]);
+    const double piv = hb_mov_bcast<0>(a[0]);
     GjDpp<NT, 0>::run(a, lane, piv, rcp_f64(piv), rinv_mine, last_pivot, bad);
 }
 
@@ -150,7 +150,7 @@ template <int NT, int J>
 struct GjDppLean {
     static __device__ __forceinline__ void run(double (&a)[NT], int lane16, int &signs, double &rinv_mine, double &last_pivot)
     {
-        const double piv = mov_bcast<J>(a[J]);           // (s_nop 1 inside: a[J] may have been written two instructions ago)
+        const double piv = hb_mov_bcast<J>(a[J]);           // (s_nop 1 inside: a[J] may have been written two instructions ago)
         signs |= __builtin_amdgcn_readfirstlane(__double2hiint(piv));
         const double rinv = rcp_halley(piv);
         const bool is = lane16 == J;
@@ -177,6 +177,7 @@ __global__ __launch_bounds__(64) void k_bench(const double *__restrict__ A, int 
 {
     const int lane = threadIdx.x;
     __shared__ double sA[NT * NT];
+    __shared__ double sScratch[16 * 17];
     for (int t = lane; t < NT * NT; t += 64) sA[t] = A[t];
     __syncthreads();
     double acc = 0.0;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(64) void k_bench(const double *__restrict__ A, int 
         if (rep < 4 && lane == 0) cycles[2 + rep] = __builtin_amdgcn_s_memtime();
         if (rep == 1) { t0 = __builtin_amdgcn_s_memtime(); r0 = wall_clock64(); }
         double a[NT];
-        const int row = (VAR == 2 || VAR == 5) ? (lane & 15) : lane;
+        const int row = (VAR == 2 || VAR == 5) ? (lane & 15) : (VAR == 6 ? GjMap<NT>::pos_of(lane) : lane);
 #pragma unroll
         for (int c = 0; c < NT; c++) a[c] = (row < NT) ? sA[row * NT + c] + acc * 1e-300 : ((c == row) ? 1.0 : 0.0);
         double rinv_mine = 0.0, last = 1.0;
@@ -196,7 +197,8 @@ __global__ __launch_bounds__(64) void k_bench(const double *__restrict__ A, int 
         else if (VAR == 4) gj_lean<NT>(a, lane, rinv_mine, last, bad);
         else if (VAR == 5) { if constexpr (NT <= 16) gj_dpp_lean<NT>(a, lane, rinv_mine, last, bad); }
         double x;
-        if (VAR == 3) { double V; x = gj_block2<NT>(a, lane, V, bad); }
+        if (VAR == 6) x = gj_solve_last<NT>(a, lane, (row < NT) ? sA[row * NT + row] : 1.0, sScratch, last, bad);
+        else if (VAR == 3) { double V; x = gj_block2<NT>(a, lane, V, bad); }
         else {
             const double rl = (VAR == 2 || VAR == 5) ? __shfl(rinv_mine, NT - 1, 64) : readlane_f64(rinv_mine, NT - 1);
             x = (row == NT - 1) ? rl : -a[NT - 1] * rinv_mine * rl;
@@ -204,6 +206,14 @@ __global__ __launch_bounds__(64) void k_bench(const double *__restrict__ A, int 
         acc += x + bad;
     }
     t1 = __builtin_amdgcn_s_memtime(); r1 = wall_clock64();
+    if (VAR == 6) {      // back to "lane = position" for the check on the host
+        __shared__ double xs[64];
+        xs[lane] = 0.0;
+        __syncthreads();
+        if (lane < GjMap<NT>::n_lanes) xs[GjMap<NT>::pos_of(lane)] = acc;
+        __syncthreads();
+        acc = xs[lane];
+    }
     out[lane] = acc;
     if (lane == 0) { cycles[0] = t1 - t0; cycles[1] = r1 - r0; }
 }
@@ -282,7 +292,14 @@ int main()
     run_wave<26>(25, 2000);
     run_wave<12>(12, 2000);
     const int reps = 2000;
-    run<20, 0>("readlane (product)", reps);
+    run<8, 6>("product: dpp, extras first", reps);
+    run<12, 6>("product: dpp, extras first", reps);
+    run<16, 6>("product: dpp, extras first", reps);
+    run<20, 6>("product: dpp, extras first", reps);
+    run<26, 6>("product: dpp, extras first", reps);
+    run<32, 6>("product: dpp, extras first", reps);
+    run<32, 0>("readlane (round 2)", reps);
+    run<20, 0>("readlane (round 2)", reps);
     run<20, 1>("readlane, pipelined rcp", reps);
     run<20, 4>("readlane, lean bookkeeping", reps);
     run<26, 4>("readlane, lean bookkeeping", reps);

@@ -20,11 +20,20 @@
 
 #include "common.hpp"
 
+#ifndef BLUEST_ABLATE      // experiment builds only (-DBLUEST_ABLATE=n, tools/ablate.sh): parts of the evaluation kernels switched off
+#define BLUEST_ABLATE 0    // for timing: 1 no fold, 2 no elimination, 3 no tile stream, 5 empty k_solve_grad, 6 empty Phi pass, 7 no gradient store,
+                           // 8 Phi pass stores its partials elsewhere, 9 Phi pass only stores
+#endif
 #ifdef BLUEST_PHASE_TIMING   // experiment builds only (tools/phase_timing.py): 100 MHz timestamps of one workgroup's phases
 __device__ long long g_phase[3][12];
 #define PHASE(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1)) \
         g_phase[blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 2 : 1)][i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int bluest_debug_phase_times(long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(long long) * 36) == hipSuccess ? 0 : 1; }
+// the same for the first TILE wavefront (thread 64) of the three sampled workgroups
+__device__ long long g_phase_tile[3][8];
+#define PHASE_TILE(i) do { if (threadIdx.x == 64 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1)) \
+        g_phase_tile[blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 2 : 1)][i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int bluest_debug_phase_times_tile(long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_tile), sizeof(long long) * 24) == hipSuccess ? 0 : 1; }
 // kernel spans in a chain of evaluations: [step % 16][kernel][begin, end] (min / max over a sample of workgroups)
 __device__ unsigned long long g_span[16][2][2];
 __device__ int g_step;
@@ -43,6 +52,7 @@ extern "C" int bluest_debug_span_reset(void)
 extern "C" int bluest_debug_span_read(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : 1; }
 #else
 #define PHASE(i)
+#define PHASE_TILE(i)
 #define SPAN_BEGIN(kid)
 #define SPAN_END(kid, bump)
 #endif
@@ -113,6 +123,7 @@ __global__ __launch_bounds__(256) void k_phi_chunks_shared(const double *__restr
     const int lane = threadIdx.x & 63;
     const int o0 = blockIdx.y * OB;
     if (chunk >= ncpo) return;
+    if (BLUEST_ABLATE == 6) return;
     SPAN_BEGIN(0);
     const int64_t CH = (int64_t)iters * 256;
     const int64_t base = chunk * CH + lane * 4;
@@ -122,7 +133,7 @@ __global__ __launch_bounds__(256) void k_phi_chunks_shared(const double *__restr
 #pragma unroll
         for (int oo = 0; oo < OB; oo++) s[oo] = 0.0;
         double amax = 0.0;
-        for (int it = 0; it < iters; it++) {
+        for (int it = 0; it < (BLUEST_ABLATE == 9 ? 0 : iters); it++) {
             const int4 cc = *reinterpret_cast<const int4 *>(cols + base + it * 256);
             double2 v01[OB], v23[OB];
 #pragma unroll
@@ -146,7 +157,9 @@ __global__ __launch_bounds__(256) void k_phi_chunks_shared(const double *__restr
 #pragma unroll
         for (int oo = 0; oo < OB; oo++) {
             const double t = wave_sum(s[oo]);
-            if (lane == 0 && o0 + oo < n_out) partial[(int64_t)c * n_chunks + (int64_t)(o0 + oo) * ncpo + chunk] = make_double2(t, amax);
+            // (experiment builds: ABLATE 8 stores into the slots of candidate 1 -- needs max_candidates >= 2 --, so the fused kernel
+            //  reads partials that were not just rewritten; ABLATE 9 skips the streams above and only stores)
+            if (lane == 0 && o0 + oo < n_out) partial[(int64_t)(c + (BLUEST_ABLATE == 8 ? 1 : 0)) * n_chunks + (int64_t)(o0 + oo) * ncpo + chunk] = make_double2(t, amax);
         }
     }
     SPAN_END(0, false);
@@ -355,8 +368,7 @@ __global__ __launch_bounds__(64) void k_pinv_from_record(int N, int n_out, const
 // KU covering the plan, so the common small-k plans keep a small register footprint)
 template <int KU>
 __global__ __launch_bounds__(256) void k_grad_tiles(const TileDesc *__restrict__ tiles, int64_t n_tiles,
-                                                    const double *__restrict__ tvals,
-                                                    const uint8_t *__restrict__ tidx, const double *__restrict__ v,
+                                                    const double *__restrict__ tvals, const double *__restrict__ v,
                                                     const int32_t *__restrict__ status, int N, int n_out, int n_cand,
                                                     double *__restrict__ grad, int64_t grad_stride,
                                                     const int32_t *__restrict__ gate)
@@ -366,10 +378,10 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const TileDesc *__restrict__
     const int lane = threadIdx.x & 63;
     if (t >= n_tiles) return;
     const TileDesc td = tiles[t];
-#define GT(KK) case KK: if (KK <= KU) { grad_tile<(KK <= KU ? KK : 1)>(td, tvals, tidx, v, status, N, n_out, n_cand, grad, grad_stride, lane); break; }
+#define GT(KK) case KK: if (KK <= KU) { grad_tile<(KK <= KU ? KK : 1)>(td, tvals, v, status, N, n_out, n_cand, grad, grad_stride, lane); break; }
     switch (td.k) {
         GT(1) GT(2) GT(3) GT(4) GT(5) GT(6) GT(7) GT(8) GT(9) GT(10) GT(11) GT(12)
-        default: grad_tile_generic(td, tvals, tidx, v, status, N, n_out, n_cand, grad, grad_stride, lane);
+        default: grad_tile_generic(td, tvals, v, status, N, n_out, n_cand, grad, grad_stride, lane);
     }
 #undef GT
 }
@@ -385,8 +397,8 @@ static int pick_ku(int kmax) { return kmax <= 5 ? 5 : kmax <= 6 ? 6 : kmax <= 8 
 template <int NT, int KU>
 __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
                                                     const double2 *__restrict__ partial, const double *__restrict__ rec, double delta,
-                                                    const TileDesc *__restrict__ tiles, int64_t n_tiles, int bpo,
-                                                    const double *__restrict__ tvals, const uint8_t *__restrict__ tidx,
+                                                    const TileDesc *__restrict__ tiles, int64_t n_tiles, int bpo, int tpb,
+                                                    const double *__restrict__ tvals,
                                                     double *__restrict__ var, double *__restrict__ v_ws,
                                                     int32_t *__restrict__ status, double *__restrict__ grad,
                                                     const int32_t *__restrict__ gate, double *__restrict__ spg_state, int last_slot,
@@ -394,7 +406,7 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
 {
     constexpr int FUSED_TPB = fused_tpb(NT, KU);
     constexpr int NTHREADS = 64 * (FUSED_TPB + 1);
-    constexpr int NE = KU * (KU + 1) / 2;
+    constexpr int PU = tile_pairs(KU);
     __shared__ SolveLds<NT> lds;
     __shared__ double spg_ls[SPG_STATE_DOUBLES];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -403,9 +415,11 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
         if (spg_state && blockIdx.x == 0 && wave == 0) spg_decide_wave(spg_state, var, status, n_out, last_slot, spg_enable, spg_ls, lane);
         return;
     }
+    if (BLUEST_ABLATE == 5) return;
     SPAN_BEGIN(1);
     PHASE(0);
-    const int64_t t0 = (int64_t)blockIdx.x * FUSED_TPB;
+    PHASE_TILE(0);
+    const int64_t t0 = (int64_t)blockIdx.x * tpb;      // tpb <= FUSED_TPB tiles per workgroup (wavefronts beyond it only fold)
     // which output, and am I its first workgroup: arithmetic when every output has the same number of workgroups (bpo > 0,
     // the usual case), else from the first tile's descriptor (one more dependent load in front of the fold)
     int o, first;
@@ -420,19 +434,21 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
     const double *rec_o = rec ? rec + (int64_t)o * (N * N + 2 * N + 1) : nullptr;
     if (rec_o) {
         for (int t = tid; t < N * N; t += NTHREADS) lds.at(t / N, t % N) = rec_o[t];
+    } else if (BLUEST_ABLATE == 1) {
+        for (int t = tid; t < N * N; t += NTHREADS) lds.at(t / N, t % N) = (t / N == t % N) ? 1.0 : 0.0;
+        if (tid < N) lds.amax[tid] = 1.0;
     } else {
         fold_rows<NT>(lds, N, rows, o * nsym, nsym, partial, tid, NTHREADS);
     }
     // the list is padded to a multiple of FUSED_TPB tiles per output, so every tile of this workgroup belongs to output o
     // (loaded by the tile wavefronts only: the solving wavefront must not wait for a descriptor it does not use)
     TileDesc td;
-    td.k = 1; td.n_valid = 0; td.val_off = td.idx_off = td.grad_off = 0; td.out = (int16_t)o;
-    if (wave > 0) td = tiles[t0 + wave - 1];
+    td.k = 1; td.n_valid = 0; td.val_off = td.grad_off = 0; td.out = (int16_t)o;
+    if (wave > 0 && wave <= tpb) td = tiles[t0 + wave - 1];
     __syncthreads();
     PHASE(2);
     const int k = td.k;
-    double s[NE];
-    int gi[KU];
+    double2 pr[PU];
     double V_pub = 0.0;      // wavefront 0: V and status of this workgroup's solve (for the single-output decision)
     int32_t st_pub = 0;
     if (wave == 0) {
@@ -451,7 +467,8 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
         double V = 0.0;
         int32_t st = 0;
         PHASE(8);
-        solve_wave<NT>(lds, N, delta, s1, s2, big, true, &V, lds.vout, &st, lane);
+        if (BLUEST_ABLATE == 2) { if (lane < N) lds.vout[lane] = 1.0; }
+        else solve_wave<NT>(lds, N, delta, s1, s2, big, true, &V, lds.vout, &st, lane);
         if (lane == 0) lds.status = st;
         V_pub = V; st_pub = st;
         if (first) {   // first workgroup of this output publishes V, status, v
@@ -459,17 +476,18 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
             if (lane < N) v_ws[(int64_t)o * N + lane] = lds.vout[lane];
         }
         PHASE(3);
-    } else if (k <= KU) {
+    } else if (k <= KU && BLUEST_ABLATE != 3) {
         // stream the tile into registers while wavefront 0 factorises (after the fold, so these loads do not queue in front of it)
-        const double *vals = tvals + td.val_off + lane;
-        const uint8_t *idx = tidx + td.idx_off + lane;
-        const int ne = k * (k + 1) / 2;
-#pragma unroll
-        for (int j = 0; j < KU; j++) if (j < k) gi[j] = idx[j * 64];
-#pragma unroll
-        for (int e = 0; e < NE; e++) if (e < ne) s[e] = vals[e * 64];
+        PHASE_TILE(1);
+        tile_load(pr, tvals + td.val_off + 2 * lane, tile_pairs(k));
+        PHASE_TILE(2);
+#ifdef BLUEST_PHASE_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PHASE_TILE(3);
+#endif
     }
     __syncthreads();
+    PHASE_TILE(4);
     if (wave == 0) {
         if (spg_state && first) {
             // SPG line search: the first workgroup of every output has published V and status above; they take a ticket and the
@@ -498,21 +516,27 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
         SPAN_END(1, true);
         return;
     }
-    const bool valid = lane < (td.n_valid & 0xffff);
+    if (BLUEST_ABLATE == 3) return;
+    const bool valid = lane < (td.n_valid & 0xffff) && (BLUEST_ABLATE != 7 || pr[0].x == 1.2345);
     const bool inf = lds.status == BLUEST_EVAL_INF;
     double *gout = grad + td.grad_off + lane;
-#define GT(KK) case KK: if (KK <= KU) { const double q = tile_form<(KK <= KU ? KK : 1)>(s, gi, lds.vout); if (valid) *gout = inf ? INFINITY : -q; break; }
+#define GT(KK) case KK: if (KK <= KU) { const double q = tile_form<(KK <= KU ? KK : 1)>(pr, lds.vout); if (valid) *gout = inf ? INFINITY : -q; break; }
     switch (k) {
         GT(1) GT(2) GT(3) GT(4) GT(5) GT(6) GT(7) GT(8) GT(9) GT(10) GT(11) GT(12)
         default: {
             // grad_tile reads v as v[(c*n_out + td.out)*N + model] and status[c*n_out + td.out]: point both at LDS
             const double *vl = lds.vout - (int64_t)td.out * N;
             const int32_t *sl = &lds.status - td.out;
-            grad_tile_generic(td, tvals, tidx, vl, sl, N, n_out, 1, grad, 0, lane);
+            grad_tile_generic(td, tvals, vl, sl, N, n_out, 1, grad, 0, lane);
         }
     }
 #undef GT
     PHASE(4);
+    PHASE_TILE(5);
+#ifdef BLUEST_PHASE_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE_TILE(6);
+#endif
     SPAN_END(1, false);
 }
 
@@ -895,24 +919,25 @@ __global__ __launch_bounds__(256) void k_fill_csr(const double *__restrict__ ic,
 }
 
 __global__ __launch_bounds__(256) void k_fill_tiles(const double *__restrict__ ic, const uint8_t *__restrict__ groups, int k, int64_t Lk,
-                                                    double *__restrict__ tvals, uint8_t *__restrict__ tidx)
-{
-    const int ne = k * (k + 1) / 2;
+                                                    double *__restrict__ tvals)
+{   // one thread per (group, entry or index byte); the tile layout is described at TileDesc (plan.hpp)
+    const int ne = tile_ne(k), ni = tile_ni(k), S = tile_slots(k);
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= Lk * (ne + k)) return;
     const int64_t gi = t / (ne + k);
     const int r = (int)(t - gi * (ne + k));
     const int64_t tile = gi >> 6;
     const int lane = (int)(gi & 63);
+    double *tb = tvals + tile * S * 64;
     if (r < ne) {
         int e = r, j = 0;
         while (e >= k - j) { e -= k - j; j++; }
         const int l = j + e;
         const double *b = ic + gi * k * k;
-        tvals[tile * ne * 64 + (int64_t)r * 64 + lane] = (j == l) ? b[j * k + j] : 0.5 * (b[j * k + l] + b[l * k + j]);
+        tb[tile_slot_off(ni + r, lane)] = (j == l) ? b[j * k + j] : 0.5 * (b[j * k + l] + b[l * k + j]);
     } else {
         const int j = r - ne;
-        tidx[tile * k * 64 + (int64_t)j * 64 + lane] = groups[gi * k + j];
+        reinterpret_cast<uint8_t *>(tb + tile_slot_off(j >> 3, lane))[j & 7] = groups[gi * k + j];
     }
 }
 
@@ -1093,33 +1118,50 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     {
         int kmax_all = 0;
         for (const auto &od : plan->outs) kmax_all = std::max(kmax_all, od.K);
-        plan->fused_tpb = fused_tpb(pick_nt(N), pick_ku(kmax_all));
+        // tiles per workgroup of the fused kernel.  What bounds its tile stream is the rate at which ONE compute unit pulls bytes
+        // that miss its L2 (~30 GB/s), so the tiles are spread over as many compute units as the device has (one workgroup of
+        // 1024 threads fills a compute unit's registers): 184 workgroups of 15 tiles left 72 of 256 units idle at the headline size
+        const int tpb_max = fused_tpb(pick_nt(N), pick_ku(kmax_all));
+        int64_t tiles_max = 1;
+        for (const auto &od : plan->outs) {
+            int64_t t = 0;
+            for (int k = 1; k <= od.K; k++) t += (od.sizes[k - 1] + 63) / 64;
+            tiles_max = std::max(tiles_max, t);
+        }
+        static std::atomic<int> cu_of[64];            // compute units per device (hipGetDeviceProperties costs about a millisecond)
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        int ncu = (dev >= 0 && dev < 64) ? cu_of[dev].load() : 0;
+        if (ncu <= 0) {
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, dev));
+            ncu = std::max(1, prop.multiProcessorCount);
+            if (dev >= 0 && dev < 64) cu_of[dev].store(ncu);
+        }
+        const int64_t wg_per_output = std::max<int64_t>(1, ncu / n_out);
+        plan->fused_tpb = (int)std::min<int64_t>(tpb_max, std::max<int64_t>(1, (tiles_max + wg_per_output - 1) / wg_per_output));
     }
     std::vector<TileDesc> tiles;
-    std::vector<std::vector<int64_t>> bucket_val(n_out), bucket_idx(n_out);    // first tile of size bucket k: offsets
-    size_t n_tvals = 0, n_tidx = 0;
+    std::vector<std::vector<int64_t>> bucket_val(n_out);    // first tile of size bucket k: offset
+    size_t n_tvals = 0;
     plan->grad_off.assign(n_out, 0);
     int64_t grad_len = 0;
     for (int o = 0; o < n_out; o++) {
         const OutputDesc &od = plan->outs[o];
         plan->grad_off[o] = grad_len;
         const size_t first_tile_of_output = tiles.size();
-        bucket_val[o].assign(od.K + 1, 0); bucket_idx[o].assign(od.K + 1, 0);
+        bucket_val[o].assign(od.K + 1, 0);
         int64_t li = 0;
         for (int k = 1; k <= od.K; k++) {
             const int64_t Lk = od.sizes[k - 1];
-            const int ne = k * (k + 1) / 2;
-            n_tidx = (n_tidx + 15) / 16 * 16;
-            bucket_val[o][k] = (int64_t)n_tvals; bucket_idx[o][k] = (int64_t)n_tidx;
+            bucket_val[o][k] = (int64_t)n_tvals;
             for (int64_t t0 = 0; t0 < Lk; t0 += 64) {
                 TileDesc td;
                 td.val_off = (int64_t)n_tvals;
-                td.idx_off = (int64_t)n_tidx;
                 td.grad_off = grad_len + li + t0;
                 td.n_valid = (int32_t)std::min<int64_t>(64, Lk - t0);
                 td.k = (int16_t)k; td.out = (int16_t)o;
-                n_tvals += (size_t)ne * 64;
-                n_tidx += (size_t)k * 64;
+                n_tvals += (size_t)tile_slots(k) * 64;
                 tiles.push_back(td);
             }
             li += Lk;
@@ -1129,7 +1171,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
         if (tiles.size() > first_tile_of_output) tiles[first_tile_of_output].n_valid |= (1 << 30);
         while ((tiles.size() - first_tile_of_output) % plan->fused_tpb || tiles.size() == first_tile_of_output) {
             TileDesc td;
-            td.val_off = 0; td.idx_off = 0; td.grad_off = 0; td.n_valid = (tiles.size() == first_tile_of_output) ? (1 << 30) : 0;
+            td.val_off = 0; td.grad_off = 0; td.n_valid = (tiles.size() == first_tile_of_output) ? (1 << 30) : 0;
             td.k = 1; td.out = (int16_t)o;
             tiles.push_back(td);
         }
@@ -1138,8 +1180,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
         else if (plan->fused_bpo != bpo) plan->fused_bpo = 0;
         grad_len += od.L_o;
     }
-    n_tvals = std::max<size_t>(n_tvals, 64);        // the empty padding tiles read (and ignore) one tile's worth at offset 0
-    n_tidx = std::max<size_t>(n_tidx, 64);
+    n_tvals = std::max<size_t>(n_tvals, 128);       // the empty padding tiles read (and ignore) one slot pair at offset 0
     plan->grad_len = grad_len;
 
     // ---- inverse maps for combine_grad ------------------------------------------------------------
@@ -1155,7 +1196,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     plan->n_tiles = (int64_t)tiles.size();
     plan->max_cand = max_candidates;
     plan->phi_bytes = n_chunks * CH * 8 + (plan->shared ? n_chunks / n_out : n_chunks) * CH * 4 + n_chunks * 16;
-    plan->grad_bytes = (int64_t)n_tvals * 8 + (int64_t)n_tidx + grad_len * 8;
+    plan->grad_bytes = (int64_t)n_tvals * 8 + grad_len * 8;
 
     timer.lap("tile descriptors + inverse maps");
     int rc;
@@ -1164,7 +1205,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     const size_t o_vals = arena.reserve((size_t)n_chunks * CH * sizeof(double)), o_cols = arena.reserve((size_t)n_chunks * CH * sizeof(int32_t));
     const size_t o_rows = arena.reserve(rows.size() * sizeof(RowDesc)), o_orb = arena.reserve(out_row_begin.size() * sizeof(int32_t));
     const size_t o_tiles = arena.reserve(tiles.size() * sizeof(TileDesc)), o_tvals = arena.reserve(n_tvals * sizeof(double));
-    const size_t o_tidx = arena.reserve(n_tidx), o_invmap = arena.reserve(invmap.size() * sizeof(int32_t));
+    const size_t o_invmap = arena.reserve(invmap.size() * sizeof(int32_t));
     const size_t o_goff = arena.reserve(plan->grad_off.size() * sizeof(int64_t));
     const size_t o_perm = arena.reserve(perm.size() * sizeof(int32_t));
     const size_t o_ocb = arena.reserve(out_chunk_begin.size() * sizeof(int64_t));
@@ -1177,12 +1218,10 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     plan->d_vals = reinterpret_cast<double *>(arena.base + o_vals);
     plan->d_cols = reinterpret_cast<int32_t *>(arena.base + o_cols);
     plan->d_tvals = reinterpret_cast<double *>(arena.base + o_tvals);
-    plan->d_tidx = reinterpret_cast<uint8_t *>(arena.base + o_tidx);
     int32_t *d_perm = nullptr;
     // clear what the scatter kernels do not write (padding slots, padding lanes); then the small tables
     HIP_TRY(hipMemsetAsync(plan->d_vals, 0, (size_t)n_chunks * CH * sizeof(double), 0));
     HIP_TRY(hipMemsetAsync(plan->d_tvals, 0, n_tvals * sizeof(double), 0));
-    HIP_TRY(hipMemsetAsync(plan->d_tidx, 0, n_tidx, 0));
     // columns: the structure's list sits at the structure's own chunk range (shared plans: output 0's range is the one the
     // Phi kernel reads; the other ranges stay unused)
     for (int o = 0; o < n_struct; o++)
@@ -1210,7 +1249,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
                 hipLaunchKernelGGL(k_fill_csr, dim3((unsigned)((Lk * ne + 255) / 256)), dim3(256), 0, 0, od.d_invcov + io, k, Lk,
                                    d_perm + struct_entries[st] + eo, plan->d_vals + out_chunk_begin[o] * CH);
                 hipLaunchKernelGGL(k_fill_tiles, dim3((unsigned)((Lk * (ne + k) + 255) / 256)), dim3(256), 0, 0, od.d_invcov + io,
-                                   od.d_groups + go, k, Lk, plan->d_tvals + bucket_val[o][k], plan->d_tidx + bucket_idx[o][k]);
+                                   od.d_groups + go, k, Lk, plan->d_tvals + bucket_val[o][k]);
             }
             io += Lk * k * k; go += Lk * k; eo += Lk * ne;
         }
@@ -1369,7 +1408,7 @@ static void launch_grad(bluest_plan_t plan, const double *v_dev, const int32_t *
     int kmax = 0;
     for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
 #define LG(KU) hipLaunchKernelGGL((k_grad_tiles<KU>), dim3((unsigned)((plan->n_tiles + 3) / 4)), dim3(256), 0, st, plan->d_tiles, plan->n_tiles, \
-                                  plan->d_tvals, plan->d_tidx, v_dev, status_dev, plan->N, n_out, n_cand, grad_dev, grad_stride, plan->gate)
+                                  plan->d_tvals, v_dev, status_dev, plan->N, n_out, n_cand, grad_dev, grad_stride, plan->gate)
     if (kmax <= 5) LG(5);
     else if (kmax <= 8) LG(8);
     else LG(12);
@@ -1487,7 +1526,7 @@ extern "C" int bluest_plan_solve_grad(bluest_plan_t plan, const double *rec_dev,
     for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
     const dim3 grid((unsigned)(plan->n_tiles / plan->fused_tpb));
 #define LSR2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, \
-                                        rec_dev, delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->d_tvals, plan->d_tidx, var_dev, plan->d_v, status_dev,  \
+                                        rec_dev, delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->fused_tpb, plan->d_tvals, var_dev, plan->d_v, status_dev,  \
                                         grad_dev, plan->gate, state_dev, last_slot, enable_dev, plan->d_ticket)
 #define LSR(NT) do { if (kmax <= 5) LSR2(NT, 5); else if (kmax <= 6) LSR2(NT, 6); else if (kmax <= 8) LSR2(NT, 8); else LSR2(NT, 12); } while (0)
     NT_DISPATCH(plan->N, LSR);
@@ -1531,7 +1570,7 @@ static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_
     if (grad_dev && n_cand == 1 && !g_debug_solve) {
         const dim3 grid((unsigned)(plan->n_tiles / plan->fused_tpb));
 #define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, nullptr, \
-                                        delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->d_tvals, plan->d_tidx, var_dev, plan->d_v, status, grad_dev, plan->gate, \
+                                        delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->fused_tpb, plan->d_tvals, var_dev, plan->d_v, status, grad_dev, plan->gate, \
                                         dec_state, dec_last, dec_enable, plan->d_ticket)
 #define LSG(NT) do { if (kmax <= 5) LSG2(NT, 5); else if (kmax <= 6) LSG2(NT, 6); else if (kmax <= 8) LSG2(NT, 8); else LSG2(NT, 12); } while (0)
         NT_DISPATCH(plan->N, LSG);

@@ -2,13 +2,23 @@
 #pragma once
 #include "solve.hpp"
 
-struct TileDesc {     // 64 groups of equal size k of one output, for the gradient pass
-    int64_t val_off;  // doubles: packed-symmetric entries, [k(k+1)/2][64]
-    int64_t idx_off;  // bytes:   model indices, [k][64]
+// Tile = 64 groups of equal size k of one output, lane = group.  Per group S(k) = ne + ni (+1 to make it even) 8-byte SLOTS:
+// slots [0, ni) hold the k model indices as bytes (ni = ceil(k/8)), slots [ni, ni+ne) the ne = k(k+1)/2 packed-symmetric
+// entries of the group's inverse.  Slots are stored in PAIRS, pair-major: pair p of lane l sits at doubles [p*128 + 2l, +2),
+// so one wave-instruction loads 16 bytes per lane, 1 KiB contiguous (the 8-byte-per-lane form of rounds 1-2 streamed at about
+// half the rate) and the indices come with the same loads (k = 5: 8 loads per tile instead of 15 + 5).
+struct TileDesc {
+    int64_t val_off;  // doubles: first slot pair of the tile
     int64_t grad_off; // position of the tile's first group inside the concatenated gradient
     int32_t n_valid;  // groups in this tile (<= 64); bit 30 set on the first tile of an output
     int16_t k, out;
 };
+__host__ __device__ constexpr int tile_ne(int k) { return k * (k + 1) / 2; }
+__host__ __device__ constexpr int tile_ni(int k) { return (k + 7) / 8; }
+__host__ __device__ constexpr int tile_slots(int k) { return (tile_ne(k) + tile_ni(k) + 1) & ~1; }
+__host__ __device__ constexpr int tile_pairs(int k) { return tile_slots(k) / 2; }
+// offset (doubles, relative to the tile) of slot sl of lane l
+__host__ __device__ constexpr int64_t tile_slot_off(int sl, int lane) { return (int64_t)(sl >> 1) * 128 + lane * 2 + (sl & 1); }
 
 
 struct OutputDesc {
@@ -50,8 +60,7 @@ struct bluest_plan_s {
     int64_t *d_out_chunk_begin = nullptr;   // n_out + 1: first chunk of every output (its partials are contiguous)
     int max_chunks_per_output = 0;
     TileDesc *d_tiles = nullptr;
-    double *d_tvals = nullptr;
-    uint8_t *d_tidx = nullptr;
+    double *d_tvals = nullptr;   // tiles: slot pairs (see TileDesc)
     int32_t *d_invmap = nullptr;
     int64_t *d_goff = nullptr;
     double2 *d_partial = nullptr;
@@ -81,83 +90,77 @@ struct DeviceScopeN {
 
 
 // ---- tile device code shared by plan.hip (gradient pass, fused kernel) and spg.hip (small-plan finish kernel) ----
-// gradient pass: one wavefront per tile, lane = group.  q = sum_j v_j (s_jj v_j + 2 sum_{l>j} s_jl v_l).
-template <int K>
-__device__ __forceinline__ void grad_tile(const TileDesc &td, const double *__restrict__ tvals,
-                                          const uint8_t *__restrict__ tidx, const double *__restrict__ v,
-                                          const int32_t *__restrict__ status, int N, int n_out, int n_cand,
-                                          double *__restrict__ grad, int64_t grad_stride, int lane)
-{
-    const double *vals = tvals + td.val_off + lane;
-    const uint8_t *idx = tidx + td.idx_off + lane;
-    int gi[K];
+// the slot pairs of one lane's group, PU pairs of registers (PU >= tile_pairs(K)); loaded with 16-byte loads
+template <int PU>
+__device__ __forceinline__ void tile_load(double2 (&pr)[PU], const double *__restrict__ tile_lane, int n_pairs)
+{   // tile_lane = tvals + td.val_off + 2 * lane
 #pragma unroll
-    for (int j = 0; j < K; j++) gi[j] = idx[j * 64];
-    double s[K * (K + 1) / 2];
-#pragma unroll
-    for (int e = 0; e < K * (K + 1) / 2; e++) s[e] = vals[e * 64];
-    for (int c = 0; c < n_cand; c++) {
-        const int64_t eo = (int64_t)c * n_out + td.out;
-        const double *vc = v + eo * N;
-        double vj[K];
-#pragma unroll
-        for (int j = 0; j < K; j++) vj[j] = vc[gi[j]];
-        double q = 0.0;
-        int e = 0;
-#pragma unroll
-        for (int j = 0; j < K; j++) {
-            double t = 0.0;
-#pragma unroll
-            for (int l = j + 1; l < K; l++) t = fma(s[e + (l - j)], vj[l], t);
-            t = fma(s[e], vj[j], 2.0 * t);
-            q = fma(vj[j], t, q);
-            e += K - j;
-        }
-        if (lane < (td.n_valid & 0xffff))
-            grad[(int64_t)c * grad_stride + td.grad_off + lane] = (status[eo] == BLUEST_EVAL_INF) ? INFINITY : -q;
-    }
+    for (int i = 0; i < PU; i++) if (i < n_pairs) pr[i] = *reinterpret_cast<const double2 *>(tile_lane + i * 128);
 }
+template <int PU>
+__device__ __forceinline__ double tile_slot(const double2 (&pr)[PU], int sl) { return (sl & 1) ? pr[sl >> 1].y : pr[sl >> 1].x; }   // sl static after unrolling
 
-// the quadratic form of one group from a tile already in registers: q = v_g^T S v_g (packed symmetric S, K static)
-template <int K, int NE, int KU>
-__device__ __forceinline__ double tile_form(const double (&s)[NE], const int (&gi)[KU], const double *__restrict__ vc)
+// the quadratic form of one group from its slot pairs: q = v_g^T S v_g (packed symmetric S, K static);
+// q = sum_j v_j (s_jj v_j + 2 sum_{l>j} s_jl v_l)
+template <int K, int PU>
+__device__ __forceinline__ double tile_form(const double2 (&pr)[PU], const double *__restrict__ vc)
 {
+    constexpr int NI = tile_ni(K);
     double vj[K];
 #pragma unroll
-    for (int j = 0; j < K; j++) vj[j] = vc[gi[j]];
+    for (int j = 0; j < K; j++) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(tile_slot(pr, j >> 3));
+        vj[j] = vc[(int)((bits >> (8 * (j & 7))) & 0xffull)];
+    }
     double q = 0.0;
-    int e = 0;
+    int e = NI;
 #pragma unroll
     for (int j = 0; j < K; j++) {
         double t = 0.0;
 #pragma unroll
-        for (int l = j + 1; l < K; l++) t = fma(s[e + (l - j)], vj[l], t);
-        t = fma(s[e], vj[j], 2.0 * t);
+        for (int l = j + 1; l < K; l++) t = fma(tile_slot(pr, e + (l - j)), vj[l], t);
+        t = fma(tile_slot(pr, e), vj[j], 2.0 * t);
         q = fma(vj[j], t, q);
         e += K - j;
     }
     return q;
 }
 
-// generic k (13..16): entries re-read per candidate, no big register arrays
-__device__ __forceinline__ void grad_tile_generic(const TileDesc &td, const double *__restrict__ tvals,
-                                                  const uint8_t *__restrict__ tidx, const double *__restrict__ v,
+// gradient pass: one wavefront per tile, lane = group
+template <int K>
+__device__ __forceinline__ void grad_tile(const TileDesc &td, const double *__restrict__ tvals, const double *__restrict__ v,
+                                          const int32_t *__restrict__ status, int N, int n_out, int n_cand,
+                                          double *__restrict__ grad, int64_t grad_stride, int lane)
+{
+    double2 pr[tile_pairs(K)];
+    tile_load(pr, tvals + td.val_off + 2 * lane, tile_pairs(K));
+    for (int c = 0; c < n_cand; c++) {
+        const int64_t eo = (int64_t)c * n_out + td.out;
+        const double q = tile_form<K>(pr, v + eo * N);
+        if (lane < (td.n_valid & 0xffff))
+            grad[(int64_t)c * grad_stride + td.grad_off + lane] = (status[eo] == BLUEST_EVAL_INF) ? INFINITY : -q;
+    }
+}
+
+// generic k (13..16): slots re-read per candidate, no big register arrays
+__device__ __forceinline__ void grad_tile_generic(const TileDesc &td, const double *__restrict__ tvals, const double *__restrict__ v,
                                                   const int32_t *__restrict__ status, int N, int n_out, int n_cand,
                                                   double *__restrict__ grad, int64_t grad_stride, int lane)
 {
     const int K = td.k;
-    const double *vals = tvals + td.val_off + lane;
-    const uint8_t *idx = tidx + td.idx_off + lane;
+    const double *tile = tvals + td.val_off;
+    const int ni = tile_ni(K);
+    auto model = [&](int j) { return (int)reinterpret_cast<const uint8_t *>(tile + tile_slot_off(j >> 3, lane))[j & 7]; };
     for (int c = 0; c < n_cand; c++) {
         const int64_t eo = (int64_t)c * n_out + td.out;
         const double *vc = v + eo * N;
         double q = 0.0;
-        int e = 0;
+        int e = ni;
         for (int j = 0; j < K; j++) {
-            const double vjj = vc[idx[j * 64]];
+            const double vjj = vc[model(j)];
             double t = 0.0;
-            for (int l = j + 1; l < K; l++) t = fma(vals[(e + (l - j)) * 64], vc[idx[l * 64]], t);
-            t = fma(vals[e * 64], vjj, 2.0 * t);
+            for (int l = j + 1; l < K; l++) t = fma(tile[tile_slot_off(e + (l - j), lane)], vc[model(l)], t);
+            t = fma(tile[tile_slot_off(e, lane)], vjj, 2.0 * t);
             q = fma(vjj, t, q);
             e += K - j;
         }

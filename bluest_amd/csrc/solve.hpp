@@ -56,6 +56,14 @@ __device__ __forceinline__ double readlane_f64(double x, int l)
 // (Staging one output's partials in LDS first -- one coalesced copy, then the fold out of LDS -- was measured and rejected:
 //  step 15.7 vs 15.3 us at the headline size; the LDS round trip and the extra barrier cost more than the dependent HBM
 //  round trip descriptor -> partials they replace.)
+// 0.0 the optimiser cannot see through.  With a literal zero it rewrites `0.0 + (cond ? load : 0.0)` into a sum INSIDE the
+// conditional block of the first load, i.e. it waits for that load before it issues the other seven: one extra round trip.
+__device__ __forceinline__ double opaque_zero()
+{
+    double z;
+    asm("v_mov_b64 %0, 0" : "=v"(z));
+    return z;
+}
 template <int NT>
 __device__ __forceinline__ void fold_rows(SolveLds<NT> &lds, int N, const RowDesc *__restrict__ rows, int row_begin,
                                           int n_rows, const double2 *__restrict__ partial, int tid, int nthreads)
@@ -65,7 +73,7 @@ __device__ __forceinline__ void fold_rows(SolveLds<NT> &lds, int N, const RowDes
         const RowDesc rd = rows[row_begin + r];
         const double2 *p = partial + rd.first_chunk;
         const int n = rd.n_chunks;
-        double s = 0.0, am = 0.0;
+        double s = opaque_zero(), am = opaque_zero();
         for (int c0 = q; c0 < n; c0 += 32) {
             double2 v[8];
 #pragma unroll

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(1024) void k_spg_update_a_fused(double *__restrict_
 // (k_grad_tiles, k_spg_update_a_fused) -- at this size every launch is pure latency.
 template <int KU>
 __global__ __launch_bounds__(1024) void k_spg_finish_small(const TileDesc *__restrict__ tiles, int64_t n_tiles,
-                                                           const double *__restrict__ tvals, const uint8_t *__restrict__ tidx,
+                                                           const double *__restrict__ tvals,
                                                            const double *__restrict__ v, const int32_t *__restrict__ status,
                                                            int N, int n_out, double *__restrict__ grad,
                                                            double *__restrict__ x, double *__restrict__ g,
@@ -269,10 +269,10 @@ __global__ __launch_bounds__(1024) void k_spg_finish_small(const TileDesc *__res
     for (int64_t t = wave; t < n_tiles; t += (blockDim.x >> 6)) {
         const TileDesc td = tiles[t];
         if ((td.n_valid & 0xffff) == 0) continue;
-#define GT(KK) case KK: if (KK <= KU) { grad_tile<(KK <= KU ? KK : 1)>(td, tvals, tidx, v, status, N, n_out, 1, grad, 0, lane); break; }
+#define GT(KK) case KK: if (KK <= KU) { grad_tile<(KK <= KU ? KK : 1)>(td, tvals, v, status, N, n_out, 1, grad, 0, lane); break; }
         switch (td.k) {
             GT(1) GT(2) GT(3) GT(4) GT(5) GT(6) GT(7) GT(8) GT(9) GT(10) GT(11) GT(12)
-            default: grad_tile_generic(td, tvals, tidx, v, status, N, n_out, 1, grad, 0, lane);
+            default: grad_tile_generic(td, tvals, v, status, N, n_out, 1, grad, 0, lane);
         }
 #undef GT
     }
@@ -1187,7 +1187,7 @@ extern "C" int bluest_spg_finish(bluest_plan_t plan, const double *v_dev, const 
         for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
         // 1024 threads: the tile rounds dominate (measured 13.0 / 14.1 / 18.0 us with 1024 / 512 / 256 threads)
 #define LFS(KU) hipLaunchKernelGGL((k_spg_finish_small<KU>), dim3(1), dim3(1024), 0, (hipStream_t)stream, plan->d_tiles, plan->n_tiles, \
-                                   plan->d_tvals, plan->d_tidx, v_dev, status_dev, plan->N, (int)plan->outs.size(), grad_dev, x_dev, g_dev,    \
+                                   plan->d_tvals, v_dev, status_dev, plan->N, (int)plan->outs.size(), grad_dev, x_dev, g_dev,    \
                                    xnew_dev, plan->d_goff, plan->d_invmap, scale_dev, state_dev, floor, plan->L)
         if (kmax <= 5) LFS(5);
         else if (kmax <= 8) LFS(8);

@@ -14,7 +14,7 @@ from bluest_amd.plan import Plan, _stream  # noqa: E402
 
 n, kmax, n_out = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else bench.HEADLINE
 prob = synth.problem(n, kmax, n_out)
-plan = Plan(n, prob["K_tot"], bench.build_outputs(prob))
+plan = Plan(n, prob["K_tot"], bench.build_outputs(prob), max_candidates=2)
 dev = plan.device
 L = prob["K_tot"]
 m = torch.from_numpy(prob["m"][0]).to(dev)

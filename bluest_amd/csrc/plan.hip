@@ -165,6 +165,131 @@ __global__ __launch_bounds__(256) void k_phi_chunks_shared(const double *__restr
     SPAN_END(0, false);
 }
 
+// Phi pass FROM THE TILES (plans whose outputs share one group list, at most 32 workgroups per output): the workgroup that owns
+// tiles [b*tpb, (b+1)*tpb) of output o in the fused solve + gradient kernel also forms their contribution to Phi_o, so the plan
+// holds ONE copy of the inverses (the destination-major copy of k_phi_chunks is not built) and both passes of a step read the
+// same bytes through the same compute unit's L2: 21 MB instead of 42 at the headline size, and that does fit the 32 MB of L2.
+// No float atomics: lane = group multiplies its packed entries by m_g and leaves the products in LDS ([tile slot][entry][lane]).
+// After a barrier the products are summed per symmetric destination in an order fixed with the plan: the destination's
+// contributions (positions into the staging area) are cut into SEGMENTS of 16, one thread sums one segment (its 16 positions
+// sit in registers since the start of the kernel: 32 bytes per thread, padded with the position of a zero), a second barrier, then
+// one thread per destination adds the destination's segment sums in order and writes ONE partial per (destination, workgroup)
+// where fold_rows expects the "chunks" of the destination's row.  max |m| over the groups containing a model rides along on
+// the diagonal destinations.
+struct PhiTilesArgs {
+    const TileDesc *tiles; const RowDesc *rows; const double *tvals; const int64_t *goff; const int32_t *gmap;
+    const uint32_t *wg_seg_base;   // [bpo + 1] first segment of every workgroup
+    const uint16_t *seg_list;      // [segments][16] staging positions
+    const uint16_t *seg_dest;      // [segments] destination (bit 15: diagonal)
+    const uint16_t *wg_dseg;       // [bpo][nsym + 1] first segment (relative to the workgroup) of every destination
+    int bpo, tpb, nsym, stage_stride, seg_cap;   // seg_cap: LDS slots for segment sums (>= segments of any workgroup)
+    uint32_t stride_inv;           // ceil(2^32 / stage_stride): tile slot of a position = mulhi(pos, stride_inv)
+};
+template <int KU, int NW>
+__global__ __launch_bounds__(64 * NW) void k_phi_tiles(const PhiTilesArgs A, const double *__restrict__ m, int64_t m_stride, int n_cand,
+                                                       int64_t n_chunks, double2 *__restrict__ partial, const int32_t *__restrict__ gate)
+{
+    extern __shared__ double phi_stage[];      // [tpb * stride products][64 zeros][(tpb + 1) * 64 |m_g|, last row zero][seg_cap sums][seg_cap maxima]
+    if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
+    if (BLUEST_ABLATE == 6) return;
+    constexpr int PU = tile_pairs(KU);
+    constexpr int NTHREADS = 64 * NW;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tpb = A.tpb, nsym = A.nsym, S = A.stage_stride;
+    const int o = blockIdx.x / A.bpo, b = blockIdx.x % A.bpo;
+    double *stage_m = phi_stage + (int64_t)tpb * S + 64;
+    double *seg_sum = stage_m + (tpb + 1) * 64, *seg_max = seg_sum + A.seg_cap;
+    const bool has = wave < tpb;
+    TileDesc td;
+    td.k = 0; td.n_valid = 0; td.val_off = td.grad_off = 0; td.out = (int16_t)o;
+    if (has) td = A.tiles[(int64_t)blockIdx.x * tpb + wave];
+    // this thread's segment of the first pass: destination and 16 positions (two 16-byte loads)
+    const uint32_t seg0 = A.wg_seg_base[b], nseg = A.wg_seg_base[b + 1] - seg0;
+    uint4 L0 = make_uint4(0, 0, 0, 0), L1 = L0;
+    int sd0 = 0;
+    if ((uint32_t)tid < nseg) {
+        const uint4 *lp = reinterpret_cast<const uint4 *>(A.seg_list + (int64_t)(seg0 + tid) * 16);
+        L0 = lp[0]; L1 = lp[1];
+        sd0 = A.seg_dest[seg0 + tid];
+    }
+    const int k = td.k;
+    double2 pr[PU];
+    if (BLUEST_ABLATE == 11) { for (int i = 0; i < PU; i++) pr[i] = make_double2(1.0, 1.0); }      // (experiment: no tile loads)
+    else if (has && k == KU) {      // the usual tile: straight-line loads
+        const double *tl = A.tvals + td.val_off + 2 * lane;
+#pragma unroll
+        for (int i = 0; i < PU; i++) pr[i] = *reinterpret_cast<const double2 *>(tl + i * 128);
+    } else if (has && k < KU) tile_load(pr, A.tvals + td.val_off + 2 * lane, tile_pairs(k));
+    const bool valid = has && lane < (td.n_valid & 0xffff);
+    int64_t gidx = 0;
+    if (valid) {
+        const int64_t li = td.grad_off - A.goff[o] + lane;
+        gidx = A.gmap ? (int64_t)A.gmap[li] : li;
+    }
+    if (tid < 64) { phi_stage[(int64_t)tpb * S + tid] = 0.0; stage_m[tpb * 64 + tid] = 0.0; }
+    double *my_stage = phi_stage + (int64_t)wave * S + lane;
+    // sum of one segment: positions p[0..16) in order
+    auto seg_reduce = [&](const uint4 &l0, const uint4 &l1, int sd, int slot) {
+        const unsigned w[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+        double s = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {      // eight reads in flight at a time (registers)
+            double v[8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { v[2 * i] = phi_stage[w[4 * h + i] & 0xffffu]; v[2 * i + 1] = phi_stage[w[4 * h + i] >> 16]; }
+#pragma unroll
+            for (int i = 0; i < 8; i++) s += v[i];
+        }
+        seg_sum[slot] = s;
+        if (sd & 0x8000) {     // diagonal destination: max |m| of the contributing groups
+            double am = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const unsigned p0 = w[i] & 0xffffu, p1 = w[i] >> 16;
+                am = fmax(am, stage_m[__umulhi(p0, A.stride_inv) * 64 + (p0 & 63)]);
+                am = fmax(am, stage_m[__umulhi(p1, A.stride_inv) * 64 + (p1 & 63)]);
+            }
+            seg_max[slot] = am;
+        }
+    };
+    for (int c = 0; c < n_cand; c++) {
+        const double mg = valid ? m[(int64_t)c * m_stride + gidx] : 0.0;
+        if (has) {
+            stage_m[wave * 64 + lane] = fabs(mg);
+#define PT(KK) case KK: if (KK <= KU) {                                                                              \
+                _Pragma("unroll") for (int e = 0; e < tile_ne(KK); e++)                                              \
+                    my_stage[e * 64] = mg * tile_slot(pr, tile_ni(KK <= KU ? KK : 1) + e);                           \
+                break; }
+            switch (k) {
+                PT(1) PT(2) PT(3) PT(4) PT(5) PT(6) PT(7) PT(8) PT(9) PT(10) PT(11) PT(12)
+                default: {      // larger groups: slots straight from global memory
+                    const double *tile = A.tvals + td.val_off;
+                    const int ni = tile_ni(k), ne = tile_ne(k);
+                    for (int e = 0; e < ne; e++) my_stage[e * 64] = mg * tile[tile_slot_off(ni + e, lane)];
+                }
+            }
+#undef PT
+        }
+        __syncthreads();
+        if (BLUEST_ABLATE == 10) continue;      // (experiment: products only)
+        if ((uint32_t)tid < nseg) seg_reduce(L0, L1, sd0, tid);
+        for (uint32_t t = tid + NTHREADS; t < nseg; t += NTHREADS) {      // (more segments than threads: rare)
+            const uint4 *lp = reinterpret_cast<const uint4 *>(A.seg_list + (int64_t)(seg0 + t) * 16);
+            seg_reduce(lp[0], lp[1], A.seg_dest[seg0 + t], (int)t);
+        }
+        __syncthreads();
+        for (int d = tid; d < nsym; d += NTHREADS) {
+            const int sb = A.wg_dseg[(int64_t)b * (nsym + 1) + d], se = A.wg_dseg[(int64_t)b * (nsym + 1) + d + 1];
+            const RowDesc rd = A.rows[(int64_t)o * nsym + d];
+            double s = 0.0, am = 0.0;
+            for (int t = sb; t < se; t++) s += seg_sum[t];
+            if (rd.a == rd.b) for (int t = sb; t < se; t++) am = fmax(am, seg_max[t]);
+            partial[(int64_t)c * n_chunks + rd.first_chunk + b] = make_double2(s, am);
+        }
+        if (c + 1 < n_cand) __syncthreads();
+    }
+}
+
 // fused: fold chunk partials + solve.  grid = (n_out, n_cand), block = fold_threads (fold) -> wavefront 0 (solve).
 // want_v: bit0 = also produce v (gradient wanted); bit1 / bit2 = timing diagnostics (fold only / solve twice).
 template <int NT>
@@ -397,7 +522,7 @@ static int pick_ku(int kmax) { return kmax <= 5 ? 5 : kmax <= 6 ? 6 : kmax <= 8 
 template <int NT, int KU>
 __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
                                                     const double2 *__restrict__ partial, const double *__restrict__ rec, double delta,
-                                                    const TileDesc *__restrict__ tiles, int64_t n_tiles, int bpo, int tpb,
+                                                    const TileDesc *__restrict__ tiles, int64_t n_tiles, int bpo, int tpb, int tile_nt,
                                                     const double *__restrict__ tvals,
                                                     double *__restrict__ var, double *__restrict__ v_ws,
                                                     int32_t *__restrict__ status, double *__restrict__ grad,
@@ -479,7 +604,8 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
     } else if (k <= KU && BLUEST_ABLATE != 3) {
         // stream the tile into registers while wavefront 0 factorises (after the fold, so these loads do not queue in front of it)
         PHASE_TILE(1);
-        tile_load(pr, tvals + td.val_off + 2 * lane, tile_pairs(k));
+        if (tile_nt) tile_load<PU, true>(pr, tvals + td.val_off + 2 * lane, tile_pairs(k));
+        else tile_load(pr, tvals + td.val_off + 2 * lane, tile_pairs(k));
         PHASE_TILE(2);
 #ifdef BLUEST_PHASE_TIMING
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -953,7 +1079,8 @@ template <typename T>
 struct RawArray {
     std::unique_ptr<T[]> p;
     size_t n;
-    explicit RawArray(size_t n_) : p(new T[std::max<size_t>(n_, 1)]), n(n_) {}
+    explicit RawArray(size_t n_ = 0) : p(new T[std::max<size_t>(n_, 1)]), n(n_) {}
+    void reset(size_t n_) { p.reset(new T[std::max<size_t>(n_, 1)]); n = n_; }
     T *data() { return p.get(); }
     const T *data() const { return p.get(); }
     size_t size() const { return n; }
@@ -1012,108 +1139,6 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     // counting sort below runs once and the other outputs reuse its result shifted by their chunk base
     const int n_struct = plan->shared ? 1 : n_out;
 
-    // ---- Phi pass: destination-major symmetric CSR, positions only ----------------------------------
-    // parallel counting sort: slice s of S owns a contiguous range of the output's groups; it counts its entries per row,
-    // the per-slice counts are prefix-summed into start offsets, then every slice writes the SLOT of its own entries -- rows
-    // keep their entries in group order whatever S is, so the layout (and every summation order on the GPU) is independent
-    // of threading
-    std::vector<std::vector<int64_t>> counts(n_struct, std::vector<int64_t>(nsym, 0));
-    int64_t max_row = 0;
-    const int S = std::max(1, host_threads() / n_struct);      // slices per structure
-    std::vector<std::vector<int64_t>> slice_cnt((size_t)n_struct * S, std::vector<int64_t>(nsym, 0));
-    auto for_groups_of_slice = [&](int o, int slice, auto &&body) {
-        const OutputDesc &od = plan->outs[o];
-        const int64_t lo = od.L_o * slice / S, hi = od.L_o * (slice + 1) / S;
-        int64_t go = 0, eo = 0, l0 = 0;
-        for (int k = 1; k <= od.K; k++) {
-            const int64_t Lk = od.sizes[k - 1];
-            const int ne = k * (k + 1) / 2;
-            for (int64_t i = std::max<int64_t>(lo - l0, 0); i < std::min<int64_t>(hi - l0, Lk); i++)
-                body(k, od.groups.data() + go + i * k, eo + i * ne, l0 + i);
-            go += Lk * k; eo += Lk * ne; l0 += Lk;
-        }
-    };
-    parallel_items(n_struct * S, [&](int item) {
-        std::vector<int64_t> &cnt = slice_cnt[item];
-        for_groups_of_slice(item / S, item % S, [&](int k, const int64_t *g, int64_t, int64_t) {
-            for (int j = 0; j < k; j++)
-                for (int l = j; l < k; l++) cnt[tri((int)std::min(g[j], g[l]), (int)std::max(g[j], g[l]))]++;
-        });
-    });
-    for (int o = 0; o < n_struct; o++)
-        for (int r = 0; r < nsym; r++) {
-            int64_t run = 0;
-            for (int sl = 0; sl < S; sl++) { const int64_t c = slice_cnt[(size_t)o * S + sl][r]; slice_cnt[(size_t)o * S + sl][r] = run; run += c; }
-            counts[o][r] = run;      // slice_cnt now holds each slice's start offset inside the row
-            max_row = std::max(max_row, run);
-        }
-    timer.lap("count");
-    int iters = 1;
-    while ((max_row + 256LL * iters - 1) / (256LL * iters) > 64 && iters < 1024) iters *= 2;
-    const int64_t CH = 256LL * iters;
-    plan->iters = iters;
-
-    std::vector<RowDesc> rows((size_t)n_out * nsym);
-    std::vector<int32_t> out_row_begin(n_out + 1);
-    std::vector<int64_t> out_chunk_begin(n_out + 1, 0);
-    int64_t n_chunks = 0;
-    for (int o = 0; o < n_out; o++) {
-        out_row_begin[o] = o * nsym;
-        out_chunk_begin[o] = n_chunks;
-        const std::vector<int64_t> &cnt = counts[plan->shared ? 0 : o];
-        for (int a = 0; a < N; a++)
-            for (int b = a; b < N; b++) {
-                RowDesc &rd = rows[(size_t)o * nsym + tri(a, b)];
-                const int64_t nc = (cnt[tri(a, b)] + CH - 1) / CH;
-                rd.first_chunk = (int32_t)n_chunks;
-                rd.n_chunks = (int32_t)nc;
-                rd.out = (int16_t)o; rd.a = (int16_t)a; rd.b = (int16_t)b; rd.pad = 0;
-                n_chunks += nc;
-            }
-    }
-    out_row_begin[n_out] = n_out * nsym;
-    out_chunk_begin[n_out] = n_chunks;
-    if (n_chunks <= 0 || n_chunks * CH > 0x7fffffff0LL) return fail(BLUEST_ERR_ARG, "problem too large for one plan (%lld chunks)", (long long)n_chunks);
-    // slot of every packed-symmetric entry (reference order: group-major, upper triangle row by row) and the column
-    // (= global index of the group) stored at that slot; per structure, relative to the structure's first chunk
-    std::vector<int64_t> struct_entries(n_struct + 1, 0), struct_slots(n_struct + 1, 0);
-    for (int o = 0; o < n_struct; o++) {
-        int64_t ne_all = 0;
-        for (int k = 1; k <= plan->outs[o].K; k++) ne_all += plan->outs[o].sizes[k - 1] * (k * (k + 1) / 2);
-        struct_entries[o + 1] = struct_entries[o] + ne_all;
-        struct_slots[o + 1] = struct_slots[o] + (out_chunk_begin[o + 1] - out_chunk_begin[o]) * CH;
-    }
-    if (struct_slots[n_struct] > 0x7fffffffLL) return fail(BLUEST_ERR_ARG, "problem too large for one plan (%lld slots per structure set)", (long long)struct_slots[n_struct]);
-    RawArray<int32_t> perm((size_t)struct_entries[n_struct]);
-    RawArray<int32_t> cols((size_t)struct_slots[n_struct]);
-    parallel_items(n_struct * S, [&](int item) {
-        const int o = item / S;
-        std::vector<int64_t> &next = slice_cnt[item];     // start offsets, advanced as the slice writes
-        const OutputDesc &od = plan->outs[o];
-        const int64_t chunk0 = out_chunk_begin[o];
-        int32_t *pm = perm.data() + struct_entries[o];
-        int32_t *cl = cols.data() + struct_slots[o];
-        for_groups_of_slice(o, item % S, [&](int k, const int64_t *g, int64_t e0, int64_t li) {
-            int e = 0;
-            for (int j = 0; j < k; j++)
-                for (int l = j; l < k; l++, e++) {
-                    const int rr = tri((int)std::min(g[j], g[l]), (int)std::max(g[j], g[l]));
-                    const int64_t pos = ((int64_t)rows[(size_t)o * nsym + rr].first_chunk - chunk0) * CH + next[rr]++;
-                    pm[e0 + e] = (int32_t)pos;
-                    cl[pos] = (int32_t)od.mapping[li];
-                }
-        });
-    });
-    // padding: value 0 (the device buffer is cleared), column = the row's first column (keeps max|m| per row exact, adds nothing)
-    parallel_items(n_struct, [&](int o) {
-        int32_t *cl = cols.data() + struct_slots[o];
-        for (int rr = 0; rr < nsym; rr++) {
-            const RowDesc &rd = rows[(size_t)o * nsym + rr];
-            const int64_t beg = ((int64_t)rd.first_chunk - out_chunk_begin[o]) * CH, end = beg + (int64_t)rd.n_chunks * CH;
-            for (int64_t pos = beg + counts[o][rr]; pos < end; pos++) cl[pos] = cl[beg];
-        }
-    });
-    timer.lap("CSR slots + columns");
     // ---- gradient pass: group-major tiles (descriptors only; values are scattered on the device) ----------------
     {
         int kmax_all = 0;
@@ -1139,7 +1164,18 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
             if (dev >= 0 && dev < 64) cu_of[dev].store(ncu);
         }
         const int64_t wg_per_output = std::max<int64_t>(1, ncu / n_out);
-        plan->fused_tpb = (int)std::min<int64_t>(tpb_max, std::max<int64_t>(1, (tiles_max + wg_per_output - 1) / wg_per_output));
+        const int64_t tpb_cu = std::max<int64_t>(1, (tiles_max + wg_per_output - 1) / wg_per_output);
+        // Phi pass from the tiles (k_phi_tiles): one group list for all outputs, at most 32 workgroups per output (the fold reads
+        // one partial per destination and workgroup), the products of a workgroup's tiles staged in LDS
+        const int64_t tpb_32 = (tiles_max + 31) / 32;
+        plan->stage_stride = tile_ne(kmax_all) * 64;
+        // LDS of k_phi_tiles (phi_tiles_lds): products + |m| row per tile slot, sums and maxima of <= stride/16 + nsym/tpb segments each
+        const int64_t tpb_lds = ((150 << 10) - 16 * (int64_t)nsym - 2048) / ((int64_t)plan->stage_stride * 9 + 512);
+        const char *tiles_env = getenv("BLUEST_PHI_TILES");        // opt-in, read per plan (profiles/r03_phi_tiles_negative_result.txt)
+        const bool want_tiles = tiles_env && atoi(tiles_env) != 0;
+        plan->phi_tiles = want_tiles && (plan->shared || n_out == 1) && tpb_32 <= std::min<int64_t>(tpb_max, tpb_lds) && kmax_all <= 16;
+        if (plan->phi_tiles) plan->fused_tpb = (int)std::min<int64_t>(std::min<int64_t>(tpb_max, tpb_lds), std::max(tpb_cu, tpb_32));
+        else plan->fused_tpb = (int)std::min<int64_t>(tpb_max, tpb_cu);
     }
     std::vector<TileDesc> tiles;
     std::vector<std::vector<int64_t>> bucket_val(n_out);    // first tile of size bucket k: offset
@@ -1183,9 +1219,185 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     n_tvals = std::max<size_t>(n_tvals, 128);       // the empty padding tiles read (and ignore) one slot pair at offset 0
     plan->grad_len = grad_len;
 
-    // ---- inverse maps for combine_grad ------------------------------------------------------------
     plan->identity = plan->shared && plan->outs[0].L_o == plan->L;
     for (int64_t li = 0; plan->identity && li < plan->L; li++) plan->identity = plan->outs[0].mapping[li] == li;
+    // ---- Phi pass, layout 1 (plans that cannot use k_phi_tiles): destination-major symmetric CSR, positions only ---------
+    int iters = 1;
+    int64_t CH = 256, n_chunks = 0;
+    std::vector<RowDesc> rows((size_t)n_out * nsym);
+    std::vector<int32_t> out_row_begin(n_out + 1);
+    std::vector<int64_t> out_chunk_begin(n_out + 1, 0);
+    std::vector<int64_t> struct_entries(n_struct + 1, 0), struct_slots(n_struct + 1, 0);
+    RawArray<int32_t> perm, cols;
+    std::vector<uint32_t> wg_seg_base;
+    std::vector<uint16_t> seg_list, seg_dest, wg_dseg;
+    std::vector<int32_t> gmap;
+    if (!plan->phi_tiles) {
+        // parallel counting sort: slice s of S owns a contiguous range of the output's groups; it counts its entries per row,
+        // the per-slice counts are prefix-summed into start offsets, then every slice writes the SLOT of its own entries -- rows
+        // keep their entries in group order whatever S is, so the layout (and every summation order on the GPU) is independent
+        // of threading
+        std::vector<std::vector<int64_t>> counts(n_struct, std::vector<int64_t>(nsym, 0));
+        int64_t max_row = 0;
+        const int S = std::max(1, host_threads() / n_struct);      // slices per structure
+        std::vector<std::vector<int64_t>> slice_cnt((size_t)n_struct * S, std::vector<int64_t>(nsym, 0));
+        auto for_groups_of_slice = [&](int o, int slice, auto &&body) {
+            const OutputDesc &od = plan->outs[o];
+            const int64_t lo = od.L_o * slice / S, hi = od.L_o * (slice + 1) / S;
+            int64_t go = 0, eo = 0, l0 = 0;
+            for (int k = 1; k <= od.K; k++) {
+                const int64_t Lk = od.sizes[k - 1];
+                const int ne = k * (k + 1) / 2;
+                for (int64_t i = std::max<int64_t>(lo - l0, 0); i < std::min<int64_t>(hi - l0, Lk); i++)
+                    body(k, od.groups.data() + go + i * k, eo + i * ne, l0 + i);
+                go += Lk * k; eo += Lk * ne; l0 += Lk;
+            }
+        };
+        parallel_items(n_struct * S, [&](int item) {
+            std::vector<int64_t> &cnt = slice_cnt[item];
+            for_groups_of_slice(item / S, item % S, [&](int k, const int64_t *g, int64_t, int64_t) {
+                for (int j = 0; j < k; j++)
+                    for (int l = j; l < k; l++) cnt[tri((int)std::min(g[j], g[l]), (int)std::max(g[j], g[l]))]++;
+            });
+        });
+        for (int o = 0; o < n_struct; o++)
+            for (int r = 0; r < nsym; r++) {
+                int64_t run = 0;
+                for (int sl = 0; sl < S; sl++) { const int64_t c = slice_cnt[(size_t)o * S + sl][r]; slice_cnt[(size_t)o * S + sl][r] = run; run += c; }
+                counts[o][r] = run;      // slice_cnt now holds each slice's start offset inside the row
+                max_row = std::max(max_row, run);
+            }
+        timer.lap("count");
+        while ((max_row + 256LL * iters - 1) / (256LL * iters) > 64 && iters < 1024) iters *= 2;
+        CH = 256LL * iters;
+        plan->iters = iters;
+
+        for (int o = 0; o < n_out; o++) {
+            out_row_begin[o] = o * nsym;
+            out_chunk_begin[o] = n_chunks;
+            const std::vector<int64_t> &cnt = counts[plan->shared ? 0 : o];
+            for (int a = 0; a < N; a++)
+                for (int b = a; b < N; b++) {
+                    RowDesc &rd = rows[(size_t)o * nsym + tri(a, b)];
+                    const int64_t nc = (cnt[tri(a, b)] + CH - 1) / CH;
+                    rd.first_chunk = (int32_t)n_chunks;
+                    rd.n_chunks = (int32_t)nc;
+                    rd.out = (int16_t)o; rd.a = (int16_t)a; rd.b = (int16_t)b; rd.pad = 0;
+                    n_chunks += nc;
+                }
+        }
+        out_row_begin[n_out] = n_out * nsym;
+        out_chunk_begin[n_out] = n_chunks;
+        if (n_chunks <= 0 || n_chunks * CH > 0x7fffffff0LL) return fail(BLUEST_ERR_ARG, "problem too large for one plan (%lld chunks)", (long long)n_chunks);
+        // slot of every packed-symmetric entry (reference order: group-major, upper triangle row by row) and the column
+        // (= global index of the group) stored at that slot; per structure, relative to the structure's first chunk
+        for (int o = 0; o < n_struct; o++) {
+            int64_t ne_all = 0;
+            for (int k = 1; k <= plan->outs[o].K; k++) ne_all += plan->outs[o].sizes[k - 1] * (k * (k + 1) / 2);
+            struct_entries[o + 1] = struct_entries[o] + ne_all;
+            struct_slots[o + 1] = struct_slots[o] + (out_chunk_begin[o + 1] - out_chunk_begin[o]) * CH;
+        }
+        if (struct_slots[n_struct] > 0x7fffffffLL) return fail(BLUEST_ERR_ARG, "problem too large for one plan (%lld slots per structure set)", (long long)struct_slots[n_struct]);
+        perm.reset((size_t)struct_entries[n_struct]);
+        cols.reset((size_t)struct_slots[n_struct]);
+        parallel_items(n_struct * S, [&](int item) {
+            const int o = item / S;
+            std::vector<int64_t> &next = slice_cnt[item];     // start offsets, advanced as the slice writes
+            const OutputDesc &od = plan->outs[o];
+            const int64_t chunk0 = out_chunk_begin[o];
+            int32_t *pm = perm.data() + struct_entries[o];
+            int32_t *cl = cols.data() + struct_slots[o];
+            for_groups_of_slice(o, item % S, [&](int k, const int64_t *g, int64_t e0, int64_t li) {
+                int e = 0;
+                for (int j = 0; j < k; j++)
+                    for (int l = j; l < k; l++, e++) {
+                        const int rr = tri((int)std::min(g[j], g[l]), (int)std::max(g[j], g[l]));
+                        const int64_t pos = ((int64_t)rows[(size_t)o * nsym + rr].first_chunk - chunk0) * CH + next[rr]++;
+                        pm[e0 + e] = (int32_t)pos;
+                        cl[pos] = (int32_t)od.mapping[li];
+                    }
+            });
+        });
+        // padding: value 0 (the device buffer is cleared), column = the row's first column (keeps max|m| per row exact, adds nothing)
+        parallel_items(n_struct, [&](int o) {
+            int32_t *cl = cols.data() + struct_slots[o];
+            for (int rr = 0; rr < nsym; rr++) {
+                const RowDesc &rd = rows[(size_t)o * nsym + rr];
+                const int64_t beg = ((int64_t)rd.first_chunk - out_chunk_begin[o]) * CH, end = beg + (int64_t)rd.n_chunks * CH;
+                for (int64_t pos = beg + counts[o][rr]; pos < end; pos++) cl[pos] = cl[beg];
+            }
+        });
+        timer.lap("CSR slots + columns");
+    } else {
+        // ---- Phi pass, layout 2: per workgroup of the tile assignment and per destination, the staging positions of its products
+        const int bpo = plan->fused_bpo, tpb = plan->fused_tpb, S = plan->stage_stride;
+        iters = 0; CH = 0;
+        n_chunks = (int64_t)n_out * nsym * bpo;
+        for (int o = 0; o < n_out; o++) {
+            out_row_begin[o] = o * nsym;
+            out_chunk_begin[o] = (int64_t)o * nsym * bpo;
+            for (int a = 0; a < N; a++)
+                for (int b = a; b < N; b++) {
+                    RowDesc &rd = rows[(size_t)o * nsym + tri(a, b)];
+                    rd.first_chunk = (int32_t)(((int64_t)o * nsym + tri(a, b)) * bpo);
+                    rd.n_chunks = (int32_t)bpo;
+                    rd.out = (int16_t)o; rd.a = (int16_t)a; rd.b = (int16_t)b; rd.pad = 0;
+                }
+        }
+        out_row_begin[n_out] = n_out * nsym;
+        out_chunk_begin[n_out] = n_chunks;
+        const OutputDesc &od = plan->outs[0];
+        std::vector<int64_t> go_k(od.K + 2, 0), l0_k(od.K + 2, 0);       // first group (member offset, local index) of every size
+        for (int k = 1; k <= od.K; k++) { go_k[k + 1] = go_k[k] + od.sizes[k - 1] * k; l0_k[k + 1] = l0_k[k] + od.sizes[k - 1]; }
+        // per workgroup: contributions sorted by destination (counting sort, increasing staging position inside a destination),
+        // then cut into segments of 16 padded with the position of the zero word behind the products
+        const uint16_t zero_pos = (uint16_t)(tpb * S);
+        std::vector<std::vector<uint16_t>> lists(bpo), dests(bpo);
+        wg_dseg.assign((size_t)bpo * (nsym + 1), 0);
+        parallel_items(bpo, [&](int b) {
+            std::vector<uint32_t> cnt(nsym + 1, 0);
+            auto for_entries = [&](auto &&body) {
+                for (int j = 0; j < tpb; j++) {
+                    const TileDesc &td = tiles[(size_t)b * tpb + j];          // output 0's tiles come first in the list
+                    const int k = td.k, nv = td.n_valid & 0xffff;
+                    const int64_t li0 = td.grad_off - plan->grad_off[0];
+                    for (int e = 0, jj = 0; jj < k; jj++)
+                        for (int ll = jj; ll < k; ll++, e++)
+                            for (int lane = 0; lane < nv; lane++) {
+                                const int64_t *g = od.groups.data() + go_k[k] + (li0 + lane - l0_k[k]) * k;
+                                body(tri((int)std::min(g[jj], g[ll]), (int)std::max(g[jj], g[ll])), (uint16_t)(j * S + e * 64 + lane));
+                            }
+                }
+            };
+            for_entries([&](int d, uint16_t) { cnt[d + 1]++; });
+            for (int d = 0; d < nsym; d++) cnt[d + 1] += cnt[d];
+            std::vector<uint16_t> sorted(cnt[nsym]);
+            std::vector<uint32_t> next(cnt.begin(), cnt.end() - 1);
+            for_entries([&](int d, uint16_t pos) { sorted[next[d]++] = pos; });
+            std::vector<bool> diag(nsym, false);
+            for (int a = 0; a < N; a++) diag[tri(a, a)] = true;
+            for (int d = 0; d < nsym; d++) {
+                wg_dseg[(size_t)b * (nsym + 1) + d] = (uint16_t)dests[b].size();
+                for (uint32_t i = cnt[d]; i < cnt[d + 1]; i += 16) {
+                    for (uint32_t t = i; t < i + 16; t++) lists[b].push_back(t < cnt[d + 1] ? sorted[t] : zero_pos);
+                    dests[b].push_back((uint16_t)(d | (diag[d] ? 0x8000 : 0)));
+                }
+            }
+            wg_dseg[(size_t)b * (nsym + 1) + nsym] = (uint16_t)dests[b].size();
+        });
+        wg_seg_base.assign(bpo + 1, 0);
+        plan->seg_cap = 1;
+        for (int b = 0; b < bpo; b++) {
+            wg_seg_base[b + 1] = wg_seg_base[b] + (uint32_t)dests[b].size();
+            plan->seg_cap = std::max<int>(plan->seg_cap, (int)dests[b].size());
+            seg_list.insert(seg_list.end(), lists[b].begin(), lists[b].end());
+            seg_dest.insert(seg_dest.end(), dests[b].begin(), dests[b].end());
+        }
+        if (plan->seg_cap > 0xffff) return fail(BLUEST_ERR_ARG, "too many contribution segments per workgroup (%d)", plan->seg_cap);
+        if (!plan->identity) { gmap.resize(od.L_o); for (int64_t li = 0; li < od.L_o; li++) gmap[li] = (int32_t)od.mapping[li]; }
+        timer.lap("contribution lists");
+    }
+    // ---- inverse maps for combine_grad ------------------------------------------------------------
     std::vector<int32_t> invmap((size_t)n_out * plan->L, -1);
     parallel_items(n_out, [&](int o) {
         for (int64_t li = 0; li < plan->outs[o].L_o; li++) invmap[(size_t)o * plan->L + plan->outs[o].mapping[li]] = (int32_t)li;
@@ -1195,8 +1407,14 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     plan->n_rows = (int64_t)rows.size();
     plan->n_tiles = (int64_t)tiles.size();
     plan->max_cand = max_candidates;
-    plan->phi_bytes = n_chunks * CH * 8 + (plan->shared ? n_chunks / n_out : n_chunks) * CH * 4 + n_chunks * 16;
+    plan->phi_bytes = plan->phi_tiles ? (int64_t)n_tvals * 8 + (int64_t)seg_list.size() * 2 + (int64_t)seg_dest.size() * 2 + plan->outs[0].L_o * 8 + n_chunks * 16
+                                      : n_chunks * CH * 8 + (plan->shared ? n_chunks / n_out : n_chunks) * CH * 4 + n_chunks * 16;
+    plan->n_segments = (int64_t)seg_dest.size();
     plan->grad_bytes = (int64_t)n_tvals * 8 + grad_len * 8;
+    {
+        static const char *nt_env = getenv("BLUEST_TILE_NT");       // A/B switch: 0 / 1 overrides the rule
+        plan->tile_nt = nt_env ? atoi(nt_env) != 0 : true;
+    }
 
     timer.lap("tile descriptors + inverse maps");
     int rc;
@@ -1209,6 +1427,9 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     const size_t o_goff = arena.reserve(plan->grad_off.size() * sizeof(int64_t));
     const size_t o_perm = arena.reserve(perm.size() * sizeof(int32_t));
     const size_t o_ocb = arena.reserve(out_chunk_begin.size() * sizeof(int64_t));
+    const size_t o_segbase = arena.reserve(wg_seg_base.size() * sizeof(uint32_t)), o_seglist = arena.reserve(seg_list.size() * sizeof(uint16_t));
+    const size_t o_segdest = arena.reserve(seg_dest.size() * sizeof(uint16_t)), o_dseg = arena.reserve(wg_dseg.size() * sizeof(uint16_t));
+    const size_t o_gmap = arena.reserve(gmap.size() * sizeof(int32_t));
     const size_t o_partial = arena.reserve((size_t)max_candidates * n_chunks * sizeof(double2));
     const size_t o_v = arena.reserve((size_t)max_candidates * n_out * N * sizeof(double));
     const size_t o_status = arena.reserve((size_t)max_candidates * n_out * sizeof(int32_t));
@@ -1220,11 +1441,11 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     plan->d_tvals = reinterpret_cast<double *>(arena.base + o_tvals);
     int32_t *d_perm = nullptr;
     // clear what the scatter kernels do not write (padding slots, padding lanes); then the small tables
-    HIP_TRY(hipMemsetAsync(plan->d_vals, 0, (size_t)n_chunks * CH * sizeof(double), 0));
+    if (!plan->phi_tiles) HIP_TRY(hipMemsetAsync(plan->d_vals, 0, (size_t)n_chunks * CH * sizeof(double), 0));
     HIP_TRY(hipMemsetAsync(plan->d_tvals, 0, n_tvals * sizeof(double), 0));
     // columns: the structure's list sits at the structure's own chunk range (shared plans: output 0's range is the one the
     // Phi kernel reads; the other ranges stay unused)
-    for (int o = 0; o < n_struct; o++)
+    for (int o = 0; o < n_struct && !plan->phi_tiles; o++)
         HIP_TRY(hipMemcpy(plan->d_cols + out_chunk_begin[o] * CH, cols.data() + struct_slots[o],
                           (size_t)(struct_slots[o + 1] - struct_slots[o]) * sizeof(int32_t), hipMemcpyHostToDevice));
     if ((rc = upload(arena, o_rows, &plan->d_rows, rows))) return rc;
@@ -1234,6 +1455,12 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     if ((rc = upload(arena, o_goff, &plan->d_goff, plan->grad_off))) return rc;
     if ((rc = upload(arena, o_perm, &d_perm, perm))) return rc;
     if ((rc = upload(arena, o_ocb, &plan->d_out_chunk_begin, out_chunk_begin))) return rc;
+    if ((rc = upload(arena, o_segbase, &plan->d_wg_seg_base, wg_seg_base))) return rc;
+    if ((rc = upload(arena, o_seglist, &plan->d_seg_list, seg_list))) return rc;
+    if ((rc = upload(arena, o_segdest, &plan->d_seg_dest, seg_dest))) return rc;
+    if ((rc = upload(arena, o_dseg, &plan->d_wg_dseg, wg_dseg))) return rc;
+    if ((rc = upload(arena, o_gmap, &plan->d_gmap, gmap))) return rc;
+    if (gmap.empty()) plan->d_gmap = nullptr;
     plan->max_chunks_per_output = 0;
     for (int o = 0; o < n_out; o++) plan->max_chunks_per_output = std::max<int>(plan->max_chunks_per_output, (int)(out_chunk_begin[o + 1] - out_chunk_begin[o]));
     timer.lap("device arena + small uploads");
@@ -1246,6 +1473,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
             const int64_t Lk = od.sizes[k - 1];
             const int ne = k * (k + 1) / 2;
             if (Lk > 0) {
+                if (!plan->phi_tiles)
                 hipLaunchKernelGGL(k_fill_csr, dim3((unsigned)((Lk * ne + 255) / 256)), dim3(256), 0, 0, od.d_invcov + io, k, Lk,
                                    d_perm + struct_entries[st] + eo, plan->d_vals + out_chunk_begin[o] * CH);
                 hipLaunchKernelGGL(k_fill_tiles, dim3((unsigned)((Lk * (ne + k) + 255) / 256)), dim3(256), 0, 0, od.d_invcov + io,
@@ -1415,9 +1643,39 @@ static void launch_grad(bluest_plan_t plan, const double *v_dev, const int32_t *
 #undef LG
 }
 
+// dynamic LDS of k_phi_tiles: products, 64 zeros, |m| rows (one more, zero), segment sums and maxima
+static size_t phi_tiles_lds(int tpb, int stage_stride, int seg_cap)
+{
+    return ((size_t)tpb * stage_stride + 64 + (size_t)(tpb + 1) * 64 + 2 * (size_t)seg_cap) * sizeof(double);
+}
+
 static void launch_chunks(bluest_plan_t p, const double *m, int n_cand, int64_t m_stride, hipStream_t st)
 {
     const int n_out = (int)p->outs.size();
+    if (p->phi_tiles) {
+        int kmax = 0;
+        for (const auto &od : p->outs) kmax = std::max(kmax, od.K);
+        const size_t lds = phi_tiles_lds(p->fused_tpb, p->stage_stride, p->seg_cap);
+        const dim3 grid((unsigned)(p->n_tiles / p->fused_tpb));
+        PhiTilesArgs A;
+        A.tiles = p->d_tiles; A.rows = p->d_rows; A.tvals = p->d_tvals; A.goff = p->d_goff; A.gmap = p->d_gmap;
+        A.wg_seg_base = p->d_wg_seg_base; A.seg_list = p->d_seg_list; A.seg_dest = p->d_seg_dest; A.wg_dseg = p->d_wg_dseg;
+        A.bpo = p->fused_bpo; A.tpb = p->fused_tpb; A.nsym = p->nsym; A.stage_stride = p->stage_stride; A.seg_cap = p->seg_cap;
+        A.stride_inv = (uint32_t)((0x100000000ull + (uint64_t)p->stage_stride - 1) / (uint64_t)p->stage_stride);
+        // same block size as the fused kernel of this plan (16 wavefronts while the tile fits 128 registers, else 8)
+#define LPT(KU, NW) do {                                                                                                          \
+            static size_t lds_set = 0;     /* dynamic LDS beyond 64 KB has to be declared once per kernel */                     \
+            if (lds > lds_set) { (void)hipFuncSetAttribute((const void *)k_phi_tiles<KU, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; } \
+            hipLaunchKernelGGL((k_phi_tiles<KU, NW>), grid, dim3(64 * NW), lds, st, A, m, m_stride, n_cand, p->n_chunks, p->d_partial, p->gate); \
+        } while (0)
+        const bool wide = fused_tpb(pick_nt(p->N), pick_ku(kmax)) == 15;
+        // groups of up to 5 models keep their tile in registers; larger ones read the slots from (L2-resident) global memory in
+        // the product phase -- with the tile AND the segment positions in registers the 1024-thread form would spill
+        if (kmax <= 5) { if (wide) LPT(5, 16); else LPT(5, 8); }
+        else { if (wide) LPT(1, 16); else LPT(1, 8); }
+#undef LPT
+        return;
+    }
     if (p->shared && n_out >= 2) {
         const int64_t ncpo = p->n_chunks / n_out;
         const unsigned gx = (unsigned)((ncpo + 3) / 4);
@@ -1526,7 +1784,7 @@ extern "C" int bluest_plan_solve_grad(bluest_plan_t plan, const double *rec_dev,
     for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
     const dim3 grid((unsigned)(plan->n_tiles / plan->fused_tpb));
 #define LSR2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, \
-                                        rec_dev, delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->fused_tpb, plan->d_tvals, var_dev, plan->d_v, status_dev,  \
+                                        rec_dev, delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->fused_tpb, plan->tile_nt ? 1 : 0, plan->d_tvals, var_dev, plan->d_v, status_dev,  \
                                         grad_dev, plan->gate, state_dev, last_slot, enable_dev, plan->d_ticket)
 #define LSR(NT) do { if (kmax <= 5) LSR2(NT, 5); else if (kmax <= 6) LSR2(NT, 6); else if (kmax <= 8) LSR2(NT, 8); else LSR2(NT, 12); } while (0)
     NT_DISPATCH(plan->N, LSR);
@@ -1570,7 +1828,7 @@ static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_
     if (grad_dev && n_cand == 1 && !g_debug_solve) {
         const dim3 grid((unsigned)(plan->n_tiles / plan->fused_tpb));
 #define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, nullptr, \
-                                        delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->fused_tpb, plan->d_tvals, var_dev, plan->d_v, status, grad_dev, plan->gate, \
+                                        delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->fused_tpb, plan->tile_nt ? 1 : 0, plan->d_tvals, var_dev, plan->d_v, status, grad_dev, plan->gate, \
                                         dec_state, dec_last, dec_enable, plan->d_ticket)
 #define LSG(NT) do { if (kmax <= 5) LSG2(NT, 5); else if (kmax <= 6) LSG2(NT, 6); else if (kmax <= 8) LSG2(NT, 8); else LSG2(NT, 12); } while (0)
         NT_DISPATCH(plan->N, LSG);

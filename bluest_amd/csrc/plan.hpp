@@ -46,6 +46,8 @@ struct bluest_plan_s {
     bool identity = false; // ... and that mapping is the identity (local index = global index for every output)
     int fused_bpo = 0;    // workgroups of k_solve_grad per output when that is the same for every output, else 0
     int fused_tpb = 15;   // tiles per workgroup of k_solve_grad for this plan (tile list is padded to it per output)
+    bool tile_nt = true;  // k_solve_grad streams its tiles with non-temporal loads (same-box A/B over six shapes: 12.8 vs 14.3 us
+                          // per step at the headline size, the others within +-2 %; BLUEST_TILE_NT=0 switches it off)
     const int32_t *gate = nullptr;  // optional device word: 0 = skip the plan's kernels (bluest_plan_set_gate)
     bool always_v = false;          // compute v in every solve (device-side SPG keeps the accepted trial's v)
     int nsym = 0;
@@ -59,6 +61,17 @@ struct bluest_plan_s {
     int32_t *d_out_row_begin = nullptr;
     int64_t *d_out_chunk_begin = nullptr;   // n_out + 1: first chunk of every output (its partials are contiguous)
     int max_chunks_per_output = 0;
+    // Phi pass from the tiles (k_phi_tiles): the plan keeps ONE copy of the inverses.  Per workgroup of the fused kernel's tile
+    // assignment and per symmetric destination, the list of that workgroup's contributions as positions into its LDS staging area
+    bool phi_tiles = false;
+    int stage_stride = 0;               // doubles of staging per tile slot of a workgroup: ne(k_max) * 64
+    int seg_cap = 0;                    // most segments any workgroup has
+    uint32_t *d_wg_seg_base = nullptr;  // [bpo + 1]
+    uint16_t *d_seg_list = nullptr;     // [segments][16] staging positions (tile slot * stage_stride + entry * 64 + lane)
+    uint16_t *d_seg_dest = nullptr;     // [segments] destination, bit 15 = diagonal
+    uint16_t *d_wg_dseg = nullptr;      // [bpo][nsym + 1]
+    int32_t *d_gmap = nullptr;          // local group index -> global index (NULL: identity)
+    int64_t n_segments = 0;
     TileDesc *d_tiles = nullptr;
     double *d_tvals = nullptr;   // tiles: slot pairs (see TileDesc)
     int32_t *d_invmap = nullptr;
@@ -91,11 +104,16 @@ struct DeviceScopeN {
 
 // ---- tile device code shared by plan.hip (gradient pass, fused kernel) and spg.hip (small-plan finish kernel) ----
 // the slot pairs of one lane's group, PU pairs of registers (PU >= tile_pairs(K)); loaded with 16-byte loads
-template <int PU>
+typedef double tile_d2v __attribute__((ext_vector_type(2)));
+template <int PU, bool NT = false>
 __device__ __forceinline__ void tile_load(double2 (&pr)[PU], const double *__restrict__ tile_lane, int n_pairs)
-{   // tile_lane = tvals + td.val_off + 2 * lane
+{   // tile_lane = tvals + td.val_off + 2 * lane; NT: non-temporal loads (the fused kernel's stream, see bluest_plan_s::tile_nt)
 #pragma unroll
-    for (int i = 0; i < PU; i++) if (i < n_pairs) pr[i] = *reinterpret_cast<const double2 *>(tile_lane + i * 128);
+    for (int i = 0; i < PU; i++)
+        if (i < n_pairs) {
+            if (NT) { const tile_d2v v = __builtin_nontemporal_load(reinterpret_cast<const tile_d2v *>(tile_lane + i * 128)); pr[i] = make_double2(v.x, v.y); }
+            else pr[i] = *reinterpret_cast<const double2 *>(tile_lane + i * 128);
+        }
 }
 template <int PU>
 __device__ __forceinline__ double tile_slot(const double2 (&pr)[PU], int sl) { return (sl & 1) ? pr[sl >> 1].y : pr[sl >> 1].x; }   // sl static after unrolling

@@ -6,11 +6,18 @@ GPU parity tests (-m gpu): the HIP path, called through the C-ABI (ctypes -> lib
 Tolerance: float64 work, north-star bar is 1e-10 relative; most checks hold 1e-12.  Where the inputs are
 ill-conditioned (Hodgkin-Huxley paper data, cond 1e9..5e10) the bound is cond*eps and is written in the test.
 """
+import ctypes
+import os
+import sys
+
 import numpy as np
 import pytest
 
 from bluest_amd import synth
 from conftest import golden, rel_err
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (build_outputs: plan description of a synthetic problem)
 
 pytestmark = pytest.mark.gpu
 
@@ -865,3 +872,47 @@ def test_native_restricted_plan_equals_the_hand_built_one():
     from bluest_amd._lib import BluestHipError
     with pytest.raises(BluestHipError):
         mos.plan.restrict(np.array([5, 3, 9]))                           # not ascending
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(8, 4, 2, 1), (20, 5, 8, 1), (20, 5, 1, 3), (12, 12, 1, 1), (14, 7, 3, 2)])
+def test_phi_pass_from_the_tiles_equals_the_chunk_pass(gpu, monkeypatch, shape):
+    """the opt-in Phi pass that reads the plan's ONE copy of the inverses (k_phi_tiles: products staged in LDS, fixed-order
+    reduction per destination; BLUEST_PHI_TILES=1) against the default destination-major pass: Phi record, V, grad V and
+    status for full plans, candidate batches and a restricted plan (non-identity mapping); large groups take the generic path"""
+    import torch
+    from bluest_amd.plan import Plan
+    n, kmax, n_out, n_cand = shape
+    prob = synth.problem(n, kmax, n_out)
+    rng = np.random.RandomState(5)
+    L = prob["K_tot"]
+    m = rng.rand(n_cand, L) * (rng.rand(n_cand, L) < 0.7) * 3.0
+    m[:, 0] = 1.0
+    monkeypatch.setenv("BLUEST_PHI_TILES", "0")
+    ref = Plan(n, L, bench.build_outputs(prob), max_candidates=n_cand)
+    monkeypatch.setenv("BLUEST_PHI_TILES", "1")
+    new = Plan(n, L, bench.build_outputs(prob), max_candidates=n_cand)
+    traffic = []
+    for pl in (ref, new):
+        phi_b, grad_b = ctypes.c_int64(), ctypes.c_int64()
+        pl.lib.bluest_plan_traffic(pl._h, ctypes.byref(phi_b), ctypes.byref(grad_b))
+        traffic.append((phi_b.value, grad_b.value))
+    assert traffic[0][1] == traffic[1][1] and traffic[0][0] != traffic[1][0]      # same tiles, another Phi pass: the switch took effect
+    mt = torch.from_numpy(m).to(ref.device)
+    r1, r2 = ref.phi(mt).cpu().numpy(), new.phi(mt).cpu().numpy()
+    N2 = n * n
+    assert np.abs(r1[..., :N2] - r2[..., :N2]).max() <= 1e-13 * np.abs(r1[..., :N2]).max()
+    assert np.array_equal(r1[..., N2:], r2[..., N2:])                     # the flags (models sampled, max |m|) are exact
+    (v1, g1, s1), (v2, g2, s2) = ref.eval(mt), new.eval(mt)
+    assert torch.equal(s1, s2)
+    assert float((v1 / v2 - 1).abs().max()) < 1e-10
+    assert float((g1 - g2).abs().max()) <= 1e-10 * float(g1.abs().max())
+    keep = np.unique(np.concatenate([[0], rng.choice(L, min(L, 150), replace=False)]))
+    monkeypatch.setenv("BLUEST_PHI_TILES", "0")
+    sub1 = ref.restrict(keep)
+    monkeypatch.setenv("BLUEST_PHI_TILES", "1")
+    sub2 = ref.restrict(keep)
+    ms = torch.from_numpy(0.2 + rng.rand(len(keep))).to(ref.device)
+    (v1, g1, s1), (v2, g2, s2) = sub1.eval(ms), sub2.eval(ms)
+    assert torch.equal(s1, s2) and float((v1 / v2 - 1).abs().max()) < 1e-10
+    assert float((g1 - g2).abs().max()) <= 1e-10 * float(g1.abs().max())

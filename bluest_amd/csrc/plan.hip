@@ -79,13 +79,14 @@ static int g_debug_solve = getenv("BLUEST_DEBUG_SOLVE") ? atoi(getenv("BLUEST_DE
 // Part 2 -- plan kernels
 // ------------------------------------------------------------------------------------------------------
 // Phi pass: one wavefront per chunk of CH = 256*iters entries; lane l owns entries [4l, 4l+4) of each 256-block.
-__global__ __launch_bounds__(256) void k_phi_chunks(const double *__restrict__ vals, const int32_t *__restrict__ cols,
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_phi_chunks(const double *__restrict__ vals, const int32_t *__restrict__ cols,
                                                     int iters, int64_t n_chunks, const double *__restrict__ m,
                                                     int64_t m_stride, int n_cand, double2 *__restrict__ partial,
                                                     const int32_t *__restrict__ gate)
 {
     if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
-    const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t chunk = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (chunk >= n_chunks) return;
     const int64_t base = chunk * (int64_t)iters * 256 + lane * 4;
@@ -112,14 +113,14 @@ __global__ __launch_bounds__(256) void k_phi_chunks(const double *__restrict__ v
 // Phi pass, shared structure: when every output has the same groups and mapping (the usual multi-output case) the
 // column indices and the gathered m are common; one wavefront streams the chunk of OB outputs and reads them once.
 // vals / partial keep the output-major chunk numbering of the general layout (chunk id = o*ncpo + c).
-template <int OB>
-__global__ __launch_bounds__(256) void k_phi_chunks_shared(const double *__restrict__ vals, const int32_t *__restrict__ cols,
+template <int OB, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void k_phi_chunks_shared(const double *__restrict__ vals, const int32_t *__restrict__ cols,
                                                            int iters, int64_t ncpo, int n_out, const double *__restrict__ m,
                                                            int64_t m_stride, int n_cand, int64_t n_chunks,
                                                            double2 *__restrict__ partial, const int32_t *__restrict__ gate)
 {
     if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
-    const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t chunk = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int o0 = blockIdx.y * OB;
     if (chunk >= ncpo) return;
@@ -1676,23 +1677,26 @@ static void launch_chunks(bluest_plan_t p, const double *m, int n_cand, int64_t 
 #undef LPT
         return;
     }
+    // wavefronts per workgroup of the chunk kernels: single-wavefront workgroups drain earliest at the kernel's end (same-box A/B
+    // at the headline size, two runs each: step 12.86 / 12.26 / 12.05 us with 4 / 2 / 1 wavefronts, 13.8 with 16)
+    static const int wpb = getenv("BLUEST_PHI_WPB") ? atoi(getenv("BLUEST_PHI_WPB")) : 1;
     if (p->shared && n_out >= 2) {
         const int64_t ncpo = p->n_chunks / n_out;
-        const unsigned gx = (unsigned)((ncpo + 3) / 4);
-#define LCS(OB) hipLaunchKernelGGL((k_phi_chunks_shared<OB>), dim3(gx, (n_out + OB - 1) / OB), dim3(256), 0, st, p->d_vals, p->d_cols, \
-                                   p->iters, ncpo, n_out, m, m_stride, n_cand, p->n_chunks, p->d_partial, p->gate)
         // outputs per wavefront: sharing the column stream saves bytes, but the pass is latency-bound, so keep at least
         // ~4096 wavefronts in flight (measured at n=20, n_out=8: OB=8 6.9 us, OB=4 5.5 us, OB=2 5.1 us, OB=1 6.1 us)
         int ob = 8;
         while (ob > 2 && (ncpo * ((n_out + ob - 1) / ob) < 4096 || ob > n_out)) ob /= 2;
-        if (ob == 8) LCS(8);
-        else if (ob == 4) LCS(4);
-        else LCS(2);
+#define LCS(OB, WPB) hipLaunchKernelGGL((k_phi_chunks_shared<OB, WPB>), dim3((unsigned)((ncpo + WPB - 1) / WPB), (n_out + OB - 1) / OB), dim3(64 * WPB), 0, st, \
+                                        p->d_vals, p->d_cols, p->iters, ncpo, n_out, m, m_stride, n_cand, p->n_chunks, p->d_partial, p->gate)
+        if (wpb == 1) { if (ob == 8) LCS(8, 1); else if (ob == 4) LCS(4, 1); else LCS(2, 1); }
+        else { if (ob == 8) LCS(8, 4); else if (ob == 4) LCS(4, 4); else LCS(2, 4); }
 #undef LCS
         return;
     }
-    hipLaunchKernelGGL(k_phi_chunks, dim3((unsigned)((p->n_chunks + 3) / 4)), dim3(256), 0, st, p->d_vals, p->d_cols,
-                       p->iters, p->n_chunks, m, m_stride, n_cand, p->d_partial, p->gate);
+    if (wpb == 1) hipLaunchKernelGGL(k_phi_chunks<1>, dim3((unsigned)p->n_chunks), dim3(64), 0, st, p->d_vals, p->d_cols,
+                                     p->iters, p->n_chunks, m, m_stride, n_cand, p->d_partial, p->gate);
+    else hipLaunchKernelGGL(k_phi_chunks<4>, dim3((unsigned)((p->n_chunks + 3) / 4)), dim3(256), 0, st, p->d_vals, p->d_cols,
+                            p->iters, p->n_chunks, m, m_stride, n_cand, p->d_partial, p->gate);
 }
 
 extern "C" int bluest_plan_phi_chunks(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, void *stream)

@@ -267,3 +267,235 @@ def solve_capped(plan, costs, cap_rows, cap_rhs, budget=None, eps=None, x0=None,
             else:
                 lo = mid
     return m_hi, info_hi
+
+
+def cost_shift_capped(plan, costs, s_norm, B, cap_rows, cap_rhs, prm=None, x_start=None, log=None):
+    """max_model_samples through the UNCAPPED second-order finish (bluest_amd.colgen.colgen_solve): at the optimum of
+
+        min_m max_o V_o(m)/s_o   s.t.  w.m = B,  a_c.m <= n_c  (a_c = indicator of the groups containing the capped model c)
+
+    stationarity reads  -dF = lambda (w + sum_c theta_c a_c),  theta_c = nu_c / lambda >= 0 -- the capped optimum is the FREE
+    optimum under the shifted costs  w' = w + sum_c theta_c a_c  and the budget  B' = B + sum_c theta_c n_c.  So the caps never enter
+    the master problem: an outer iteration finds theta >= 0 with  theta_c (a_c.m(theta) - n_c) = 0,  a_c.m(theta) <= n_c
+    (active-set Broyden iteration on the relative violations; one warm-started free solve per step).  The bound is free as well:
+    {w.m = B, a_c.m <= n_c} lies inside {w'.m <= B'}, so the certified lower bound of every free solve bounds the capped problem.
+    Works over sharded plans too (nothing but costs and budget changes).  Returns (m, info) or (None, reason)."""
+    from .colgen import colgen_solve
+    prm = dict(prm or {})
+    w = np.asarray(costs, dtype=np.float64)
+    A = np.asarray(cap_rows, dtype=np.float64)
+    n = np.asarray(cap_rhs, dtype=np.float64)
+    ncap = len(n)
+    tol = float(prm.pop("cap_tol", 1.0e-8))
+    max_solves = int(prm.pop("cap_max_solves", 24))
+    warm_ma = int(prm.pop("cap_warm_ma_iterations", 40))
+    warm = bool(prm.pop("cap_warm_start", False))      # measured: a free solve from the previous (sparse) optimum needs more pricing rounds
+                                                        # than one from the uniform point (75 vs 20 ms at the headline size)
+    state = {"solves": 0, "newton_it": 0, "evals": 0, "rounds": 0}
+
+    def run(theta, x0):
+        w2 = w + theta @ A
+        B2 = float(B + theta @ n)
+        p = dict(prm)
+        if x0 is not None and warm:
+            p["ma_iterations"] = warm_ma
+        import time
+        t0_ = time.perf_counter()
+        x, info = colgen_solve(plan, w2, s_norm, B2, x0=x0 if warm else None, prm=p)
+        if x is None:
+            return None, info
+        if log:
+            log("      %.1f ms (ma %.1f, rounds %.1f): rounds %d newton %d full %d master evals %d" % ((time.perf_counter() - t0_) * 1e3, info.get("t_ma_ms", 0), info.get("t_rounds_ms", 0), info["rounds"], info["newton_it"], info["full_evals"], info["master_evals"]))
+        state["solves"] += 1
+        state["newton_it"] += info["newton_it"]
+        state["evals"] += info["full_evals"] + info["master_evals"]
+        state["rounds"] += info["rounds"]
+        m = (B2 / w2) * x
+        g = (A @ m) / n - 1.0
+        if log:
+            log("cost shift solve %2d: theta %s  violation %s  F %.12e gap %.1e" % (state["solves"], np.array2string(theta, precision=4), np.array2string(g, precision=3), info["F"], info["gap"]))
+        return (x, m, g, info), None
+
+    theta = np.zeros(ncap)
+    cur, why = run(theta, x_start)
+    if cur is None:
+        return None, why
+    best_lb = cur[3]["lower_bound"]                     # theta = 0: the free problem is a relaxation as well
+    active = cur[2] > tol
+    lo, hi = np.zeros(ncap), np.full(ncap, np.inf)      # per cap: largest shift seen with the cap violated, smallest seen with it slack
+    J = None
+    th_prev = g_prev = None
+
+    def bracket(th, g_):
+        for c in range(ncap):
+            if g_[c] > 0.0:
+                lo[c] = max(lo[c], th[c])
+                if th[c] >= hi[c]:
+                    hi[c] = np.inf              # the other shifts moved: the old observation no longer holds
+            elif th[c] > 0.0:
+                hi[c] = min(hi[c], th[c])
+                if th[c] <= lo[c]:
+                    lo[c] = 0.0
+
+    def into_bracket(th_new, th_old, act, probe):
+        """usage as a function of one shift is steep and convex (a cheap model drops out altogether): a step that leaves the
+        bracket of its cap is replaced by the bracket's geometric middle (or a tenth of the slack end while nothing smaller is known)"""
+        for i, c in enumerate(act):
+            t = th_new[c]
+            if lo[c] < t < hi[c]:
+                continue
+            if np.isfinite(hi[c]):
+                th_new[c] = np.sqrt(lo[c] * hi[c]) if lo[c] > 0.0 else 0.1 * hi[c]
+            else:
+                th_new[c] = max(2.0 * th_old[c], probe[i])
+        return th_new
+
+    bracket(theta, cur[2])
+    iterates = []                                       # (m, F, w.m, A m) of every free solve: material for the primal recovery
+    recovered = None
+    gap_tol = float(prm.get("gap_tol", 1.0e-7))
+
+    def recover():
+        """At the optimal shifts the free problem has many optima (a face) and the solver returns one of them, so the violations
+        jump and no shift makes them vanish.  The capped optimum is a convex combination on that face: by convexity of F,
+        F(sum_j alpha_j m_j) <= sum_j alpha_j F(m_j), so the best combination of the iterates that respects budget and caps (a tiny
+        LP in alpha) is a feasible point whose value is re-evaluated exactly and compared with the best lower bound."""
+        from scipy.optimize import linprog
+        k = len(iterates)
+        Fj = np.array([it[1] for it in iterates])
+        rows = np.vstack([np.array([it[2] for it in iterates])[None, :] / B, np.stack([it[3] for it in iterates], axis=1) / n[:, None]])
+        # An iterate with slack caps overspends the true budget (it spends B' on w'), one with violated caps underspends it: a
+        # combination is scaled by t = its largest constraint ratio, which multiplies F by t.  First-order model of
+        # t(alpha) * sum_j alpha_j F_j around (1, F_min):  minimise  t + sum_j alpha_j F_j / F_min  -- an LP in (alpha, t).
+        cost = np.concatenate([Fj / Fj.min(), [1.0]])
+        A_ub = np.hstack([rows, -np.ones((ncap + 1, 1))])
+        res = linprog(cost, A_ub=A_ub, b_ub=np.zeros(ncap + 1), A_eq=np.concatenate([np.ones(k), [0.0]])[None, :], b_eq=[1.0],
+                      bounds=[(0, None)] * k + [(0, None)], method="highs")
+        if res.status != 0:
+            return None
+        y = -np.asarray(res.ineqlin.marginals)           # prices of the budget row and the cap rows (sum to 1)
+        state["lp_theta"] = (y[1:] / n) / (y[0] / B) if y[0] > 1.0e-12 else None
+        alpha = np.maximum(res.x[:k], 0.0)
+        m_c = sum(a_ * it[0] for a_, it in zip(alpha, iterates) if a_ > 0)
+        t_ = max(float(w @ m_c) / B, float(((A @ m_c) / n).max()))
+        m_c = m_c / t_                                   # exactly feasible; spends the whole budget or sits at a cap
+        var, _, status = plan.eval(m_c, want_grad=False)
+        if not (status[0].cpu().numpy() == EVAL_OK).all():
+            return None
+        state["evals"] += 1
+        return m_c, float((var[0].cpu().numpy() / np.asarray(s_norm)).max())
+
+    while True:
+        x, m, g, info = cur
+        best_lb = max(best_lb, info["lower_bound"])
+        iterates.append((m, info["F"], float(w @ m), A @ m))
+        viol = np.where(active, np.abs(g), np.maximum(g, 0.0))
+        newly = (~active) & (g > tol)
+        if viol.max() <= tol:
+            break
+        if len(iterates) >= 3 and hasattr(plan, "eval"):
+            got = recover()
+            if got is not None and (recovered is None or got[1] < recovered[1]):
+                recovered = got
+            if log and got is not None:
+                log("   recovery over %d iterates: F %.12e  gap %.2e" % (len(iterates), got[1], 1.0 - best_lb / got[1]))
+            if recovered is not None and 1.0 - best_lb / recovered[1] <= max(gap_tol, 1.0e-7):
+                break
+        if state["solves"] >= max_solves:
+            if viol.max() <= 1.0e-5 or (recovered is not None and 1.0 - best_lb / recovered[1] <= 1.0e-4):
+                break
+            return None, "cost shift did not converge in %d solves (violation %.1e)" % (state["solves"], viol.max())
+        active = active | newly
+        act = np.flatnonzero(active)
+        # Dantzig-Wolfe step: once the iterates lie on both sides of every active cap, the prices of the recovery LP (its budget
+        # and cap rows) ARE the next shifts -- column generation over free optima, the columns being whole allocations
+        G = np.stack([it[3] for it in iterates], axis=1) / n[:, None] - 1.0
+        both = all((G[c] > 0).any() and (G[c] < 0).any() for c in act)
+        if both and state.get("lp_theta") is not None and len(iterates) >= 3:
+            th_new = np.maximum(np.asarray(state["lp_theta"], dtype=np.float64), 0.0)
+            if np.isfinite(th_new).all() and any(np.allclose(th_new, it_th, rtol=1e-3, atol=0) for it_th in state.setdefault("thetas", [])):
+                # the prices have settled but the free solver keeps returning the same few points of the optimal face: look at its
+                # neighbours -- one shift a few per cent up or down, cap by cap
+                k_ = state["perturb"] = state.get("perturb", -1) + 1
+                c_ = act[k_ % len(act)]
+                th_new[c_] *= 1.0 + (0.03 if (k_ // len(act)) % 2 == 0 else -0.03) * (1 + k_ // (2 * len(act)))
+            if np.isfinite(th_new).all() and not any(np.allclose(th_new, it_th, rtol=1e-9, atol=0) for it_th in state.setdefault("thetas", [])):
+                state["thetas"].append(th_new.copy())
+                nxt, why = run(th_new, x)
+                if nxt is None:
+                    return None, why
+                bracket(th_new, nxt[2])
+                th_prev, g_prev, J = None, None, None
+                theta, cur = th_new, nxt
+                continue
+        # scale of a shift: a thousandth of the usage-weighted mean cost of the cap's groups (the capped model is usually a cheap one)
+        usage_w = np.array([float((A[c] * m) @ w / max(A[c] @ m, 1e-300)) if (A[c] @ m) > 0 else float((A[c] @ w) / max(A[c].sum(), 1.0)) for c in act])
+        probe = 1.0e-3 * usage_w
+        never_slack = [c for c in act if not np.isfinite(hi[c]) and g[c] > tol]
+        if never_slack and len(iterates) >= 4:
+            # a cap that has been violated at every shift tried so far: quadruple its shift until it is not
+            th_new = theta.copy()
+            for c in never_slack:
+                th_new[c] = max(4.0 * theta[c], probe[list(act).index(c)])
+            nxt, why = run(th_new, x)
+            if nxt is None:
+                return None, why
+            bracket(th_new, nxt[2])
+            th_prev, g_prev, J = None, None, None
+            theta, cur = th_new, nxt
+            continue
+        if newly.any() or J is None or J.shape[0] != len(act):
+            # (re)start: one probe along all active caps, diagonal secant
+            step = np.where(theta[act] > 0, 0.1 * theta[act], probe) * np.where(g[act] >= 0, 1.0, -1.0)
+            th_new = theta.copy()
+            th_new[act] = np.maximum(theta[act] + step, 0.0)
+            th_new = into_bracket(th_new, theta, act, probe)
+            nxt, why = run(th_new, x)
+            if nxt is None:
+                return None, why
+            bracket(th_new, nxt[2])
+            dth = (th_new - theta)[act]
+            dg = nxt[2][act] - g[act]
+            diag = np.where((np.abs(dg) > 1e-12) & (np.abs(dth) > 0), dg / np.where(dth != 0, dth, 1.0), -1.0 / np.maximum(probe, 1e-300))
+            J = np.diag(np.minimum(diag, -1e-6 / np.maximum(usage_w, 1e-300)))       # more cost, less usage
+            th_prev, g_prev = theta.copy(), g.copy()
+            theta, cur = th_new, nxt
+            continue
+        if th_prev is not None:                                   # Broyden update on the active set
+            dth, dg = (theta - th_prev)[act], (g - g_prev)[act]
+            den = float(dth @ dth)
+            if den > 0:
+                J = J + np.outer(dg - J @ dth, dth) / den
+        try:
+            step = -np.linalg.solve(J, g[act])
+        except np.linalg.LinAlgError:
+            step = -g[act] / np.minimum(np.diag(J), -1e-300)
+        if not np.isfinite(step).all():
+            step = -g[act] / np.minimum(np.diag(J), -1e-300)
+        th_new = theta.copy()
+        th_new[act] = np.maximum(theta[act] + step, 0.0)
+        th_new = into_bracket(th_new, theta, act, probe)
+        drop = (th_new[act] <= 0.0) & (g[act] < 0.0)              # a cap that is slack at zero shift leaves the active set
+        th_prev, g_prev = theta.copy(), g.copy()
+        nxt, why = run(th_new, x)
+        if nxt is None:
+            return None, why
+        bracket(th_new, nxt[2])
+        if drop.any():
+            active[act[drop]] = False
+            J = None if not active.any() else J[np.ix_(~drop, ~drop)]
+            th_prev = None
+        theta, cur = th_new, nxt
+    x, m, g, info = cur
+    # feasible point: one common factor (V is homogeneous of degree -1, so F grows by exactly that factor)
+    t = max(1.0, float(w @ m) / B, float(((A @ m) / n).max()))
+    m = m / t
+    F = info["F"] * t
+    if recovered is not None and recovered[1] <= F:
+        m, F = recovered
+    out = {"F": F, "gap": 1.0 - best_lb / F, "lower_bound": best_lb, "newton_it": state["newton_it"], "rounds": state["rounds"],
+           "full_evals": state["evals"], "master_evals": 0, "kkt": float(np.where(theta > 0, np.abs(g), np.maximum(g, 0.0)).max()),
+           "support": int((m > 0).sum()), "cap_usage": ((A @ m) / n).tolist(), "mu": info.get("mu"), "solves": state["solves"],
+           "theta": theta.tolist()}
+    return m, out
+

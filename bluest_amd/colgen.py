@@ -180,12 +180,16 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
         if x0 is not None:
             xh = (1.0 - 1.0e-3) * xh + 1.0e-3 / L                # the multiplicative update cannot leave a zero
         x_d, m_d = to_dev(xh), to_dev(cc_h * xh)
+        import time as _time
+        _t_ma0 = _time.perf_counter()
         for _ in range(ma_its):
             evaluate(m_d, var)
             check(lib.bluest_ma_update(plan._h, var.data_ptr(), status.data_ptr(), grad.data_ptr(), s_d.data_ptr(), cc.data_ptr(), ma_p,
                                        x_d.data_ptr(), m_d.data_ptr(), st))
         info["full_evals"] += ma_its
         xh = x_d.cpu().numpy()
+        info["t_ma_ms"] = (_time.perf_counter() - _t_ma0) * 1e3
+        _t_r0 = _time.perf_counter()
         S0 = min(L, s_max, max(init_mult * N, N + 1))
         if sharded is not None:
             # every rank owns the entries of its groups; the others never moved (or were zeroed by the first update)
@@ -382,6 +386,7 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
         if (used > cap_rhs * (1.0 + 1.0e-9)).any():
             return None, "the final allocation violates a sample cap"
         info["cap_usage"] = used / cap_rhs
+    info["t_rounds_ms"] = (_time.perf_counter() - _t_r0) * 1e3
     info.update({"F": F_true, "F_background": F_last, "lower_bound": best_lb, "gap": 1.0 - best_lb / F_true, "mu": mu,
                  "support": int((x > 0).sum()), "kkt": float(out[2]), "certificate": cert})
     return x, info

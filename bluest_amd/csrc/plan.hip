@@ -83,12 +83,14 @@ template <int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_phi_chunks(const double *__restrict__ vals, const int32_t *__restrict__ cols,
                                                     int iters, int64_t n_chunks, const double *__restrict__ m,
                                                     int64_t m_stride, int n_cand, double2 *__restrict__ partial,
+                                                    const int32_t *__restrict__ pslot, int64_t pstride,
                                                     const int32_t *__restrict__ gate)
 {
     if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
     const int64_t chunk = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (chunk >= n_chunks) return;
+    const int64_t slot = pslot ? (int64_t)pslot[chunk] : chunk;      // where the fold expects this chunk's partial
     const int64_t base = chunk * (int64_t)iters * 256 + lane * 4;
     for (int c = 0; c < n_cand; c++) {
         const double *mc = m + (int64_t)c * m_stride;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(64 * WPB) void k_phi_chunks(const double *__restric
         }
         s = wave_sum(s);
         amax = wave_max(amax);
-        if (lane == 0) partial[(int64_t)c * n_chunks + chunk] = make_double2(s, amax);
+        if (lane == 0) partial[(int64_t)c * pstride + slot] = make_double2(s, amax);
     }
 }
 
@@ -116,8 +118,8 @@ __global__ __launch_bounds__(64 * WPB) void k_phi_chunks(const double *__restric
 template <int OB, int WPB = 4>
 __global__ __launch_bounds__(64 * WPB) void k_phi_chunks_shared(const double *__restrict__ vals, const int32_t *__restrict__ cols,
                                                            int iters, int64_t ncpo, int n_out, const double *__restrict__ m,
-                                                           int64_t m_stride, int n_cand, int64_t n_chunks,
-                                                           double2 *__restrict__ partial, const int32_t *__restrict__ gate)
+                                                           int64_t m_stride, int n_cand, int64_t pstride, const int32_t *__restrict__ pslot,
+                                                           int slots_per_output, double2 *__restrict__ partial, const int32_t *__restrict__ gate)
 {
     if (gate && *gate == 0) return;   // device-side predication (SPG line-search slots)
     const int64_t chunk = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -125,6 +127,8 @@ __global__ __launch_bounds__(64 * WPB) void k_phi_chunks_shared(const double *__
     const int o0 = blockIdx.y * OB;
     if (chunk >= ncpo) return;
     if (BLUEST_ABLATE == 6) return;
+    // where the fold expects this chunk's partials: output-major chunk numbering, or the regular rows' slots (one structure for all outputs)
+    const int64_t slot = pslot ? (int64_t)pslot[chunk] : chunk, ostride = pslot ? (int64_t)slots_per_output : ncpo;
     SPAN_BEGIN(0);
     const int64_t CH = (int64_t)iters * 256;
     const int64_t base = chunk * CH + lane * 4;
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(64 * WPB) void k_phi_chunks_shared(const double *__
             const double t = wave_sum(s[oo]);
             // (experiment builds: ABLATE 8 stores into the slots of candidate 1 -- needs max_candidates >= 2 --, so the fused kernel
             //  reads partials that were not just rewritten; ABLATE 9 skips the streams above and only stores)
-            if (lane == 0 && o0 + oo < n_out) partial[(int64_t)(c + (BLUEST_ABLATE == 8 ? 1 : 0)) * n_chunks + (int64_t)(o0 + oo) * ncpo + chunk] = make_double2(t, amax);
+            if (lane == 0 && o0 + oo < n_out) partial[(int64_t)(c + (BLUEST_ABLATE == 8 ? 1 : 0)) * pstride + (int64_t)(o0 + oo) * ostride + slot] = make_double2(t, amax);
         }
     }
     SPAN_END(0, false);
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(64 * NW) void k_phi_tiles(const PhiTilesArgs A, con
 // fused: fold chunk partials + solve.  grid = (n_out, n_cand), block = fold_threads (fold) -> wavefront 0 (solve).
 // want_v: bit0 = also produce v (gradient wanted); bit1 / bit2 = timing diagnostics (fold only / solve twice).
 template <int NT>
-__global__ __launch_bounds__(fold_threads(NT)) void k_solve_from_chunks(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
+__global__ __launch_bounds__(fold_threads(NT)) void k_solve_from_chunks(int N, int n_out, const RowDesc *__restrict__ rows, int nsym, FoldReg reg,
                                                            const double2 *__restrict__ partial, int64_t n_chunks,
                                                            double delta, int want_v, double *__restrict__ var,
                                                            double *__restrict__ v, int32_t *__restrict__ status,
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(fold_threads(NT)) void k_solve_from_chunks(int N, i
     SpgPrefetch pf;
     if (spg_state && tid < WAVE) spg_prefetch_state(spg_state, tid, pf);   // in flight during the fold (see spg_state.hpp)
     if (N < NT) { clear_pads(lds, N, tid, fold_threads(NT)); __syncthreads(); }   // uniform; every real entry is written by the fold
-    fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, fold_threads(NT));
+    fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, fold_threads(NT), reg);
     __syncthreads();
     if (tid >= WAVE) return;   // single wavefront from here on
     const int lane = tid;
@@ -358,13 +362,13 @@ __global__ __launch_bounds__(fold_threads(NT)) void k_solve_from_chunks(int N, i
 
 // multi-GPU path, phase A tail: fold chunk partials into an all-reduce-able record.
 template <int NT>
-__global__ __launch_bounds__(fold_threads(NT)) void k_fold_to_record(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
+__global__ __launch_bounds__(fold_threads(NT)) void k_fold_to_record(int N, int n_out, const RowDesc *__restrict__ rows, int nsym, FoldReg reg,
                                                         const double2 *__restrict__ partial, int64_t n_chunks,
                                                         double *__restrict__ rec)
 {
     __shared__ SolveLds<NT> lds;
     const int o = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
-    fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, fold_threads(NT));
+    fold_rows(lds, N, rows, o * nsym, nsym, partial + (int64_t)c * n_chunks, tid, fold_threads(NT), reg);
     __syncthreads();
     const int reclen = N * N + 2 * N + 1;
     double *r = rec + ((int64_t)c * n_out + o) * reclen;
@@ -521,7 +525,7 @@ __global__ __launch_bounds__(256) void k_grad_tiles(const TileDesc *__restrict__
 __host__ __device__ constexpr int fused_tpb(int NT, int KU) { return (NT <= 26 && KU <= 8) ? 15 : 7; }
 static int pick_ku(int kmax) { return kmax <= 5 ? 5 : kmax <= 6 ? 6 : kmax <= 8 ? 8 : 12; }
 template <int NT, int KU>
-__global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int N, int n_out, const RowDesc *__restrict__ rows, int nsym,
+__global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int N, int n_out, const RowDesc *__restrict__ rows, int nsym, FoldReg reg,
                                                     const double2 *__restrict__ partial, const double *__restrict__ rec, double delta,
                                                     const TileDesc *__restrict__ tiles, int64_t n_tiles, int bpo, int tpb, int tile_nt,
                                                     const double *__restrict__ tvals,
@@ -564,7 +568,7 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
         for (int t = tid; t < N * N; t += NTHREADS) lds.at(t / N, t % N) = (t / N == t % N) ? 1.0 : 0.0;
         if (tid < N) lds.amax[tid] = 1.0;
     } else {
-        fold_rows<NT>(lds, N, rows, o * nsym, nsym, partial, tid, NTHREADS);
+        fold_rows<NT>(lds, N, rows, o * nsym, nsym, partial, tid, NTHREADS, reg);
     }
     // the list is padded to a multiple of FUSED_TPB tiles per output, so every tile of this workgroup belongs to output o
     // (loaded by the tile wavefronts only: the solving wavefront must not wait for a descriptor it does not use)
@@ -1232,7 +1236,10 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     RawArray<int32_t> perm, cols;
     std::vector<uint32_t> wg_seg_base;
     std::vector<uint16_t> seg_list, seg_dest, wg_dseg;
-    std::vector<int32_t> gmap;
+    std::vector<int32_t> gmap, pslot;
+    plan->fold_reg = FoldReg{0, 0, nullptr};
+    std::vector<uint16_t> rank_ab;
+    plan->slots_per_output = 0;
     if (!plan->phi_tiles) {
         // parallel counting sort: slice s of S owns a contiguous range of the output's groups; it counts its entries per row,
         // the per-slice counts are prefix-summed into start offsets, then every slice writes the SLOT of its own entries -- rows
@@ -1328,6 +1335,31 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
                 for (int64_t pos = beg + counts[o][rr]; pos < end; pos++) cl[pos] = cl[beg];
             }
         });
+        // regular rows (solve.hpp FoldReg): fixed partial strides per destination class when that wastes at most a quarter
+        {
+            int Cd = 0, Co = 0;
+            for (const RowDesc &rd : rows) { if (rd.a == rd.b) Cd = std::max<int>(Cd, rd.n_chunks); else Co = std::max<int>(Co, rd.n_chunks); }
+            Co = std::max(Co, 1);
+            const int64_t slots = (int64_t)N * Cd + (int64_t)(nsym - N) * Co;
+            static const bool no_reg = getenv("BLUEST_NO_REGULAR_FOLD") != nullptr;       // A/B switch
+            if (!no_reg && Cd >= 1 && Cd <= 32 && Co <= 32 && slots * n_out * 4 <= n_chunks * 5 && slots < 0x7fffffff / std::max(1, n_out)) {
+                plan->fold_reg = FoldReg{Cd, Co, nullptr};
+                for (int a = 0; a < N; a++) rank_ab.push_back((uint16_t)(a | (a << 8)));
+                for (int a = 0; a < N; a++) for (int b = a + 1; b < N; b++) rank_ab.push_back((uint16_t)(a | (b << 8)));
+                plan->slots_per_output = (int)slots;
+                pslot.assign((size_t)(plan->shared ? n_chunks / n_out : n_chunks), 0);
+                std::vector<int> off_before(N + 1, 0);          // pairs a' < b' with a' < a
+                for (int a = 0; a < N; a++) off_before[a + 1] = off_before[a] + (N - 1 - a);
+                for (int o = 0; o < n_struct; o++)
+                    for (int a = 0; a < N; a++)
+                        for (int b = a; b < N; b++) {
+                            const RowDesc &rd = rows[(size_t)o * nsym + tri(a, b)];
+                            const int64_t first = (a == b) ? (int64_t)a * Cd : (int64_t)N * Cd + (int64_t)(off_before[a] + (b - a - 1)) * Co;
+                            for (int j = 0; j < rd.n_chunks; j++)
+                                pslot[(size_t)(rd.first_chunk - (plan->shared ? out_chunk_begin[o] : 0)) + j] = (int32_t)(first + (plan->shared ? 0 : (int64_t)o * slots) + j);
+                        }
+            }
+        }
         timer.lap("CSR slots + columns");
     } else {
         // ---- Phi pass, layout 2: per workgroup of the tile assignment and per destination, the staging positions of its products
@@ -1405,6 +1437,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     });
 
     plan->n_chunks = n_chunks;
+    plan->partial_stride = plan->fold_reg.Cd > 0 ? (int64_t)plan->slots_per_output * n_out : n_chunks;
     plan->n_rows = (int64_t)rows.size();
     plan->n_tiles = (int64_t)tiles.size();
     plan->max_cand = max_candidates;
@@ -1431,7 +1464,8 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     const size_t o_segbase = arena.reserve(wg_seg_base.size() * sizeof(uint32_t)), o_seglist = arena.reserve(seg_list.size() * sizeof(uint16_t));
     const size_t o_segdest = arena.reserve(seg_dest.size() * sizeof(uint16_t)), o_dseg = arena.reserve(wg_dseg.size() * sizeof(uint16_t));
     const size_t o_gmap = arena.reserve(gmap.size() * sizeof(int32_t));
-    const size_t o_partial = arena.reserve((size_t)max_candidates * n_chunks * sizeof(double2));
+    const size_t o_partial = arena.reserve((size_t)max_candidates * plan->partial_stride * sizeof(double2));
+    const size_t o_pslot = arena.reserve(pslot.size() * sizeof(int32_t)), o_rankab = arena.reserve(rank_ab.size() * sizeof(uint16_t));
     const size_t o_v = arena.reserve((size_t)max_candidates * n_out * N * sizeof(double));
     const size_t o_status = arena.reserve((size_t)max_candidates * n_out * sizeof(int32_t));
     const size_t o_ticket = arena.reserve(256);
@@ -1461,6 +1495,13 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     if ((rc = upload(arena, o_segdest, &plan->d_seg_dest, seg_dest))) return rc;
     if ((rc = upload(arena, o_dseg, &plan->d_wg_dseg, wg_dseg))) return rc;
     if ((rc = upload(arena, o_gmap, &plan->d_gmap, gmap))) return rc;
+    if ((rc = upload(arena, o_pslot, &plan->d_pslot, pslot))) return rc;
+    if (pslot.empty()) plan->d_pslot = nullptr;
+    {
+        uint16_t *d_rank_ab = nullptr;
+        if ((rc = upload(arena, o_rankab, &d_rank_ab, rank_ab))) return rc;
+        plan->fold_reg.rank_ab = rank_ab.empty() ? nullptr : d_rank_ab;
+    }
     if (gmap.empty()) plan->d_gmap = nullptr;
     plan->max_chunks_per_output = 0;
     for (int o = 0; o < n_out; o++) plan->max_chunks_per_output = std::max<int>(plan->max_chunks_per_output, (int)(out_chunk_begin[o + 1] - out_chunk_begin[o]));
@@ -1486,6 +1527,11 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(0));
     plan->d_partial = reinterpret_cast<double2 *>(arena.base + o_partial);
+    // regular rows read slots no chunk writes: they stay zero for the plan's life
+    if (plan->fold_reg.Cd > 0) {
+        HIP_TRY(hipMemsetAsync(plan->d_partial, 0, (size_t)max_candidates * plan->partial_stride * sizeof(double2), 0));
+        HIP_TRY(hipStreamSynchronize(0));
+    }
     plan->d_v = reinterpret_cast<double *>(arena.base + o_v);
     plan->d_status = reinterpret_cast<int32_t *>(arena.base + o_status);
     plan->d_ticket = reinterpret_cast<unsigned int *>(arena.base + o_ticket);
@@ -1667,7 +1713,7 @@ static void launch_chunks(bluest_plan_t p, const double *m, int n_cand, int64_t 
 #define LPT(KU, NW) do {                                                                                                          \
             static size_t lds_set = 0;     /* dynamic LDS beyond 64 KB has to be declared once per kernel */                     \
             if (lds > lds_set) { (void)hipFuncSetAttribute((const void *)k_phi_tiles<KU, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; } \
-            hipLaunchKernelGGL((k_phi_tiles<KU, NW>), grid, dim3(64 * NW), lds, st, A, m, m_stride, n_cand, p->n_chunks, p->d_partial, p->gate); \
+            hipLaunchKernelGGL((k_phi_tiles<KU, NW>), grid, dim3(64 * NW), lds, st, A, m, m_stride, n_cand, p->partial_stride, p->d_partial, p->gate); \
         } while (0)
         const bool wide = fused_tpb(pick_nt(p->N), pick_ku(kmax)) == 15;
         // groups of up to 5 models keep their tile in registers; larger ones read the slots from (L2-resident) global memory in
@@ -1687,16 +1733,16 @@ static void launch_chunks(bluest_plan_t p, const double *m, int n_cand, int64_t 
         int ob = 8;
         while (ob > 2 && (ncpo * ((n_out + ob - 1) / ob) < 4096 || ob > n_out)) ob /= 2;
 #define LCS(OB, WPB) hipLaunchKernelGGL((k_phi_chunks_shared<OB, WPB>), dim3((unsigned)((ncpo + WPB - 1) / WPB), (n_out + OB - 1) / OB), dim3(64 * WPB), 0, st, \
-                                        p->d_vals, p->d_cols, p->iters, ncpo, n_out, m, m_stride, n_cand, p->n_chunks, p->d_partial, p->gate)
+                                        p->d_vals, p->d_cols, p->iters, ncpo, n_out, m, m_stride, n_cand, p->partial_stride, p->d_pslot, p->slots_per_output, p->d_partial, p->gate)
         if (wpb == 1) { if (ob == 8) LCS(8, 1); else if (ob == 4) LCS(4, 1); else LCS(2, 1); }
         else { if (ob == 8) LCS(8, 4); else if (ob == 4) LCS(4, 4); else LCS(2, 4); }
 #undef LCS
         return;
     }
     if (wpb == 1) hipLaunchKernelGGL(k_phi_chunks<1>, dim3((unsigned)p->n_chunks), dim3(64), 0, st, p->d_vals, p->d_cols,
-                                     p->iters, p->n_chunks, m, m_stride, n_cand, p->d_partial, p->gate);
+                                     p->iters, p->n_chunks, m, m_stride, n_cand, p->d_partial, p->d_pslot, p->partial_stride, p->gate);
     else hipLaunchKernelGGL(k_phi_chunks<4>, dim3((unsigned)((p->n_chunks + 3) / 4)), dim3(256), 0, st, p->d_vals, p->d_cols,
-                            p->iters, p->n_chunks, m, m_stride, n_cand, p->d_partial, p->gate);
+                            p->iters, p->n_chunks, m, m_stride, n_cand, p->d_partial, p->d_pslot, p->partial_stride, p->gate);
 }
 
 extern "C" int bluest_plan_phi_chunks(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, void *stream)
@@ -1718,7 +1764,7 @@ extern "C" int bluest_plan_phi(bluest_plan_t plan, const double *m_dev, int n_ca
     const int n_out = (int)plan->outs.size();
     launch_chunks(plan, m_dev, n_cand, m_stride, st);
 #define LFR(NT) hipLaunchKernelGGL((k_fold_to_record<NT>), dim3(n_out, n_cand), dim3(fold_threads(NT)), 0, st, plan->N, n_out, plan->d_rows, \
-                                   plan->nsym, plan->d_partial, plan->n_chunks, phi_dev)
+                                   plan->nsym, plan->fold_reg, plan->d_partial, plan->partial_stride, phi_dev)
     NT_DISPATCH(plan->N, LFR);
 #undef LFR
     HIP_TRY(hipGetLastError());
@@ -1787,7 +1833,7 @@ extern "C" int bluest_plan_solve_grad(bluest_plan_t plan, const double *rec_dev,
     int kmax = 0;
     for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
     const dim3 grid((unsigned)(plan->n_tiles / plan->fused_tpb));
-#define LSR2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, \
+#define LSR2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->fold_reg, plan->d_partial, \
                                         rec_dev, delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->fused_tpb, plan->tile_nt ? 1 : 0, plan->d_tvals, var_dev, plan->d_v, status_dev,  \
                                         grad_dev, plan->gate, state_dev, last_slot, enable_dev, plan->d_ticket)
 #define LSR(NT) do { if (kmax <= 5) LSR2(NT, 5); else if (kmax <= 6) LSR2(NT, 6); else if (kmax <= 8) LSR2(NT, 8); else LSR2(NT, 12); } while (0)
@@ -1831,7 +1877,7 @@ static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_
     // fused solve + gradient pass (2 launches per evaluation); groups larger than 12 take the generic tile code inside it
     if (grad_dev && n_cand == 1 && !g_debug_solve) {
         const dim3 grid((unsigned)(plan->n_tiles / plan->fused_tpb));
-#define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->d_partial, nullptr, \
+#define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->fold_reg, plan->d_partial, nullptr, \
                                         delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->fused_tpb, plan->tile_nt ? 1 : 0, plan->d_tvals, var_dev, plan->d_v, status, grad_dev, plan->gate, \
                                         dec_state, dec_last, dec_enable, plan->d_ticket)
 #define LSG(NT) do { if (kmax <= 5) LSG2(NT, 5); else if (kmax <= 6) LSG2(NT, 6); else if (kmax <= 8) LSG2(NT, 8); else LSG2(NT, 12); } while (0)
@@ -1843,7 +1889,7 @@ static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_
     }
     const int want = ((grad_dev || plan->always_v) ? 1 : 0) | g_debug_solve;
 #define LSC(NT) hipLaunchKernelGGL((k_solve_from_chunks<NT>), dim3(n_out, n_cand), dim3(fold_threads(NT)), 0, st, plan->N, n_out, plan->d_rows, \
-                                   plan->nsym, plan->d_partial, plan->n_chunks, delta, want, var_dev, plan->d_v, status, plan->gate, \
+                                   plan->nsym, plan->fold_reg, plan->d_partial, plan->partial_stride, delta, want, var_dev, plan->d_v, status, plan->gate, \
                                    dec_state, dec_last, dec_enable, plan->d_ticket)
     NT_DISPATCH(plan->N, LSC);
 #undef LSC

@@ -76,6 +76,10 @@ struct bluest_plan_s {
     double *d_tvals = nullptr;   // tiles: slot pairs (see TileDesc)
     int32_t *d_invmap = nullptr;
     int64_t *d_goff = nullptr;
+    FoldReg fold_reg = {0, 0, nullptr};          // regular rows: fixed partial strides per destination class (solve.hpp), else {0, 0}
+    int32_t *d_pslot = nullptr;         // chunk -> partial slot (regular rows; per structure)
+    int64_t partial_stride = 0;         // partial slots per candidate
+    int slots_per_output = 0;
     double2 *d_partial = nullptr;
     double *d_v = nullptr;       // workspace for eval
     void *d_arena = nullptr;     // ONE device allocation behind all the d_* arrays (hipMalloc is 1-3 ms a piece on a busy process)

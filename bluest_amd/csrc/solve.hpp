@@ -64,11 +64,45 @@ __device__ __forceinline__ double opaque_zero()
     asm("v_mov_b64 %0, 0" : "=v"(z));
     return z;
 }
+// REGULAR rows (the usual plans: every model in equally many groups): the partials of an output sit at fixed strides -- first
+// the N diagonal destinations with Cd slots each, then the off-diagonal ones (a < b, row by row) with Co slots each; slots a
+// row does not use stay zero -- so the fold needs no descriptor: one memory round trip instead of two dependent ones
+// (descriptor -> partials), measured 0.47 us of the 1.5 us fold at the headline size.  Cd = 0: the descriptor path.
+struct FoldReg { int Cd, Co; const uint16_t *rank_ab; };     // rank_ab[r] = a | b << 8 of the destination with rank r
 template <int NT>
 __device__ __forceinline__ void fold_rows(SolveLds<NT> &lds, int N, const RowDesc *__restrict__ rows, int row_begin,
-                                          int n_rows, const double2 *__restrict__ partial, int tid, int nthreads)
+                                          int n_rows, const double2 *__restrict__ partial, int tid, int nthreads, FoldReg reg)
 {
     const int q = tid & 3;
+    if (reg.Cd > 0) {
+        const int slots = N * reg.Cd + (n_rows - N) * reg.Co;
+        const double2 *po = partial + (int64_t)(row_begin / n_rows) * slots;
+        for (int r = tid >> 2; r < n_rows; r += nthreads >> 2) {
+            const bool dg = r < N;
+            const int n = dg ? reg.Cd : reg.Co;
+            const double2 *p = po + (dg ? r * reg.Cd : N * reg.Cd + (r - N) * reg.Co);
+            const unsigned ab = reg.rank_ab[r];            // (an independent load, in flight with the partials)
+            double s = opaque_zero(), am = opaque_zero();
+            for (int c0 = q; c0 < n; c0 += 32) {
+                double2 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = (c0 + 4 * i < n) ? p[c0 + 4 * i] : make_double2(0.0, 0.0);
+#pragma unroll
+                for (int i = 0; i < 8; i++) { s += v[i].x; am = fmax(am, v[i].y); }
+            }
+            const int a = (int)(ab & 0xffu), b = (int)(ab >> 8);
+            s += __shfl_xor(s, 1);
+            am = fmax(am, __shfl_xor(am, 1));
+            s += __shfl_xor(s, 2);
+            am = fmax(am, __shfl_xor(am, 2));
+            if (q == 0) {
+                lds.at(a, b) = s;
+                lds.at(b, a) = s;
+                if (dg) lds.amax[a] = am;
+            }
+        }
+        return;
+    }
     for (int r = tid >> 2; r < n_rows; r += nthreads >> 2) {
         const RowDesc rd = rows[row_begin + r];
         const double2 *p = partial + rd.first_chunk;

@@ -142,12 +142,27 @@ def enforce_sample_caps(plan, costs, es, rhs, samples, budget, eps, solver_param
         if tot > rr:
             clipped[np.asarray(ee) > 0] *= rr / tot
     budget_solver = None
-    if prm["method"] == "newton" and cap_models is not None and type(plan).__name__ == "Plan" and len(es) <= 64:
+    if prm["method"] == "newton" and cap_models is not None and type(getattr(plan, "plan", plan)).__name__ == "Plan":
         cap = {"models": np.asarray(cap_models, dtype=np.int32), "rows": np.stack([np.asarray(ee) for ee in es]), "rhs": np.asarray(rhs, dtype=np.float64)}
         w_h = np.asarray(costs, dtype=np.float64)
+        from .capped import cost_shift_capped
 
         def budget_solver(B, s_norm, start):
-            """the second-order finish with the caps inside its master problem (colgen.colgen_solve); None -> first-order fall-back"""
+            """the second-order finish under shifted costs (capped.cost_shift_capped: the caps never enter the master problem);
+            if that fails, the caps as rows of the master's KKT system (colgen.colgen_solve(caps=...), single GPU, <= 64 caps);
+            None -> first-order fall-back"""
+            x_start = None
+            if start is not None:
+                x_start = np.maximum(np.asarray(start, dtype=np.float64), 0.0) * w_h
+                x_start = x_start / x_start.sum() if x_start.sum() > 0 else None
+            m_cs, cinfo = cost_shift_capped(plan, w_h, s_norm, float(B), cap["rows"], cap["rhs"], prm=prm.get("newton"), x_start=x_start)
+            if m_cs is not None:
+                return m_cs, {"it": cinfo["newton_it"], "count": cinfo["full_evals"], "gpmax": cinfo["kkt"], "f": cinfo["F"], "solver_info": 0,
+                              "fevals": cinfo["full_evals"], "gevals": cinfo["full_evals"], "pruned": int(len(m_cs) - cinfo["support"]),
+                              "method": "newton", "caps": "cost shift (%d free solves)" % cinfo["solves"], "certified_gap": cinfo["gap"],
+                              "rounds": cinfo["rounds"], "cap_usage": cinfo["cap_usage"], "multipliers": cinfo["mu"]}
+            if type(plan).__name__ != "Plan" or len(es) > 64:
+                return None
             xn, ninfo = colgen_solve(plan, w_h, s_norm, float(B), prm=prm.get("newton"), caps=cap)
             if xn is None:
                 return None

@@ -42,3 +42,20 @@ for rep in range(3):
     m = prob["budget"] / prob["costs"] * x
     print("rep %d: %.4f s  max V %.12e  nnz %d  %s" % (rep, dt, max(mos.variances(m)), int((x > 0).sum()),
                                                      {k: (float("%.4g" % v) if isinstance(v, float) else v) for k, v in info.items() if k not in ("mu", "certificate", "cap_usage")}))
+if caps is not None:         # the same caps through the free solver under shifted costs (bluest_amd.capped.cost_shift_capped)
+    from bluest_amd.capped import cost_shift_capped
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        from bluest_amd.host import host_section
+        with host_section():        # (as MOSAP.solve does: no BLAS thread pool, no cyclic collector while the kernels are driven)
+            m, info = cost_shift_capped(mos.plan, prob["costs"], np.ones(n_out), prob["budget"], caps["rows"], caps["rhs"], prm=dict(prm),
+                                        log=print if (verbose and rep == 0) else None)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if m is None:
+            print("cost shift failed:", info)
+            break
+        print("cost shift rep %d: %.4f s  max V %.12e  nnz %d  %s" % (rep, dt, max(mos.variances(m)), int((m > 0).sum()),
+              {k: (float("%.4g" % v) if isinstance(v, float) else v) for k, v in info.items() if k not in ("mu", "certificate")}))
+

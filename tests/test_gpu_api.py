@@ -599,3 +599,34 @@ def test_dropping_a_problem_releases_everything_without_the_cyclic_collector():
     finally:
         spg_device.DeviceSpg.__init__ = orig
         gc.enable()
+
+
+@pytest.mark.parametrize("shape", [(12, 12, 1, 2), (20, 5, 1, 3), (20, 5, 8, 3)])
+def test_sample_caps_through_shifted_costs_are_certified(shape):
+    """max_model_samples (bluest/sap.py:222-240) by free solves under shifted costs (bluest_amd.capped.cost_shift_capped): the
+    allocation respects budget and caps exactly, every binding cap is tight, and the value is within the CERTIFIED gap of the
+    optimum -- the lower bound is the free solver's own bound of a relaxation of the capped problem"""
+    from bluest_amd.capped import cost_shift_capped
+    from bluest_amd.colgen import colgen_solve
+    from bluest_amd.host import host_section
+    from bluest_amd.mosap import MOSAP
+    n, kmax, n_out, ncaps = shape
+    prob = synth.problem(n, kmax, n_out)
+    groups, w, B = prob["groups"], prob["costs"], prob["budget"]
+    mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in groups] for _ in range(n_out)],
+                w, [w] * n_out, verbose=False)
+    with host_section():
+        x_free, info_free = colgen_solve(mos.plan, w, np.ones(n_out), B)
+        m_free = B / w * x_free
+        usage = np.array([float(mos.ES[i] @ m_free) for i in range(n)])
+        models = np.sort(np.argsort(-usage)[:ncaps])
+        rows = np.stack([mos.ES[i] for i in models])
+        rhs = np.array([max(1.0, np.floor(0.5 * usage[i])) for i in models])
+        m, info = cost_shift_capped(mos.plan, w, np.ones(n_out), B, rows, rhs)
+    assert m is not None, info
+    print("cost shift:", {k: info[k] for k in ("F", "gap", "solves", "cap_usage")})
+    assert (m >= 0).all() and m @ w <= B * (1 + 1e-12) and ((rows @ m) <= rhs * (1 + 1e-12)).all()
+    assert min(info["cap_usage"]) > 1 - 1e-6                      # all of these caps bind (half of the free usage)
+    F = float(max(mos.variances(m)))
+    assert abs(F / info["F"] - 1) < 1e-9 and F >= info_free["F"] * (1 - 1e-9)
+    assert 0 <= info["gap"] <= 2e-6 and info["lower_bound"] <= F

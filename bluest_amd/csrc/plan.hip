@@ -1732,6 +1732,8 @@ static void launch_chunks(bluest_plan_t p, const double *m, int n_cand, int64_t 
         // ~4096 wavefronts in flight (measured at n=20, n_out=8: OB=8 6.9 us, OB=4 5.5 us, OB=2 5.1 us, OB=1 6.1 us)
         int ob = 8;
         while (ob > 2 && (ncpo * ((n_out + ob - 1) / ob) < 4096 || ob > n_out)) ob /= 2;
+        static const int ob_env = getenv("BLUEST_PHI_OB") ? atoi(getenv("BLUEST_PHI_OB")) : 0;        // A/B switch
+        if (ob_env == 2 || ob_env == 4 || ob_env == 8) ob = ob_env;
 #define LCS(OB, WPB) hipLaunchKernelGGL((k_phi_chunks_shared<OB, WPB>), dim3((unsigned)((ncpo + WPB - 1) / WPB), (n_out + OB - 1) / OB), dim3(64 * WPB), 0, st, \
                                         p->d_vals, p->d_cols, p->iters, ncpo, n_out, m, m_stride, n_cand, p->partial_stride, p->d_pslot, p->slots_per_output, p->d_partial, p->gate)
         if (wpb == 1) { if (ob == 8) LCS(8, 1); else if (ob == 4) LCS(4, 1); else LCS(2, 1); }

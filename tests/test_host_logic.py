@@ -166,3 +166,54 @@ def test_blueproblem_mpi_semantics_without_mpi():
                       "variances": [4.0], "cost": 8.0}
     mus, errs, cost = p.solve(budget=10.0)
     assert p.MOSAP is None and mus == [1.25] and errs[0] == 2.0 and cost == 8.0
+
+
+def test_sample_caps_by_shifted_costs_on_a_separable_problem(monkeypatch):
+    """the outer iteration of bluest_amd.capped.cost_shift_capped (shifted costs, brackets, Dantzig-Wolfe prices, primal
+    recovery, certified gap) with the free solver replaced by a closed form: F(m) = sum_i v_i / m_i is convex and homogeneous of
+    degree -1 like the estimator variance, its free optimum under costs w and budget B is m_i = B sqrt(v_i / w_i) / sum_j sqrt(v_j w_j),
+    and with caps m_i <= n_i on single entries the optimum is: capped entries at their caps, the rest of the budget spent freely"""
+    import torch
+    from bluest_amd import capped, colgen
+    rng = np.random.RandomState(3)
+    L = 12
+    v, w, B = 0.5 + rng.rand(L), 0.2 + rng.rand(L), 100.0
+
+    def free(costs, budget):
+        m = budget * np.sqrt(v / costs) / np.sqrt(v * costs).sum()
+        return m, float((v / m).sum())
+
+    def fake_colgen(plan, costs, s, budget, x0=None, prm=None, log=None, caps=None):
+        m, F = free(np.asarray(costs), budget)
+        x = np.asarray(costs) * m / budget
+        return x, {"F": F, "lower_bound": F * (1 - 1e-12), "gap": 1e-12, "newton_it": 1, "full_evals": 1, "master_evals": 0, "rounds": 1, "mu": np.ones(1)}
+
+    class FakePlan(object):
+        n_out = 1
+
+        def eval(self, m, want_grad=False):
+            return torch.tensor([[float((v / np.asarray(m)).sum())]], dtype=torch.float64), None, torch.zeros((1, 1), dtype=torch.int32)
+
+    monkeypatch.setattr(colgen, "colgen_solve", fake_colgen)
+    m_free, F_free = free(w, B)
+    capped_idx = np.argsort(-m_free)[:3]
+    rows = np.zeros((3, L))
+    rows[np.arange(3), capped_idx] = 1.0
+    rhs = np.array([0.5, 0.6, 0.7]) * m_free[capped_idx]
+    m, info = capped.cost_shift_capped(FakePlan(), w, np.ones(1), B, rows, rhs)
+    assert m is not None, info
+    # closed form: the capped entries sit at their caps, the others share what is left of the budget
+    rest = np.setdiff1d(np.arange(L), capped_idx)
+    B_rest = B - float(w[capped_idx] @ rhs)
+    m_ref = np.zeros(L)
+    m_ref[capped_idx] = rhs
+    m_ref[rest] = B_rest * np.sqrt(v[rest] / w[rest]) / np.sqrt(v[rest] * w[rest]).sum()
+    F_ref = float((v / m_ref).sum())
+    assert m @ w <= B * (1 + 1e-12) and (rows @ m <= rhs * (1 + 1e-12)).all()
+    assert abs(info["F"] / float((v / m).sum()) - 1) < 1e-12
+    assert info["lower_bound"] <= F_ref * (1 + 1e-9) and info["F"] >= F_ref * (1 - 1e-9)      # bound and value bracket the optimum
+    assert info["F"] / F_ref - 1 < 1e-5 and info["gap"] < 1e-5, (info["F"], F_ref, info["gap"], info["solves"])
+    assert np.abs(m - m_ref).max() < 1e-2 * m_ref.max()
+    # caps that do not bind: the free optimum comes back after one solve
+    m2, info2 = capped.cost_shift_capped(FakePlan(), w, np.ones(1), B, rows, 2.0 * m_free[capped_idx])
+    assert info2["solves"] == 1 and np.allclose(m2, m_free, rtol=1e-12)

@@ -868,7 +868,7 @@ __global__ __launch_bounds__(256) void k_ma_update(int64_t L, int n_out, const d
     __shared__ int64_t sgo[64];                            // ... and so are the gradient offsets (a dependent load per output otherwise)
     __shared__ int sok;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    __shared__ double sr[64];
+    __shared__ double sr[64], sterm[64];
     __shared__ int sst[64];
     if (threadIdx.x < n_out) {                             // the per-output scalars in parallel (one dependent round trip, not 3 n_out)
         const int o = threadIdx.x;
@@ -876,19 +876,23 @@ __global__ __launch_bounds__(256) void k_ma_update(int64_t L, int n_out, const d
         sr[o] = var[o] / so; sst[o] = status[o]; sgo[o] = goff[o]; wgt[o] = so;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < n_out) {                             // ... and the weights too: one pow() per thread, not n_out of them on one
+        const int o = threadIdx.x;
         double rmax = 0.0;
         bool ok = true;
-        for (int o = 0; o < n_out; o++) { ok = ok && sst[o] == BLUEST_EVAL_OK; rmax = fmax(rmax, sr[o]); }
+        for (int oo = 0; oo < n_out; oo++) { ok = ok && sst[oo] == BLUEST_EVAL_OK; rmax = fmax(rmax, sr[oo]); }
         ok = ok && rmax > 0.0 && isfinite(rmax);
+        const double ro = sr[o];
+        const double w = (n_out == 1 || !ok) ? 1.0 : pow(ro / rmax, p - 1.0);
+        sterm[o] = w;                                      // (the denominator is summed below, in output order)
+        wgt[o] = w / wgt[o];
+        if (o == 0) sok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                // the denominator in output order (same sum as before)
         double den = 0.0;
-        for (int o = 0; o < n_out && ok; o++) {
-            const double ro = sr[o];
-            const double w = n_out == 1 ? 1.0 : pow(ro / rmax, p - 1.0);
-            den = fma(w, ro, den);
-            wgt[o] = w / wgt[o];
-        }
-        sden = den; sok = ok ? 1 : 0;
+        for (int o = 0; o < n_out; o++) den = fma(sterm[o], sr[o], den);
+        sden = den;
     }
     __syncthreads();
     if (i >= L || !sok) return;                            // not evaluable: the iterate is left alone (uniform across the grid)

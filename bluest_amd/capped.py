@@ -276,10 +276,18 @@ def cost_shift_capped(plan, costs, s_norm, B, cap_rows, cap_rhs, prm=None, x_sta
 
     stationarity reads  -dF = lambda (w + sum_c theta_c a_c),  theta_c = nu_c / lambda >= 0 -- the capped optimum is the FREE
     optimum under the shifted costs  w' = w + sum_c theta_c a_c  and the budget  B' = B + sum_c theta_c n_c.  So the caps never enter
-    the master problem: an outer iteration finds theta >= 0 with  theta_c (a_c.m(theta) - n_c) = 0,  a_c.m(theta) <= n_c
-    (active-set Broyden iteration on the relative violations; one warm-started free solve per step).  The bound is free as well:
-    {w.m = B, a_c.m <= n_c} lies inside {w'.m <= B'}, so the certified lower bound of every free solve bounds the capped problem.
+    the master problem: an outer iteration runs free solves for shifts theta >= 0.
+
+    At the optimal shifts the free problem has a whole FACE of optima and the free solver returns some point of it, so the cap
+    violations jump and no shift makes them vanish; the capped optimum is a convex combination on that face.  Hence a
+    Dantzig-Wolfe scheme whose columns are whole allocations: (1) probes / a bracketed Broyden iteration on the relative
+    violations until the iterates lie on both sides of every active cap; (2) a small LP over the iterates recovers a feasible
+    combination (`recover`), whose value is re-evaluated exactly, and the LP's prices of the budget and cap rows are the next
+    shifts; (3) when the prices settle on shifts already tried, neighbours a few per cent away are visited (other points of the
+    face).  The bound is free: {w.m = B, a_c.m <= n_c} lies inside {w'.m <= B'}, so the certified lower bound of EVERY free solve
+    bounds the capped problem, and the iteration stops when the recovered value is within gap_tol of the best bound.
     Works over sharded plans too (nothing but costs and budget changes).  Returns (m, info) or (None, reason)."""
+    import time
     from .colgen import colgen_solve
     prm = dict(prm or {})
     w = np.asarray(costs, dtype=np.float64)
@@ -299,7 +307,6 @@ def cost_shift_capped(plan, costs, s_norm, B, cap_rows, cap_rhs, prm=None, x_sta
         p = dict(prm)
         if x0 is not None and warm:
             p["ma_iterations"] = warm_ma
-        import time
         t0_ = time.perf_counter()
         x, info = colgen_solve(plan, w2, s_norm, B2, x0=x0 if warm else None, prm=p)
         if x is None:

@@ -1341,7 +1341,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
             for (const RowDesc &rd : rows) { if (rd.a == rd.b) Cd = std::max<int>(Cd, rd.n_chunks); else Co = std::max<int>(Co, rd.n_chunks); }
             Co = std::max(Co, 1);
             const int64_t slots = (int64_t)N * Cd + (int64_t)(nsym - N) * Co;
-            static const bool no_reg = getenv("BLUEST_NO_REGULAR_FOLD") != nullptr;       // A/B switch
+            const bool no_reg = getenv("BLUEST_NO_REGULAR_FOLD") != nullptr;              // A/B switch, read per plan
             if (!no_reg && Cd >= 1 && Cd <= 32 && Co <= 32 && slots * n_out * 4 <= n_chunks * 5 && slots < 0x7fffffff / std::max(1, n_out)) {
                 plan->fold_reg = FoldReg{Cd, Co, nullptr};
                 for (int a = 0; a < N; a++) rank_ab.push_back((uint16_t)(a | (a << 8)));
@@ -1446,7 +1446,7 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     plan->n_segments = (int64_t)seg_dest.size();
     plan->grad_bytes = (int64_t)n_tvals * 8 + grad_len * 8;
     {
-        static const char *nt_env = getenv("BLUEST_TILE_NT");       // A/B switch: 0 / 1 overrides the rule
+        const char *nt_env = getenv("BLUEST_TILE_NT");              // A/B switch, read per plan: 0 = plain loads
         plan->tile_nt = nt_env ? atoi(nt_env) != 0 : true;
     }
 

@@ -916,3 +916,32 @@ def test_phi_pass_from_the_tiles_equals_the_chunk_pass(gpu, monkeypatch, shape):
     (v1, g1, s1), (v2, g2, s2) = sub1.eval(ms), sub2.eval(ms)
     assert torch.equal(s1, s2) and float((v1 / v2 - 1).abs().max()) < 1e-10
     assert float((g1 - g2).abs().max()) <= 1e-10 * float(g1.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(9, 3, 3), (20, 5, 8), (25, 6, 1)])
+def test_layout_switches_do_not_change_a_bit(gpu, monkeypatch, shape):
+    """the plan-time choices of the second session of round 3 are pure layout / load-policy choices: regular rows (fold without
+    descriptors) against the descriptor path, non-temporal against plain loads of the tile stream -- V, grad V and status
+    must come out bit-identical (the regular rows only add +0.0 for the slots a destination does not use)"""
+    import torch
+    from bluest_amd.plan import Plan
+    n, kmax, n_out = shape
+    prob = synth.problem(n, kmax, n_out)
+    L = prob["K_tot"]
+    rng = np.random.RandomState(9)
+    m = rng.rand(L) * (rng.rand(L) < 0.6) * 2.0
+    m[0] = 1.0
+    got = []
+    for env in ({}, {"BLUEST_NO_REGULAR_FOLD": "1"}, {"BLUEST_TILE_NT": "0"}, {"BLUEST_NO_REGULAR_FOLD": "1", "BLUEST_TILE_NT": "0"}):
+        for k_ in ("BLUEST_NO_REGULAR_FOLD", "BLUEST_TILE_NT"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        pl = Plan(n, L, bench.build_outputs(prob))
+        mt = torch.from_numpy(m).to(pl.device)
+        var, grad, status = pl.eval(mt)
+        rec = pl.phi(mt)
+        got.append((var.clone(), grad.clone(), status.clone(), rec.clone()))
+    for other in got[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(got[0], other))

@@ -313,9 +313,16 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
                         % (eps, rnd, F, gap, S, int(pos.sum()), int(out[4]), int(out[5]), len(enter), out[2], int(out[7])))
                 x_full = (keep[pos], xs[pos] / xs[pos].sum())
                 F_last = F
+                nudge = 0.0
                 if int(out[7]) == 1 and int(out[4]) == 0 and rnd > 0:
-                    break                                          # the master cannot move from here (stalled): pricing again would
-                                                                   # offer the same columns; the certified gap says how far this is
+                    # the master cannot move from here (stalled): pricing again would offer the same columns.  While the certified
+                    # gap is not met and columns still want to enter, let them enter with a little mass instead of zero (a column
+                    # at zero is where the master's quadratic model is least trustworthy) -- a few times per stage, then give up
+                    nudges = info.setdefault("nudges", [0] * len(eps_list))
+                    if gap <= gap_tol or len(enter) == 0 or nudges[stage] >= 3:
+                        break
+                    nudges[stage] += 1
+                    nudge = 1.0e-3 * float(xs[pos].mean())
                 if len(enter) == 0:
                     if mtol > 1.0e-9:
                         mtol = 1.0e-9                              # the support is priced out at a loose master: tighten once
@@ -325,7 +332,7 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
                 viol = cand_v[0] / level - 1.0
                 mtol = max(1.0e-9, min(1.0e-2, 1.0e-2 * float(viol)))
                 new_keep = np.concatenate([keep[pos], np.asarray(enter, dtype=np.int64)])
-                new_x = np.concatenate([xs[pos], np.zeros(len(enter))])   # enter at zero: the master frees them (reduced cost < 0)
+                new_x = np.concatenate([xs[pos], np.full(len(enter), nudge)])   # enter at zero: the master frees them (reduced cost < 0)
                 o2 = np.argsort(new_keep, kind="stable")
                 keep, xs = new_keep[o2], new_x[o2] / new_x.sum()
                 if gap <= gap_tol and stage == len(eps_list) - 1:

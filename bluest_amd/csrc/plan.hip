@@ -13,16 +13,20 @@
 //                16-byte loads and gathers m from L2; fixed-order butterfly sum => bit-reproducible (no float atomics).
 //   * solve    : per (candidate, output): quads of lanes fold the chunk partials per row -> Phi in LDS; one wavefront holds
 //                the restricted, permuted matrix in registers and eliminates by Gauss-Jordan (solve.hpp).
-//   * grad pass: group-major tiles of 64 groups, lane = group, packed-symmetric inverse stored entry-major so every
-//                wave-instruction reads 512 contiguous bytes; fused with the solve for the single-candidate evaluation
-//                (k_solve_grad: one solver wavefront, 15 tile wavefronts streaming while it factorises).
+//   * grad pass: group-major tiles of 64 groups, lane = group; per group the model indices and the packed-symmetric inverse as
+//                8-byte slots stored in pairs, so every wave-instruction reads 16 bytes per lane, 1 KiB contiguous (TileDesc,
+//                plan.hpp); fused with the solve for the single-candidate evaluation (k_solve_grad: one solver wavefront, the
+//                tile wavefronts streaming -- non-temporal loads -- while it factorises; tiles per workgroup chosen per plan
+//                so that the workgroups cover every compute unit).
+//   * What bounds a step after round 3: the two copies of the inverses (Phi layout + tiles) evict each other from the L2s; see
+//                DESIGN.md section 4 and profiles/r03_phi_tiles_negative_result.txt (k_phi_tiles below is the single-copy pass).
 // No CPU fallback exists in this library.
 
 #include "common.hpp"
 
 #ifndef BLUEST_ABLATE      // experiment builds only (-DBLUEST_ABLATE=n, tools/ablate.sh): parts of the evaluation kernels switched off
-#define BLUEST_ABLATE 0    // for timing: 1 no fold, 2 no elimination, 3 no tile stream, 5 empty k_solve_grad, 6 empty Phi pass, 7 no gradient store,
-                           // 8 Phi pass stores its partials elsewhere, 9 Phi pass only stores
+#define BLUEST_ABLATE 0    // for timing: 1 no fold, 2 no elimination, 3 no tile stream, 5 empty k_solve_grad, 6 empty Phi pass, 7 no gradient
+                           // store, 8 Phi pass stores its partials elsewhere, 9 Phi pass only stores, 10 / 11 k_phi_tiles: products only / no tile loads
 #endif
 #ifdef BLUEST_PHASE_TIMING   // experiment builds only (tools/phase_timing.py): 100 MHz timestamps of one workgroup's phases
 __device__ long long g_phase[3][12];

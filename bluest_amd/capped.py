@@ -344,10 +344,15 @@ def cost_shift_capped(plan, costs, s_norm, B, cap_rows, cap_rhs, prm=None, x_sta
                 if th[c] <= lo[c]:
                     lo[c] = 0.0
 
-    def into_bracket(th_new, th_old, act, probe):
+    def into_bracket(th_new, th_old, act, probe, g_now=None):
         """usage as a function of one shift is steep and convex (a cheap model drops out altogether): a step that leaves the
-        bracket of its cap is replaced by the bracket's geometric middle (or a tenth of the slack end while nothing smaller is known)"""
+        bracket of its cap is replaced by the bracket's geometric middle (or a tenth of the slack end while nothing smaller is known).
+        A bracket that has collapsed while the cap is still violated on its lower side has located a JUMP of the usage (two
+        vertices of the optimal face): step just across it, so that the recovery sees both vertices at the current shifts"""
         for i, c in enumerate(act):
+            if g_now is not None and lo[c] > 0.0 and np.isfinite(hi[c]) and hi[c] / lo[c] - 1.0 < 1.0e-2 and abs(g_now[c]) > 1.0e-3:
+                th_new[c] = hi[c] * (1.0 + 2.0e-3) if g_now[c] > 0.0 else lo[c] * (1.0 - 2.0e-3)
+                continue
             t = th_new[c]
             if lo[c] < t < hi[c]:
                 continue
@@ -411,7 +416,15 @@ def cost_shift_capped(plan, costs, s_norm, B, cap_rows, cap_rhs, prm=None, x_sta
         if state["solves"] >= max_solves:
             if viol.max() <= 1.0e-5 or (recovered is not None and 1.0 - best_lb / recovered[1] <= 1.0e-4):
                 break
-            return None, "cost shift did not converge in %d solves (violation %.1e)" % (state["solves"], viol.max())
+            why = "cost shift did not converge in %d solves (violation %.1e)" % (state["solves"], viol.max())
+            if recovered is not None and 1.0 - best_lb / recovered[1] <= 1.0e-3:
+                # not good enough to stop looking, good enough to beat an uncertified first-order answer: the caller may take it
+                m_c, F_c = recovered
+                return None, {"reason": why, "candidate": (m_c, {
+                    "F": F_c, "gap": 1.0 - best_lb / F_c, "lower_bound": best_lb, "newton_it": state["newton_it"], "rounds": state["rounds"],
+                    "full_evals": state["evals"], "master_evals": 0, "kkt": float(viol.max()), "support": int((m_c > 0).sum()),
+                    "cap_usage": ((A @ m_c) / n).tolist(), "mu": info.get("mu"), "solves": state["solves"], "theta": theta.tolist()})}
+            return None, why
         active = active | newly
         act = np.flatnonzero(active)
         # Dantzig-Wolfe step: once the iterates lie on both sides of every active cap, the prices of the recovery LP (its budget
@@ -481,7 +494,7 @@ def cost_shift_capped(plan, costs, s_norm, B, cap_rows, cap_rhs, prm=None, x_sta
             step = -g[act] / np.minimum(np.diag(J), -1e-300)
         th_new = theta.copy()
         th_new[act] = np.maximum(theta[act] + step, 0.0)
-        th_new = into_bracket(th_new, theta, act, probe)
+        th_new = into_bracket(th_new, theta, act, probe, g)
         drop = (th_new[act] <= 0.0) & (g[act] < 0.0)              # a cap that is slack at zero shift leaves the active set
         th_prev, g_prev = theta.copy(), g.copy()
         nxt, why = run(th_new, x)

@@ -156,14 +156,17 @@ def enforce_sample_caps(plan, costs, es, rhs, samples, budget, eps, solver_param
                 x_start = np.maximum(np.asarray(start, dtype=np.float64), 0.0) * w_h
                 x_start = x_start / x_start.sum() if x_start.sum() > 0 else None
             m_cs, cinfo = cost_shift_capped(plan, w_h, s_norm, float(B), cap["rows"], cap["rhs"], prm=prm.get("newton"), x_start=x_start)
+            candidate = cinfo.get("candidate") if (m_cs is None and isinstance(cinfo, dict)) else None
+            xn = None
+            if m_cs is None and type(plan).__name__ == "Plan" and len(es) <= 64:
+                xn, ninfo = colgen_solve(plan, w_h, s_norm, float(B), prm=prm.get("newton"), caps=cap)
+            if m_cs is None and xn is None and candidate is not None:
+                m_cs, cinfo = candidate                      # certified to 1e-3 .. 1e-4: better than the uncertified first-order loop
             if m_cs is not None:
                 return m_cs, {"it": cinfo["newton_it"], "count": cinfo["full_evals"], "gpmax": cinfo["kkt"], "f": cinfo["F"], "solver_info": 0,
                               "fevals": cinfo["full_evals"], "gevals": cinfo["full_evals"], "pruned": int(len(m_cs) - cinfo["support"]),
                               "method": "newton", "caps": "cost shift (%d free solves)" % cinfo["solves"], "certified_gap": cinfo["gap"],
                               "rounds": cinfo["rounds"], "cap_usage": cinfo["cap_usage"], "multipliers": cinfo["mu"]}
-            if type(plan).__name__ != "Plan" or len(es) > 64:
-                return None
-            xn, ninfo = colgen_solve(plan, w_h, s_norm, float(B), prm=prm.get("newton"), caps=cap)
             if xn is None:
                 return None
             return (float(B) / w_h) * xn, {"it": ninfo["newton_it"], "count": ninfo["full_evals"] + ninfo["master_evals"], "gpmax": ninfo["kkt"],

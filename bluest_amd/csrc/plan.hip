@@ -26,7 +26,7 @@
 
 #ifndef BLUEST_ABLATE      // experiment builds only (-DBLUEST_ABLATE=n, tools/ablate.sh): parts of the evaluation kernels switched off
 #define BLUEST_ABLATE 0    // for timing: 1 no fold, 2 no elimination, 3 no tile stream, 5 empty k_solve_grad, 6 empty Phi pass, 7 no gradient
-                           // store, 8 Phi pass stores its partials elsewhere, 9 Phi pass only stores, 10 / 11 k_phi_tiles: products only / no tile loads
+                           // store, 8 Phi pass stores its partials elsewhere, 9 Phi pass only stores, 10 / 11 k_phi_tiles: products only / no tile loads, 12 Phi pass without the gather of m
 #endif
 #ifdef BLUEST_PHASE_TIMING   // experiment builds only (tools/phase_timing.py): 100 MHz timestamps of one workgroup's phases
 __device__ long long g_phase[3][12];
@@ -152,7 +152,11 @@ __global__ __launch_bounds__(64 * WPB) void k_phi_chunks_shared(const double *__
                 v01[oo] = *reinterpret_cast<const double2 *>(vp);
                 v23[oo] = *reinterpret_cast<const double2 *>(vp + 2);
             }
+#if BLUEST_ABLATE == 12      // (experiment: no gather of m)
+            const double m0 = 1.0 + cc.x, m1 = 1.0 + cc.y, m2 = 1.0 + cc.z, m3 = 1.0 + cc.w;
+#else
             const double m0 = mc[cc.x], m1 = mc[cc.y], m2 = mc[cc.z], m3 = mc[cc.w];
+#endif
             amax = fmax(fmax(amax, fmax(fabs(m0), fabs(m1))), fmax(fabs(m2), fabs(m3)));
 #pragma unroll
             for (int oo = 0; oo < OB; oo++) {

@@ -82,9 +82,18 @@ static int g_debug_solve = getenv("BLUEST_DEBUG_SOLVE") ? atoi(getenv("BLUEST_DE
 // ------------------------------------------------------------------------------------------------------
 // Part 2 -- plan kernels
 // ------------------------------------------------------------------------------------------------------
+// columns (global group indices) are stored as uint16 when the allocation vector has at most 65 536 entries (half the bytes of the
+// column stream, which the shared kernel re-reads per pair of outputs), else as int32
+template <typename COLT> __device__ __forceinline__ int4 load_cols4(const COLT *p);
+template <> __device__ __forceinline__ int4 load_cols4<int32_t>(const int32_t *p) { return *reinterpret_cast<const int4 *>(p); }
+template <> __device__ __forceinline__ int4 load_cols4<uint16_t>(const uint16_t *p)
+{
+    const uint2 w = *reinterpret_cast<const uint2 *>(p);
+    return make_int4((int)(w.x & 0xffffu), (int)(w.x >> 16), (int)(w.y & 0xffffu), (int)(w.y >> 16));
+}
 // Phi pass: one wavefront per chunk of CH = 256*iters entries; lane l owns entries [4l, 4l+4) of each 256-block.
-template <int WPB>
-__global__ __launch_bounds__(64 * WPB) void k_phi_chunks(const double *__restrict__ vals, const int32_t *__restrict__ cols,
+template <int WPB, typename COLT>
+__global__ __launch_bounds__(64 * WPB) void k_phi_chunks(const double *__restrict__ vals, const COLT *__restrict__ cols,
                                                     int iters, int64_t n_chunks, const double *__restrict__ m,
                                                     int64_t m_stride, int n_cand, double2 *__restrict__ partial,
                                                     const int32_t *__restrict__ pslot, int64_t pstride,
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(64 * WPB) void k_phi_chunks(const double *__restric
         for (int it = 0; it < iters; it++) {
             const double2 v01 = *reinterpret_cast<const double2 *>(vals + base + it * 256);
             const double2 v23 = *reinterpret_cast<const double2 *>(vals + base + it * 256 + 2);
-            const int4 cc = *reinterpret_cast<const int4 *>(cols + base + it * 256);
+            const int4 cc = load_cols4<COLT>(cols + base + it * 256);
             const double m0 = mc[cc.x], m1 = mc[cc.y], m2 = mc[cc.z], m3 = mc[cc.w];
             s = fma(v01.x, m0, s);
             s = fma(v01.y, m1, s);
@@ -119,8 +128,8 @@ __global__ __launch_bounds__(64 * WPB) void k_phi_chunks(const double *__restric
 // Phi pass, shared structure: when every output has the same groups and mapping (the usual multi-output case) the
 // column indices and the gathered m are common; one wavefront streams the chunk of OB outputs and reads them once.
 // vals / partial keep the output-major chunk numbering of the general layout (chunk id = o*ncpo + c).
-template <int OB, int WPB = 4>
-__global__ __launch_bounds__(64 * WPB) void k_phi_chunks_shared(const double *__restrict__ vals, const int32_t *__restrict__ cols,
+template <int OB, int WPB, typename COLT>
+__global__ __launch_bounds__(64 * WPB) void k_phi_chunks_shared(const double *__restrict__ vals, const COLT *__restrict__ cols,
                                                            int iters, int64_t ncpo, int n_out, const double *__restrict__ m,
                                                            int64_t m_stride, int n_cand, int64_t pstride, const int32_t *__restrict__ pslot,
                                                            int slots_per_output, double2 *__restrict__ partial, const int32_t *__restrict__ gate)
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(64 * WPB) void k_phi_chunks_shared(const double *__
         for (int oo = 0; oo < OB; oo++) s[oo] = 0.0;
         double amax = 0.0;
         for (int it = 0; it < (BLUEST_ABLATE == 9 ? 0 : iters); it++) {
-            const int4 cc = *reinterpret_cast<const int4 *>(cols + base + it * 256);
+            const int4 cc = load_cols4<COLT>(cols + base + it * 256);
             double2 v01[OB], v23[OB];
 #pragma unroll
             for (int oo = 0; oo < OB; oo++) {
@@ -1445,12 +1454,13 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     });
 
     plan->n_chunks = n_chunks;
+    plan->cols16 = plan->L <= 65536 && getenv("BLUEST_COLS32") == nullptr;       // (A/B switch: BLUEST_COLS32=1 keeps int32 columns)
     plan->partial_stride = plan->fold_reg.Cd > 0 ? (int64_t)plan->slots_per_output * n_out : n_chunks;
     plan->n_rows = (int64_t)rows.size();
     plan->n_tiles = (int64_t)tiles.size();
     plan->max_cand = max_candidates;
     plan->phi_bytes = plan->phi_tiles ? (int64_t)n_tvals * 8 + (int64_t)seg_list.size() * 2 + (int64_t)seg_dest.size() * 2 + plan->outs[0].L_o * 8 + n_chunks * 16
-                                      : n_chunks * CH * 8 + (plan->shared ? n_chunks / n_out : n_chunks) * CH * 4 + n_chunks * 16;
+                                      : n_chunks * CH * 8 + (plan->shared ? n_chunks / n_out : n_chunks) * CH * (plan->cols16 ? 2 : 4) + n_chunks * 16;
     plan->n_segments = (int64_t)seg_dest.size();
     plan->grad_bytes = (int64_t)n_tvals * 8 + grad_len * 8;
     {
@@ -1488,6 +1498,14 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     HIP_TRY(hipMemsetAsync(plan->d_tvals, 0, n_tvals * sizeof(double), 0));
     // columns: the structure's list sits at the structure's own chunk range (shared plans: output 0's range is the one the
     // Phi kernel reads; the other ranges stay unused)
+    if (plan->cols16) {
+        RawArray<uint16_t> c16(cols.size());
+        for (size_t i = 0; i < cols.size(); i++) c16.data()[i] = (uint16_t)cols.data()[i];
+        uint16_t *d16 = reinterpret_cast<uint16_t *>(plan->d_cols);
+        for (int o = 0; o < n_struct && !plan->phi_tiles; o++)
+            HIP_TRY(hipMemcpy(d16 + out_chunk_begin[o] * CH, c16.data() + struct_slots[o],
+                              (size_t)(struct_slots[o + 1] - struct_slots[o]) * sizeof(uint16_t), hipMemcpyHostToDevice));
+    } else
     for (int o = 0; o < n_struct && !plan->phi_tiles; o++)
         HIP_TRY(hipMemcpy(plan->d_cols + out_chunk_begin[o] * CH, cols.data() + struct_slots[o],
                           (size_t)(struct_slots[o + 1] - struct_slots[o]) * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -1742,17 +1760,20 @@ static void launch_chunks(bluest_plan_t p, const double *m, int n_cand, int64_t 
         while (ob > 2 && (ncpo * ((n_out + ob - 1) / ob) < 4096 || ob > n_out)) ob /= 2;
         static const int ob_env = getenv("BLUEST_PHI_OB") ? atoi(getenv("BLUEST_PHI_OB")) : 0;        // A/B switch
         if (ob_env == 2 || ob_env == 4 || ob_env == 8) ob = ob_env;
-#define LCS(OB, WPB) hipLaunchKernelGGL((k_phi_chunks_shared<OB, WPB>), dim3((unsigned)((ncpo + WPB - 1) / WPB), (n_out + OB - 1) / OB), dim3(64 * WPB), 0, st, \
-                                        p->d_vals, p->d_cols, p->iters, ncpo, n_out, m, m_stride, n_cand, p->partial_stride, p->d_pslot, p->slots_per_output, p->d_partial, p->gate)
+#define LCS2(OB, WPB, COLT) hipLaunchKernelGGL((k_phi_chunks_shared<OB, WPB, COLT>), dim3((unsigned)((ncpo + WPB - 1) / WPB), (n_out + OB - 1) / OB), dim3(64 * WPB), 0, st, \
+                                        p->d_vals, reinterpret_cast<const COLT *>(p->d_cols), p->iters, ncpo, n_out, m, m_stride, n_cand, p->partial_stride, p->d_pslot, p->slots_per_output, p->d_partial, p->gate)
+#define LCS(OB, WPB) do { if (p->cols16) LCS2(OB, WPB, uint16_t); else LCS2(OB, WPB, int32_t); } while (0)
         if (wpb == 1) { if (ob == 8) LCS(8, 1); else if (ob == 4) LCS(4, 1); else LCS(2, 1); }
         else { if (ob == 8) LCS(8, 4); else if (ob == 4) LCS(4, 4); else LCS(2, 4); }
 #undef LCS
+#undef LCS2
         return;
     }
-    if (wpb == 1) hipLaunchKernelGGL(k_phi_chunks<1>, dim3((unsigned)p->n_chunks), dim3(64), 0, st, p->d_vals, p->d_cols,
-                                     p->iters, p->n_chunks, m, m_stride, n_cand, p->d_partial, p->d_pslot, p->partial_stride, p->gate);
-    else hipLaunchKernelGGL(k_phi_chunks<4>, dim3((unsigned)((p->n_chunks + 3) / 4)), dim3(256), 0, st, p->d_vals, p->d_cols,
-                            p->iters, p->n_chunks, m, m_stride, n_cand, p->d_partial, p->d_pslot, p->partial_stride, p->gate);
+#define LPC(WPB, COLT) hipLaunchKernelGGL((k_phi_chunks<WPB, COLT>), dim3((unsigned)((p->n_chunks + WPB - 1) / WPB)), dim3(64 * WPB), 0, st, p->d_vals, \
+                                       reinterpret_cast<const COLT *>(p->d_cols), p->iters, p->n_chunks, m, m_stride, n_cand, p->d_partial, p->d_pslot, p->partial_stride, p->gate)
+    if (wpb == 1) { if (p->cols16) LPC(1, uint16_t); else LPC(1, int32_t); }
+    else { if (p->cols16) LPC(4, uint16_t); else LPC(4, int32_t); }
+#undef LPC
 }
 
 extern "C" int bluest_plan_phi_chunks(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, void *stream)

@@ -56,7 +56,8 @@ struct bluest_plan_s {
     int64_t phi_bytes = 0, grad_bytes = 0;
     // device
     double *d_vals = nullptr;
-    int32_t *d_cols = nullptr;
+    int32_t *d_cols = nullptr;          // columns of the Phi layout; holds uint16 entries when cols16 (allocation vectors of <= 65 536 entries)
+    bool cols16 = false;
     RowDesc *d_rows = nullptr;
     int32_t *d_out_row_begin = nullptr;
     int64_t *d_out_chunk_begin = nullptr;   // n_out + 1: first chunk of every output (its partials are contiguous)

@@ -922,7 +922,7 @@ def test_phi_pass_from_the_tiles_equals_the_chunk_pass(gpu, monkeypatch, shape):
 @pytest.mark.parametrize("shape", [(9, 3, 3), (20, 5, 8), (25, 6, 1)])
 def test_layout_switches_do_not_change_a_bit(gpu, monkeypatch, shape):
     """the plan-time choices of the second session of round 3 are pure layout / load-policy choices: regular rows (fold without
-    descriptors) against the descriptor path, non-temporal against plain loads of the tile stream -- V, grad V and status
+    descriptors) against the descriptor path, non-temporal against plain loads of the tile stream, 16-bit against 32-bit columns -- V, grad V and status
     must come out bit-identical (the regular rows only add +0.0 for the slots a destination does not use)"""
     import torch
     from bluest_amd.plan import Plan
@@ -933,8 +933,9 @@ def test_layout_switches_do_not_change_a_bit(gpu, monkeypatch, shape):
     m = rng.rand(L) * (rng.rand(L) < 0.6) * 2.0
     m[0] = 1.0
     got = []
-    for env in ({}, {"BLUEST_NO_REGULAR_FOLD": "1"}, {"BLUEST_TILE_NT": "0"}, {"BLUEST_NO_REGULAR_FOLD": "1", "BLUEST_TILE_NT": "0"}):
-        for k_ in ("BLUEST_NO_REGULAR_FOLD", "BLUEST_TILE_NT"):
+    for env in ({}, {"BLUEST_NO_REGULAR_FOLD": "1"}, {"BLUEST_TILE_NT": "0"}, {"BLUEST_COLS32": "1"},
+                {"BLUEST_NO_REGULAR_FOLD": "1", "BLUEST_TILE_NT": "0", "BLUEST_COLS32": "1"}):
+        for k_ in ("BLUEST_NO_REGULAR_FOLD", "BLUEST_TILE_NT", "BLUEST_COLS32"):
             monkeypatch.delenv(k_, raising=False)
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)

@@ -1198,6 +1198,9 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
         plan->phi_tiles = want_tiles && (plan->shared || n_out == 1) && tpb_32 <= std::min<int64_t>(tpb_max, tpb_lds) && kmax_all <= 16;
         if (plan->phi_tiles) plan->fused_tpb = (int)std::min<int64_t>(std::min<int64_t>(tpb_max, tpb_lds), std::max(tpb_cu, tpb_32));
         else plan->fused_tpb = (int)std::min<int64_t>(tpb_max, tpb_cu);
+        if (const char *tpb_env = getenv("BLUEST_TPB")) {                       // A/B switch (not for the single-copy pass)
+            if (!plan->phi_tiles && atoi(tpb_env) >= 1) plan->fused_tpb = (int)std::min<int64_t>(tpb_max, atoi(tpb_env));
+        }
     }
     std::vector<TileDesc> tiles;
     std::vector<std::vector<int64_t>> bucket_val(n_out);    // first tile of size bucket k: offset

@@ -96,8 +96,10 @@ def sap_wallclock(prob, reps=4):
                   "certified_gap": float(mos.solver_info.get("certified_gap", float("nan"))),
                   "max_variance": float(max(mos.variances(m_cap))), "max_variance_free": float(max(mos.variances(m_free))),
                   "cap_usage": [float(mos.ES[i] @ m_cap / caps[i]) for i in np.flatnonzero(np.isfinite(caps))],
-                  "note": "includes the unconstrained solve that finds the caps violated (MOSAP.solve does both); the caps are rows of the "
-                          "master problem's KKT system (bluest_master_newton_capped)"}
+                  "caps_method": mos.solver_info.get("caps", "first-order loop over the capped set (bluest_amd/capped.py)"),
+                  "note": "includes the unconstrained solve that finds the caps violated (MOSAP.solve does both); caps_method is the "
+                          "path enforce_sample_caps took: free solves under shifted costs first, rows of the master's KKT system second, "
+                          "the first-order loop third"}
         mos = None
     except Exception as err:      # the headline line must not depend on this leg
         capped = {"error": repr(err)[:300]}
@@ -178,6 +180,7 @@ def cpu_baseline(prob, seconds=14.0):
             kind, value = "reference", res["R"]
         except Exception as err:
             sys.stderr.write("cpu_baseline: reference leg unavailable (%s)\n" % err)
+    orc.select_strict()            # the checker's build again for whatever follows in this process
     return {"value": value, "unit": "Phi-assemblies/s", "cores": 1, "kind": kind,
             "sample": "output 0 of the n=%d,k_max=%d workload, variance+gradient evaluations repeated for ~%.0f s per leg on one core; "
                       "reference leg = numpy psi@m (1 BLAS thread) + numpy pinv + the reference's compiled gradK_c (bluest/misc.py:479-495)"

@@ -7,11 +7,14 @@ raises loudly if either is missing (there is no CPU fallback).
 """
 from ._lib import BluestHipError  # noqa: F401
 
-__all__ = ["SAP", "MOSAP", "BLUESTError", "BLUEProblem", "BluestHipError"]
+__all__ = ["blue_fn", "SAP", "MOSAP", "BLUESTError", "BLUEProblem", "BluestHipError"]
 
 
 def __getattr__(name):
     # lazy so that `import bluest_amd` (and bluest_amd.synth / .build) works without torch being imported
+    if name == "blue_fn":
+        from ._blue_fn import blue_fn
+        return blue_fn
     if name == "SAP":
         from .sap import SAP
         return SAP

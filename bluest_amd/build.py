@@ -30,8 +30,21 @@ def _inputs():
     return [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [HDR]
 
 
+STAMP = os.path.join(OBJDIR, "hipcc_flags.txt")      # the extra flags the library was built with: an experiment build is never "current"
+
+
+def _extra_flags():
+    return os.environ.get("BLUEST_EXTRA_HIPCC_FLAGS", "").split()
+
+
 def up_to_date():
-    return os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(f) for f in _inputs())
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in _inputs()):
+        return False
+    try:
+        built_with = open(STAMP).read().split()
+    except OSError:
+        built_with = []
+    return built_with == _extra_flags()
 
 
 SHIM_SRC = os.path.join(HERE, "csrc", "cmisc_shim.cpp")
@@ -65,7 +78,7 @@ def build(force=False, verbose=False):
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJDIR, exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-pthread", "-I" + os.path.join(ROOT, "include"),
-             "-I" + CSRC] + os.environ.get("BLUEST_EXTRA_HIPCC_FLAGS", "").split()
+             "-I" + CSRC] + _extra_flags()
 
     def compile_one(name):
         obj = os.path.join(OBJDIR, os.path.splitext(name)[0] + ".o")
@@ -81,6 +94,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(" ".join(_extra_flags()))
     build_shim(force=True, verbose=verbose)
     return LIB
 

@@ -14,7 +14,7 @@ import ctypes
 import numpy as np
 import torch
 
-from ._lib import check
+from ._lib import BluestHipError, check
 from .plan import EVAL_OK, _stream
 
 MASTER_OUT = 16            # layout of the master's result record (include/bluest_hip.h, bluest_master_newton)
@@ -197,15 +197,17 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
             for o_ in sharded.local_outputs:
                 own[np.asarray(o_["mapping"], dtype=np.int64)] = True
             xh = np.where(own, xh, 0.0)
-            top = np.argsort(-xh, kind="stable")[:S0]
+            mine = np.flatnonzero(own)                            # only owned entries travel (a rank with fewer than S0 groups
+            top = mine[np.argsort(-xh[mine], kind="stable")[:S0]]  # would otherwise offer indices it does not own, at value 0)
             parts = gather((top, xh[top]))
             idx_all = np.concatenate([p_[0] for p_ in parts])
             val_all = np.concatenate([p_[1] for p_ in parts])
             if not np.isfinite(val_all).all() or val_all.sum() <= 0.0:
                 return None, "multiplicative phase produced a non-finite iterate"
             order = np.lexsort((idx_all, -val_all))[:S0]       # largest first, ties by index: the same on every rank
-            keep = np.sort(idx_all[order])
-            xs = val_all[order][np.argsort(idx_all[order], kind="stable")]
+            order = order[val_all[order] > 0.0]                # the master wants a strictly ascending support of positive entries
+            keep, first = np.unique(idx_all[order], return_index=True)
+            xs = val_all[order][first]
             xs = xs / xs.sum()
         else:
             if not np.isfinite(xh).all() or xh.sum() <= 0.0:
@@ -244,14 +246,17 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
                 keep_h = np.ascontiguousarray(keep, dtype=np.int64)
                 cc_keep = np.ascontiguousarray(cc_h[keep])
                 mplan, msup = master_plan(keep_h)
-                if ncap:
-                    b_host = np.ascontiguousarray(b_eps)
-                    check(lib.bluest_master_newton_capped(mplan._h, S, msup.ctypes.data, cc_keep.ctypes.data, s_d.data_ptr(), bg_d.data_ptr(),
-                                                          float(eps), bufs.ptr("xs"), bufs.ptr("mu"), float(mtol), newton_maxit, bufs.ptr("out"),
-                                                          ncap, cap_models.ctypes.data, b_host.ctypes.data, nu_d.data_ptr(), st))
-                else:
-                    check(lib.bluest_master_newton(mplan._h, S, msup.ctypes.data, cc_keep.ctypes.data, s_d.data_ptr(), bg_d.data_ptr(), float(eps),
-                                                   bufs.ptr("xs"), bufs.ptr("mu"), float(mtol), newton_maxit, bufs.ptr("out"), st))
+                try:
+                    if ncap:
+                        b_host = np.ascontiguousarray(b_eps)
+                        check(lib.bluest_master_newton_capped(mplan._h, S, msup.ctypes.data, cc_keep.ctypes.data, s_d.data_ptr(), bg_d.data_ptr(),
+                                                              float(eps), bufs.ptr("xs"), bufs.ptr("mu"), float(mtol), newton_maxit, bufs.ptr("out"),
+                                                              ncap, cap_models.ctypes.data, b_host.ctypes.data, nu_d.data_ptr(), st))
+                    else:
+                        check(lib.bluest_master_newton(mplan._h, S, msup.ctypes.data, cc_keep.ctypes.data, s_d.data_ptr(), bg_d.data_ptr(), float(eps),
+                                                       bufs.ptr("xs"), bufs.ptr("mu"), float(mtol), newton_maxit, bufs.ptr("out"), st))
+                except BluestHipError as err:                     # e.g. the LDS attribute refused on this device: the caller falls back
+                    return None, "master launch failed (%s)" % err
                 sup_d[:S] = torch.from_numpy(keep_h)
                 check(lib.bluest_support_point(L, S, sup_d.data_ptr(), bufs.ptr("xs"), cc.data_ptr(), float(eps), m_d.data_ptr(), st))
                 evaluate(m_d, var_view)

@@ -918,7 +918,10 @@ __global__ __launch_bounds__(256) void k_support_point(int64_t L, int S, const i
     m[i] = cc[i] * ((1.0 - eps) * xi + eps / (double)L);
 }
 
-// pricing: c_i = cc_i sum_o (mu_o / s_o) q_{o,i} for every group; every workgroup reports its PRICE_TOP largest (value, index)
+// pricing: c_i = cc_i sum_o (mu_o / s_o) q_{o,i} for every group.  Every thread keeps the largest entry of its strided scan and
+// the workgroup reports the PRICE_TOP largest of those per-thread maxima (value, index): the first is the workgroup's true
+// maximum (all the bound needs), the others are candidates -- two of the true top 16 that fall on the same thread's stride
+// yield one candidate, the other enters in a later round.
 #define PRICE_TOP 16
 #define PRICE_BLOCKS 64
 __global__ __launch_bounds__(256) void k_price(int64_t L, int n_out, const double *__restrict__ grad, const int64_t *__restrict__ goff,
@@ -1148,10 +1151,11 @@ static int master_launch(bluest_plan_t plan, int S, const int64_t *support_host,
     // attribute (the kernel also has ~1 KB of static LDS: ask for what is needed, not for the whole limit)
 #define LAUNCH_MASTER(NT)                                                                                                     \
     do {                                                                                                                      \
-        static size_t granted = 0;                                                                                            \
-        if (lds > granted) {                                                                                                  \
+        static size_t granted[64] = {0};      /* per device: the attribute belongs to the device's copy of the kernel */      \
+        const int dv = (plan->device >= 0 && plan->device < 64) ? plan->device : 0;                                           \
+        if (lds > granted[dv] || dv != plan->device) {                                                                        \
             HIP_TRY(hipFuncSetAttribute((const void *)k_master_newton<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            granted = lds;                                                                                                    \
+            granted[dv] = lds;                                                                                                \
         }                                                                                                                     \
         hipLaunchKernelGGL((k_master_newton<NT>), dim3(1), dim3(MASTER_THREADS), lds, st, A);                                 \
     } while (0)

@@ -15,7 +15,7 @@ import torch
 from . import misc
 from .plan import EVAL_INF, EVAL_SINGULAR, Plan
 from .host import phase_clock
-from .sap import BLUESTError, LazyIndicators, SAP, SpgAllocator, restrict_plan, enforce_sample_caps, host_section, in_host_section, normalise_groups, status_to_python
+from .sap import BLUESTError, LazyIndicators, SAP, SpgAllocator, restrict_plan, enforce_sample_caps, host_section, in_host_section, normalise_groups, sample_cap_rows, status_to_python
 
 
 def _group_keys(gk, N):
@@ -388,18 +388,7 @@ class MOSAP(object):
 
     def get_max_sample_constraints(self, max_model_samples):
         """bluest/mosap.py:326-344"""
-        if max_model_samples is None:
-            return [], []
-        if not isinstance(max_model_samples, np.ndarray) or len(max_model_samples) != self.N:
-            raise ValueError("The maximum number of model samples must be prescribed as a numpy array of the same length as the number of models.")
-        if max_model_samples[0] < 1:
-            raise ValueError("The high-fidelity model must be sampled at least once.")
-        es, rhs = [], []
-        for i in range(self.N):
-            if np.isfinite(max_model_samples[i]):
-                es.append(self.ES[i])
-                rhs.append(int(np.round(max_model_samples[i])))
-        return es, rhs
+        return sample_cap_rows(self.ES, self.N, max_model_samples)
 
     @in_host_section
     def solve(self, budget=None, eps=None, solver="spg", x0=None, continuous_relaxation=False, max_model_samples=None,

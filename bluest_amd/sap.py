@@ -171,7 +171,8 @@ def enforce_sample_caps(plan, costs, es, rhs, samples, budget, eps, solver_param
                 return None
             return (float(B) / w_h) * xn, {"it": ninfo["newton_it"], "count": ninfo["full_evals"] + ninfo["master_evals"], "gpmax": ninfo["kkt"],
                                            "f": ninfo["F"], "solver_info": 0, "fevals": ninfo["full_evals"], "gevals": ninfo["full_evals"],
-                                           "pruned": int(len(xn) - ninfo["support"]), "method": "newton", "certified_gap": ninfo["gap"],
+                                           "pruned": int(len(xn) - ninfo["support"]), "method": "newton", "caps": "rows of the master's KKT system",
+                                           "certified_gap": ninfo["gap"],
                                            "rounds": ninfo["rounds"], "cap_usage": ninfo["cap_usage"], "multipliers": ninfo["mu"]}
     m, info = solve_capped(plan, costs, es, rhs, budget=budget, eps=eps, x0=clipped, prm=prm,
                            unconstrained_cost=float(np.asarray(costs) @ samples), budget_solver=budget_solver)
@@ -507,6 +508,51 @@ class SpgAllocator(object):
         return m.cpu().numpy()
 
 
+def estimator_rhs(N, K, cumsizes, groups, invcovs, sums, m):
+    """y = sum_i R_i^T C_i^-1 sums_i over the SAMPLED groups (bluest/sap.py:104-110; the reference walks all L groups in Python:
+    minutes at K_tot = 245505, the unsampled ones contribute invcov * 0).  Per group size the products C_i^-1 sums_i are one einsum
+    and the scatter into y one np.add.at; sums that are not plain numbers (user objects with + and *) take the generic accumulation.
+    Returns (y as an (N, ...) array or None, {model: accumulated object})."""
+    y_num, y_obj = None, {}
+    for k in range(1, K + 1):
+        hit = np.flatnonzero(m[cumsizes[k - 1]:cumsizes[k]] != 0)
+        if len(hit) == 0:
+            continue
+        members = np.asarray(groups[k - 1])[hit]                                       # (h, k) model indices
+        blocks = np.asarray(invcovs[k - 1]).reshape(-1, k, k)[hit]                    # (h, k, k)
+        mine = [sums[cumsizes[k - 1] + i] for i in hit.tolist()]
+        try:
+            vals = np.asarray(mine, dtype=np.float64)                                  # (h, k) or (h, k, ...) for array-valued outputs
+            numeric = vals.ndim >= 2 and vals.shape[:2] == members.shape
+        except (TypeError, ValueError):
+            numeric = False
+        if numeric:
+            contrib = np.einsum("hjs,hs...->hj...", blocks, vals)
+            if y_num is None:
+                y_num = np.zeros((N,) + contrib.shape[2:])
+            np.add.at(y_num, members, contrib)
+        else:
+            for g, blk, sm in zip(members.tolist(), blocks, mine):
+                for j, model in enumerate(g):
+                    for c, term in zip(blk[j].tolist(), sm):
+                        y_obj[model] = y_obj[model] + c * term if model in y_obj else c * term
+    return y_num, y_obj
+
+
+def sample_cap_rows(ES, N, max_model_samples):
+    """bluest/sap.py:222-240, bluest/mosap.py:326-344: (indicator rows ES[i], integer caps) of the models with a finite cap; the
+    argument is checked as the reference checks it (numpy array, one entry per model, model 0 may be sampled at least once)"""
+    if max_model_samples is None:
+        return [], []
+    caps = max_model_samples
+    if not isinstance(caps, np.ndarray) or len(caps) != N:
+        raise ValueError("max_model_samples must be a numpy array with one entry per model (%d); np.inf leaves a model uncapped" % N)
+    if caps[0] < 1:
+        raise ValueError("max_model_samples[0] < 1: the high-fidelity model needs at least one sample")
+    capped = np.flatnonzero(np.isfinite(caps))
+    return [ES[i] for i in capped], [int(np.round(caps[i])) for i in capped]
+
+
 class SAP(object):
     def __init__(self, C, K, groups, costs, verbose=True, device=None, max_candidates=1):
         """bluest/sap.py:53-97.  `groups` (list over k of lists of model tuples) is converted in place to int64
@@ -659,45 +705,27 @@ class SAP(object):
         return hess
 
     def compute_BLUE_estimator(self, sums, samples=None):
-        """bluest/sap.py:99-119 + bluest/misc.py:518-544 (PHIinvY0): y = sum_i R_i^T C_i^-1 sums_i (host: the sums may be
-        arbitrary user objects), mu = sum_j pinv(PHI[idx])[0,j] y_j with row 0 of the pseudo-inverse from the GPU solve"""
+        """bluest/sap.py:99-119 + bluest/misc.py:518-544 (PHIinvY0): y = sum_i R_i^T C_i^-1 sums_i (estimator_rhs, host), then
+        mu = sum_j pinv(PHI[idx])[0,j] y_j with row 0 of the pseudo-inverse from the GPU solve"""
         if samples is None: samples = self.samples
-        K, L, sizes, cumsizes, groups, invcovs = self.K, self.L, self.sizes, self.cumsizes, self.groups, self.invcovs
-        y = [0 for i in range(self.N)]
-        sums = [sums[cumsizes[k]:cumsizes[k + 1]] for k in range(K)]
         m = np.asarray(samples, dtype=np.float64)
-        for k in range(1, K + 1):
-            # only the sampled groups carry sums (the reference loops over all L groups in Python, sap.py:105-110: minutes at
-            # K_tot = 245505; their terms are invcov * 0)
-            for i in np.flatnonzero(m[cumsizes[k - 1]:cumsizes[k]] != 0).tolist():
-                for j in range(k):
-                    for s in range(k):
-                        y[groups[k - 1][i][j]] += invcovs[k - 1][k * k * i + k * j + s] * sums[k - 1][i][s]
+        y_num, y_obj = estimator_rhs(self.N, self.K, self.cumsizes, self.groups, self.invcovs, sums, m)
         if abs(m).max() < 0.05: return np.inf
         rec = self.plan.phi(m)
         var, v, status = self.plan.solve(rec)
         status_to_python(int(status[0, 0]), "compute_BLUE_estimator")
         v = v[0, 0].cpu().numpy()
         mu = 0
-        for j in range(self.N):
-            if v[j] != 0.0:
-                mu += v[j] * y[j]
+        for j in np.flatnonzero(v).tolist():
+            if y_num is not None:
+                mu = mu + v[j] * y_num[j]
+            if j in y_obj:
+                mu = mu + v[j] * y_obj[j]
         return mu, float(var[0, 0])
 
     def get_max_sample_constraints(self, max_model_samples):
         """bluest/sap.py:222-240"""
-        if max_model_samples is None:
-            return [], []
-        if not isinstance(max_model_samples, np.ndarray) or len(max_model_samples) != self.N:
-            raise ValueError("The maximum number of model samples must be prescribed as a numpy array of the same length as the number of models.")
-        if max_model_samples[0] < 1:
-            raise ValueError("The high-fidelity model must be sampled at least once.")
-        es, rhs = [], []
-        for i in range(self.N):
-            if np.isfinite(max_model_samples[i]):
-                es.append(self.ES[i])
-                rhs.append(int(np.round(max_model_samples[i])))
-        return es, rhs
+        return sample_cap_rows(self.ES, self.N, max_model_samples)
 
     @in_host_section
     def solve(self, budget=None, eps=None, solver="spg", x0=None, continuous_relaxation=False, max_model_samples=None,

@@ -2,7 +2,7 @@
 oracle/oracle.py -- numpy + plain-C restatement of the BLUEST sample-allocation hot path.
 
 TEST INFRASTRUCTURE ONLY.  Importable only from tests/, __graft_entry__.smoke() and bench.py's
-cpu_baseline leg; bluest_amd/ never imports it (tests/test_no_oracle_in_product.py enforces that).
+cpu_baseline leg; bluest_amd/ never imports it (tests/test_abi.py::test_product_never_touches_the_oracle enforces that).
 Parity status: PINNED by tests/golden/*.npz, generated from the real reference by oracle/gen_golden.py.
 
 Layers restated (paths relative to /root/reference/):
@@ -51,6 +51,14 @@ def select_fast_math():
     global _FAST, _LIB
     if not _FAST:
         _FAST, _LIB = True, None
+
+
+def select_strict():
+    """back to the strict-IEEE build after a timed leg (the FTZ/DAZ bits a fast-math object set at load time stay set for the
+    process; what this restores is WHICH object the wrappers call)"""
+    global _FAST, _LIB
+    if _FAST:
+        _FAST, _LIB = False, None
 
 
 def lib():

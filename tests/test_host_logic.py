@@ -217,3 +217,75 @@ def test_sample_caps_by_shifted_costs_on_a_separable_problem(monkeypatch):
     # caps that do not bind: the free optimum comes back after one solve
     m2, info2 = capped.cost_shift_capped(FakePlan(), w, np.ones(1), B, rows, 2.0 * m_free[capped_idx])
     assert info2["solves"] == 1 and np.allclose(m2, m_free, rtol=1e-12)
+
+
+def test_estimator_rhs_matches_the_group_by_group_accumulation():
+    """SAP.compute_BLUE_estimator's right-hand side y = sum_i R_i^T C_i^-1 sums_i (bluest/sap.py:104-110): the vectorised
+    accumulation (einsum + np.add.at per group size) against the plain quadruple loop, for scalar sums, array-valued sums and
+    sums that are opaque objects; unsampled groups contribute nothing."""
+    import itertools
+    from fractions import Fraction
+    from bluest_amd.sap import estimator_rhs
+    rng = np.random.RandomState(5)
+    N, K = 5, 3
+    groups = [np.array(list(itertools.combinations(range(N), k)), dtype=np.int64) for k in range(1, K + 1)]
+    sizes = [0] + [len(g) for g in groups]
+    cs = np.cumsum(sizes)
+    invcovs = [rng.randn(len(groups[k - 1]) * k * k) for k in range(1, K + 1)]
+    L = int(cs[-1])
+    m = np.where(rng.rand(L) < 0.6, rng.randint(1, 9, L), 0).astype(float)
+
+    def loop(sums):
+        y = [0.0] * N
+        for k in range(1, K + 1):
+            for i in range(sizes[k]):
+                if m[cs[k - 1] + i] == 0:
+                    continue
+                for j in range(k):
+                    for s in range(k):
+                        y[groups[k - 1][i][j]] = y[groups[k - 1][i][j]] + invcovs[k - 1][k * k * i + k * j + s] * sums[cs[k - 1] + i][s]
+        return y
+
+    flat_k = [k for k in range(1, K + 1) for _ in range(sizes[k])]
+    scalar = [list(rng.randn(k)) for k in flat_k]
+    y_num, y_obj = estimator_rhs(N, K, cs, groups, invcovs, scalar, m)
+    assert not y_obj and np.allclose(y_num, loop(scalar), rtol=1e-13, atol=1e-13)
+    vec = [[rng.randn(3) for _ in range(k)] for k in flat_k]
+    y_num, y_obj = estimator_rhs(N, K, cs, groups, invcovs, vec, m)
+    assert not y_obj and y_num.shape == (N, 3) and np.allclose(y_num, np.array(loop(vec)), rtol=1e-13, atol=1e-13)
+
+    class Opaque(object):                                   # a user object that only knows + and scalar *
+        def __init__(self, v): self.v = v
+        def __add__(self, o): return Opaque(self.v + o.v)
+        def __rmul__(self, c): return Opaque(c * self.v)
+    obj = [[Opaque(v) for v in row] for row in scalar]
+    y_num, y_obj = estimator_rhs(N, K, cs, groups, invcovs, obj, m)
+    assert y_num is None
+    ref = loop(scalar)
+    for j in range(N):
+        assert abs(y_obj[j].v - ref[j]) <= 1e-12 * max(1.0, abs(ref[j]))
+    assert Fraction(1, 2) + 0 == Fraction(1, 2)
+
+
+def test_blue_fn_sums_and_refusals():
+    """bluest_amd.blue_fn (role of bluest/blue_fn.py:36-211): sums of the outputs and of their pairwise inner products, the batched
+    sampler gives the same sums as one path at a time, a stated problem cost wins, the sample-file options are refused"""
+    import bluest_amd
+
+    class Problem(object):
+        def evaluate(self, ls, inputs):
+            return [[inputs[i] * (l + 1) for i, l in enumerate(ls)], [inputs[i] ** 2 + l for i, l in enumerate(ls)]]
+
+    ls = [0, 2]
+    se, sc, cost = bluest_amd.blue_fn(ls, 40, Problem(), No=2, verbose=False)
+    draws = np.random.RandomState(1).randn(40)
+    assert np.allclose(np.ravel(se[0]), [draws.sum(), 3 * draws.sum()])
+    assert np.allclose(sc[0], np.array([[1, 3], [3, 9]]) * (draws ** 2).sum())
+    assert np.allclose(np.ravel(se[1]), [(draws ** 2).sum(), (draws ** 2 + 2).sum()])
+    assert cost >= 0.0
+    se7, sc7, _ = bluest_amd.blue_fn(ls, 40, Problem(), No=2, N1=7, verbose=False)
+    assert np.allclose(np.ravel(se7[0]), np.ravel(se[0])) and np.allclose(sc7[1], sc[1])
+    Problem.cost = 2.5
+    assert bluest_amd.blue_fn(ls, 4, Problem(), No=2, verbose=False)[2] == 10.0
+    with pytest.raises(bluest_amd.BLUESTError):
+        bluest_amd.blue_fn(ls, 4, Problem(), No=2, filename="x.npz")

@@ -5,9 +5,9 @@
 #   usage: tools/ablate.sh out.txt "flags of variant 1" "flags of variant 2" ...
 out=$1; shift
 : > $out
+trap 'env -u BLUEST_EXTRA_HIPCC_FLAGS python -m bluest_amd.build --force > /dev/null 2>&1' EXIT     # product build back, whatever ends the script
 for v in "$@"; do
   BLUEST_EXTRA_HIPCC_FLAGS="$v" python -m bluest_amd.build --force > /dev/null 2>&1 || { echo "build '$v' failed" >> $out; continue; }
   echo "[$v] $(timeout -k 10 120 python tools/step_parts.py $ABLATE_ARGS 2>/dev/null | tail -1)" >> $out
 done
-python -m bluest_amd.build --force > /dev/null 2>&1
 cat $out

@@ -305,6 +305,22 @@ def eager_time(torch, fn, R=50, reps=7):
     return float(np.median(ts))
 
 
+def launch_ranks(n, argv):
+    """run this script as n ranks under torch.distributed.run (rendezvous on 127.0.0.1, a free port), stdout/stderr passed
+    through; returns the launcher's exit code"""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL and the peer-write mailboxes need it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -320,6 +336,11 @@ def main():
     ap.add_argument("--kmax", type=int, default=None)
     ap.add_argument("--n-out", type=int, default=None)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly (`python bench.py --gpus N`): this process becomes the launcher -- it starts the N ranks as a CHILD
+        # (torch.distributed.run, one process per GPU), relays rank 0's JSON line and exits with the child's code.  Nothing here has
+        # touched the GPU (torch is not even imported yet) and nothing is exec'ed.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -330,7 +351,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs the torch.distributed.run launcher with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but the launcher started %d ranks (--nproc-per-node must equal --gpus)" % (args.gpus, world))
     # BLUEST_BENCH_BACKEND=gloo + BLUEST_BENCH_SHARE_GPU=1: rehearsal of the N>1 path with all ranks on one GPU (RCCL refuses
     # two ranks per device); the driver's real runs use nccl = RCCL, one rank per GPU.
     backend = os.environ.get("BLUEST_BENCH_BACKEND", "nccl")
@@ -371,7 +392,8 @@ def main():
         plan = Plan(n, L, [build_outputs(prob)[o] for o in my_outputs], max_candidates=1, device=dev)
     else:
         from bluest_amd.dist import ShardedPlan
-        sharded = ShardedPlan(n, [len(g) for g in prob["groups"]], build_outputs(prob), max_candidates=1, device=dev)
+        sharded = ShardedPlan(n, [len(g) for g in prob["groups"]], build_outputs(prob), max_candidates=1 if args.no_batched else max(BATCHES),
+                              device=dev)
         plan = sharded.plan
     n_out = plan.n_out
 
@@ -494,6 +516,31 @@ def main():
                 "exchange_us": t_xchg * 1e6, "k_solve_grad_us(redundant solve + shard gradient)": t_sg * 1e6,
                 "exchange": {"algorithm": sharded.exchange_name, "bytes_per_rank_per_step": rec_bytes,
                              "doubles": int(n_out * plan.reclen)}}
+        if not args.no_batched:
+            # the batched sharded step (sharding pays once the candidate axis is batched across the exchange):
+            # nc allocation vectors per step, the partial records of all of them in ONE exchange of nc * n_out * reclen doubles,
+            # then nc redundant solves and the shard's gradients.  Collective: every rank runs it.
+            batched = {}
+            for nc in BATCHES:
+                rngb = np.random.RandomState(77 + nc)            # the same vectors on every rank
+                rings = [torch.from_numpy(10.0 * rngb.rand(nc, L)).to(dev) for _ in range(2)]
+                bv = torch.empty((nc, n_out), dtype=torch.float64, device=dev)
+                bgr = torch.empty((nc, plan.grad_len), dtype=torch.float64, device=dev)
+                bs = torch.empty((nc, n_out), dtype=torch.int32, device=dev)
+                brec = torch.empty((nc, n_out, plan.reclen), dtype=torch.float64, device=dev)
+                bstep = lambda i, rings=rings, bv=bv, bgr=bgr, bs=bs, brec=brec: sharded.eval(rings[i % 2], rec=brec, out=(bv, bgr, bs))   # noqa: E731
+                bst = Stepper(torch, bstep, 2, max(40, args.steps // nc), args.graph_steps, graphable and not args.no_graph, barrier, agree)
+                sec, rpt = bst.timed(max(4, args.warmup // nc))
+                sec = float(agree(sec))
+                assert bool((bs == 0).all())
+                t_bx = timer(torch, lambda brec=brec: sharded.reduce_records(brec))
+                t_bx = float(agree(t_bx))
+                batched["n_cand=%d" % nc] = {"value": nc * n_out_all / sec, "ms_per_step": sec * 1e3, "steps": bst.steps, "repeats": rpt,
+                                             "launch": bst.launch_label(), "exchange_us": t_bx * 1e6,
+                                             "exchange_bytes_per_rank_per_step": int(nc * n_out * plan.reclen * 8),
+                                             "exchanges_per_step": 1}
+            batched["note"] = ("group set sharded as in the headline step, nc allocation vectors per step with ONE exchange of the nc "
+                               "records; value = assemblies/s of the whole job (max over ranks)")
         # roofline of the shard's dominant streaming kernel: algorithmic bytes of the shard (1/world of the pass: shards are
         # balanced by sum k^2) over its launch time
         if t_sg >= t_chunks:

@@ -114,11 +114,23 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
     s = np.asarray(s, dtype=np.float64)
     s_max = master_max_support(plan)
     enter_per = int(prm.get("enter_per_round", N))
+    if n_out > 64:
+        return None, "more than 64 outputs"
     if s_max < min(L, N + 8):
         return None, "master problem does not fit one workgroup (support limit %d)" % s_max
 
     def to_dev(a, dtype=np.float64):
         return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(dev)
+
+    import time as _time
+    host_ms = {} if prm.get("profile") else None         # prm["profile"]: host wall-clock per segment of this function (info["host_ms"])
+    _last = [_time.perf_counter()]
+
+    def lap(name):
+        if host_ms is not None:
+            now = _time.perf_counter()
+            host_ms[name] = host_ms.get(name, 0.0) + (now - _last[0]) * 1e3
+            _last[0] = now
 
     cc_h = B / w
     cc, s_d = to_dev(cc_h), to_dev(s)
@@ -180,14 +192,16 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
         if x0 is not None:
             xh = (1.0 - 1.0e-3) * xh + 1.0e-3 / L                # the multiplicative update cannot leave a zero
         x_d, m_d = to_dev(xh), to_dev(cc_h * xh)
-        import time as _time
+        lap("background")
         _t_ma0 = _time.perf_counter()
         for _ in range(ma_its):
             evaluate(m_d, var)
             check(lib.bluest_ma_update(plan._h, var.data_ptr(), status.data_ptr(), grad.data_ptr(), s_d.data_ptr(), cc.data_ptr(), ma_p,
                                        x_d.data_ptr(), m_d.data_ptr(), st))
         info["full_evals"] += ma_its
+        lap("ma launches")
         xh = x_d.cpu().numpy()
+        lap("ma wait + fetch")
         info["t_ma_ms"] = (_time.perf_counter() - _t_ma0) * 1e3
         _t_r0 = _time.perf_counter()
         S0 = min(L, s_max, max(init_mult * N, N + 1))
@@ -214,8 +228,9 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
                 return None, "multiplicative phase produced a non-finite iterate"
             xh = np.maximum(xh, 0.0) / xh.sum()
             # ---- initial support: the largest entries -----------------------------------------------------------------------
-            keep = np.sort(np.argsort(-xh, kind="stable")[:S0])
-            xs = xh[keep] / xh[keep].sum()
+            keep = np.sort(np.argpartition(-xh, S0 - 1)[:S0] if S0 < L else np.arange(L))     # O(L) selection (a full sort of
+            xs = xh[keep] / xh[keep].sum()                                                       # 245505 entries costs 15-25 ms)
+        lap("initial support")
         mu = np.full(n_out, 1.0 / n_out)
         best_lb, F_last, gap, cert = 0.0, np.inf, np.inf, None
         x_full = None
@@ -246,6 +261,7 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
                 keep_h = np.ascontiguousarray(keep, dtype=np.int64)
                 cc_keep = np.ascontiguousarray(cc_h[keep])
                 mplan, msup = master_plan(keep_h)
+                lap("round: stage inputs")
                 try:
                     if ncap:
                         b_host = np.ascontiguousarray(b_eps)
@@ -257,6 +273,7 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
                                                        bufs.ptr("xs"), bufs.ptr("mu"), float(mtol), newton_maxit, bufs.ptr("out"), st))
                 except BluestHipError as err:                     # e.g. the LDS attribute refused on this device: the caller falls back
                     return None, "master launch failed (%s)" % err
+                lap("round: master launch")
                 sup_d[:S] = torch.from_numpy(keep_h)
                 check(lib.bluest_support_point(L, S, sup_d.data_ptr(), bufs.ptr("xs"), cc.data_ptr(), float(eps), m_d.data_ptr(), st))
                 evaluate(m_d, var_view)
@@ -267,7 +284,9 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
                 else:
                     check(lib.bluest_price(plan._h, grad.data_ptr(), bufs.ptr("mu"), s_d.data_ptr(), cc.data_ptr(), S, sup_d.data_ptr(),
                                            bufs.ptr("csup"), bufs.ptr("topv"), bufs.ptr("topi"), bufs.ptr("y0"), st))
+                lap("round: eval + price launches")
                 h = bufs.fetch()                                  # the round's only synchronisation
+                lap("round: wait + fetch")
                 nu_h = nu_d.cpu().numpy()[:ncap] if ncap else None
                 if sharded is not None:
                     # every rank priced its own groups: merge the candidates and the support's reduced costs (a rank reports 0
@@ -283,7 +302,7 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
                 info["full_evals"] += 1
                 info["master_solves"] = info.get("master_solves", 0) + int(out[6])
                 if out[10:16].any():                              # experiment build (-DMASTER_TIMING): per-phase microseconds
-                    info["master_phase_us"] = [a + b for a, b in zip(info.get("master_phase_us", [0.0] * 6), out[10:16])]
+                    info["master_phase_us"] = [a + b for a, b in zip(info.get("master_phase_us", [0.0] * 8), out[8:16])]
                 if int(out[7]) == 2 or not np.isfinite(out[0]):
                     return None, "master start not evaluable"
                 xs, mu = h["xs"][:S].copy(), h["mu"].copy()
@@ -318,6 +337,7 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
                         % (eps, rnd, F, gap, S, int(pos.sum()), int(out[4]), int(out[5]), len(enter), out[2], int(out[7])))
                 x_full = (keep[pos], xs[pos] / xs[pos].sum())
                 F_last = F
+                lap("round: host decisions")
                 nudge = 0.0
                 if int(out[7]) == 1 and int(out[4]) == 0 and rnd > 0:
                     # the master cannot move from here (stalled): pricing again would offer the same columns.  While the certified
@@ -343,6 +363,7 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
                 if gap <= gap_tol and stage == len(eps_list) - 1:
                     pass                                           # keep pricing until no column enters: cheap, and it lowers F
         # ---- polish on the final support without background (the function the reference evaluates) --------------------------
+        lap("round: host decisions")
         keep, xs = x_full
         S = len(keep)
         bufs.put("xs", xs)
@@ -385,6 +406,9 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
             if F_pol < F_true:
                 xs, mu, F_true = h["xs"][:S].copy(), h["mu"].copy(), F_pol
                 info["polished"] = True
+    lap("polish + final evaluations")
+    if host_ms is not None:
+        info["host_ms"] = {k_: round(v_, 3) for k_, v_ in host_ms.items()}
     if not np.isfinite(F_true):
         return None, "final allocation not evaluable"
     if 1.0 - best_lb / F_true > float(prm.get("give_up_gap", 1.0e-3)):

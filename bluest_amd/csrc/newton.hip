@@ -11,8 +11,12 @@
 // bluest/cmisc.cpp:74-97 (bluest/sap.py:387-456); there is no reference code to follow.
 #include "plan.hpp"     // brings solve.hpp: readlane_f64, wave_lds_sync
 
-#ifdef MASTER_TIMING      // experiment build only: per-phase wall-clock (100 MHz counter) of thread 0 accumulated into out[10..15]
-#define TSTAMP(k) do { __syncthreads(); if (threadIdx.x == 0) { const long long t_ = wall_clock64(); tacc[k] += t_ - tlast; tlast = t_; } } while (0)
+#ifdef MASTER_TIMING      // experiment build only: per-phase wall-clock (100 MHz counter) of thread 0, accumulated in L.scal[240..248] (as
+                          // 64-bit integers; slot 8 = the last stamp) and returned in out[8..15] -- the record's damping / multiplier
+                          // slots are overwritten, nothing on the host reads them.  Phases: 0 load, 1 Phi assembly, 2 elimination of the
+                          // evaluations, 3 active set + derivatives, 4 free set / step formation / bookkeeping, 5 Hessian, 6 elimination of
+                          // the Newton system, 7 K + the small KKT system
+#define TSTAMP(k) do { __syncthreads(); if (threadIdx.x == 0) { long long *tq_ = reinterpret_cast<long long *>(L.scal + 240); const long long t_ = wall_clock64(); tq_[k] += t_ - tq_[8]; tq_[8] = t_; } } while (0)
 #else
 #define TSTAMP(k)
 #endif
@@ -22,6 +26,7 @@
 #define MASTER_MCAP 4      // sample caps (max_model_samples rows) that can be in the step as equality rows at once
 #define MASTER_NE (MASTER_PACT + MASTER_MCAP + 1)      // columns of E: active outputs, active caps, the simplex row
 #define MASTER_OUT 16      // doubles in front of r[] in the result record
+#define MASTER_STATIC_LDS 2048   // room kept for the kernel's static LDS (the small KKT system: 1.5 KB) next to the dynamic part
 
 struct MasterArgs {
     int N, n_out, S, KM;               // models, outputs, support size (<= 64), largest group size in the support
@@ -44,30 +49,40 @@ struct MasterArgs {
     double *nu;                        // [ncap] out: cap multipliers (>= 0)
 };
 
+// register size of the per-output elimination: the matrix of an output is kept REVERSED (solve.hpp: position p = model NT-1-p,
+// row stride NT + 2) so that the DPP elimination of the evaluation reads its row as NT contiguous doubles; 0 = more than 32
+// models: natural layout, elimination out of LDS
+__host__ __device__ constexpr int master_nt(int N) { return N <= 12 ? 12 : N <= 20 ? 20 : N <= 26 ? 26 : N <= 32 ? 32 : 0; }
+__host__ __device__ constexpr int master_phi_doubles(int N) { return master_nt(N) ? master_nt(N) * (master_nt(N) + 2) : N * (N + 1); }
+
 struct MasterLds {                     // carved out of dynamic LDS by master_carve()
     double *PHI, *TACT, *BLK, *M, *AAC, *GQ;
     double *x, *xt, *d, *cc, *Dm, *glv, *mvec, *r, *rt, *mu, *muh, *scal, *capb, *capslack, *nu;
+    double *fcol;                      // [2][72]: multiplier column + pivot of the factorisation's current step (double-buffered)
     int *kk, *fi, *act, *istate, *capmodel, *actc;
     signed char *pos;
     unsigned char *idx;
     unsigned long long *memb;          // [N] bit j: support group j contains the model
-    int LDN, LDM, KE;
+    unsigned short *dl_off, *dl_ab, *dl_ent;   // destination lists of the Phi assembly: offsets [ND + 1], (a | b << 8) [ND], entries j | e << 7
+    int LDN, LDM, KE, ND, PHS;         // PHS: doubles per output in PHI
 };
 
 __host__ __device__ inline size_t master_lds_bytes(int N, int n_out, int S, int KM)
 {
-    const size_t LDN = N + 1, LDM = (S + MASTER_NE + 1) | 1, KE = (size_t)KM * (KM + 1) / 2;
-    size_t d = (size_t)n_out * N * LDN + (size_t)MASTER_PACT * N * LDN + (size_t)S * n_out * KE + (size_t)S * LDM +
-               (size_t)MASTER_PACT * S * KM + (size_t)S * MASTER_PACT + 7 * (size_t)S + 4 * (size_t)n_out + 256 + 3 * 64 + (size_t)N;
+    const size_t LDN = N + 1, LDM = (S + MASTER_NE + 1) | 1, KE = (size_t)KM * (KM + 1) / 2, ND = (size_t)N * (N + 1) / 2;
+    size_t d = (size_t)n_out * master_phi_doubles(N) + (size_t)MASTER_PACT * N * LDN + (size_t)S * n_out * KE + (size_t)S * LDM +
+               (size_t)MASTER_PACT * S * KM + (size_t)S * MASTER_PACT + 7 * (size_t)S + 4 * (size_t)n_out + 256 + 3 * 64 + (size_t)N + 2 * 72;
     size_t bytes = d * sizeof(double) + (3 * (size_t)S + 2 * MASTER_PACT + 48 + 64 + 2 * MASTER_MCAP) * sizeof(int) + (size_t)S * N + (size_t)S * KM + 64;
+    bytes = (bytes + 7) & ~(size_t)7;
+    bytes += (2 * ND + 2 + (size_t)S * KE + 8) * sizeof(unsigned short);
     return (bytes + 15) & ~(size_t)15;
 }
 
 __device__ inline void master_carve(MasterLds &L, unsigned char *base, int N, int n_out, int S, int KM)
 {
-    L.LDN = N + 1; L.LDM = (S + MASTER_NE + 1) | 1; L.KE = KM * (KM + 1) / 2;
+    L.LDN = N + 1; L.LDM = (S + MASTER_NE + 1) | 1; L.KE = KM * (KM + 1) / 2; L.ND = N * (N + 1) / 2; L.PHS = master_phi_doubles(N);
     double *p = reinterpret_cast<double *>(base);
-    L.PHI = p;  p += (size_t)n_out * N * L.LDN;
+    L.PHI = p;  p += (size_t)n_out * L.PHS;
     L.TACT = p; p += (size_t)MASTER_PACT * N * L.LDN;
     L.BLK = p;  p += (size_t)S * n_out * L.KE;
     L.M = p;    p += (size_t)S * L.LDM;
@@ -77,6 +92,7 @@ __device__ inline void master_carve(MasterLds &L, unsigned char *base, int N, in
     L.r = p; p += n_out; L.rt = p; p += n_out; L.mu = p; p += n_out; L.muh = p; p += n_out;
     L.scal = p; p += 256;
     L.capb = p; p += 64; L.capslack = p; p += 64; L.nu = p; p += 64;
+    L.fcol = p; p += 2 * 72;
     L.memb = reinterpret_cast<unsigned long long *>(p); p += N;
     int *q = reinterpret_cast<int *>(p);
     L.kk = q; q += S; L.fi = q; q += S; L.act = q; q += 2 * MASTER_PACT; L.istate = q; q += 48;      // act: current list, then the iteration's list (act0)
@@ -84,6 +100,11 @@ __device__ inline void master_carve(MasterLds &L, unsigned char *base, int N, in
     q += S;     // spare
     L.pos = reinterpret_cast<signed char *>(q);
     L.idx = reinterpret_cast<unsigned char *>(L.pos + (size_t)S * N);
+    size_t used = (size_t)((L.idx + (size_t)S * KM) - base);
+    used = (used + 7) & ~(size_t)7;
+    L.dl_off = reinterpret_cast<unsigned short *>(base + used);
+    L.dl_ab = L.dl_off + L.ND + 1;
+    L.dl_ent = L.dl_ab + L.ND + 1;
 }
 
 // scal[] slots
@@ -109,121 +130,220 @@ __device__ __forceinline__ double cap_a(const MasterArgs &A, const MasterLds &L,
 // packed symmetric index of (l, l2), l <= l2, in a k x k block
 __device__ __forceinline__ int sym_e(int l, int l2, int k) { return l * k - l * (l - 1) / 2 + (l2 - l); }
 
-// r[o] = V_o / s_o of the allocation with support vector xv (LDS) -- all threads.  Leaves T_o = Phi_o^-1 (on the touched
-// models, zero elsewhere) in L.PHI.  Fixed summation orders: the result is bit-reproducible (every rank of a sharded solve
-// runs this redundantly and must get the same bits).
-// in-place Gauss-Jordan inverse of the SPD matrix P (N x N, row stride LDN, LDS) by one wavefront, lane = row.
-// NT > 0: the row lives in NT registers, the pivot row is broadcast with v_readlane, everything is straight-line code (the
-// LDS version below serialises on LDS round trips: load - fma - store per column, ~3 us per pivot measured).  NT == 0: LDS.
+// address of entry (a, b) of one output's information matrix in L.PHI (reversed with stride NT + 2 for the register
+// eliminations, natural with stride N + 1 beyond 32 models)
 template <int NT>
-__device__ __forceinline__ bool inverse_wave(double *P, int N, int LDN, int lane)
+__device__ __forceinline__ int phi_idx(int a, int b, int LDN)
+{
+    if constexpr (NT > 0) return (NT - 1 - a) * (NT + 2) + (NT - 1 - b);
+    else return a * LDN + b;
+}
+
+// in-place Gauss-Jordan inverse of the SPD matrix P (N x N, row stride LDN, LDS, natural order) by one wavefront out of LDS,
+// lane = row: more than 32 models only (the register versions below serve the usual sizes).
+__device__ __forceinline__ bool inverse_wave_lds(double *P, int N, int LDN, int lane)
 {
     const bool mine = lane < N;
     bool bad = false;
-    if constexpr (NT > 0) {
-        double a[NT];
+    bool untouched = false;
+    if (mine && !(P[lane * LDN + lane] > 0.0)) { untouched = true; P[lane * LDN + lane] = 1.0; }
+    wave_lds_sync();
+    for (int p = 0; p < N; p++) {
+        const double piv = P[p * LDN + p];
+        if (!(piv > 0.0) || !isfinite(piv)) { bad = true; break; }            // wave-uniform (same address)
+        const double rinv = 1.0 / piv;
+        if (mine && lane != p) {
+            const double f = P[lane * LDN + p] * rinv;
+            for (int c0 = 0; c0 < N; c0 += 8) {                               // loads first, then the updates: 16 LDS reads in flight
+                double u[8], w[8];
 #pragma unroll
-        for (int c = 0; c < NT; c++) a[c] = (mine && c < N) ? P[lane * LDN + c] : ((c == lane) ? 1.0 : 0.0);
-        bool untouched = false;
+                for (int q = 0; q < 8; q++) { const int c = c0 + q < N ? c0 + q : N - 1; u[q] = P[p * LDN + c]; w[q] = P[lane * LDN + c]; }
 #pragma unroll
-        for (int c = 0; c < NT; c++) if (c == lane && mine && !(a[c] > 0.0)) { untouched = true; a[c] = 1.0; }
-#pragma unroll
-        for (int p = 0; p < NT; p++) {
-            const double piv = readlane_f64(a[p], p);
-            bad = bad || !(piv > 0.0) || !isfinite(piv);
-            const double rinv = 1.0 / piv;
-            const bool is = lane == p;
-            const double f = a[p] * rinv;
-#pragma unroll
-            for (int c = 0; c < NT; c++) {
-                if (c == p) continue;
-                const double u = readlane_f64(a[c], p);
-                a[c] = is ? u * rinv : fma(-f, u, a[c]);
+                for (int q = 0; q < 8; q++) if (c0 + q < N && c0 + q != p) P[lane * LDN + c0 + q] = fma(-f, u[q], w[q]);
             }
-            a[p] = is ? rinv : -f;
+            P[lane * LDN + p] = -f;
         }
-#pragma unroll
-        for (int c = 0; c < NT; c++) if (c == lane && untouched) a[c] = 0.0;
-        if (mine)
-#pragma unroll
-            for (int c = 0; c < NT; c++) if (c < N) P[lane * LDN + c] = a[c];
         wave_lds_sync();
-        return bad;
+        if (lane == p) {
+            for (int c = 0; c < N; c++)
+                if (c != p) P[p * LDN + c] *= rinv;
+            P[p * LDN + p] = rinv;
+        }
+        wave_lds_sync();
+    }
+    if (untouched) P[lane * LDN + lane] = 0.0;
+    wave_lds_sync();
+    return bad;
+}
+
+// T = P^-1 of one output by one wavefront, row `lane` (= model) in NT registers: P is read from the reversed layout of L.PHI and
+// left alone, T is written in natural order (row stride LDN) -- the matrix the Hessian and the gradients of an iteration are made
+// from.  Gauss-Jordan without pivoting.  Per step the pivot lane first scales its own row by 1/piv (one multiply per entry under
+// its EXEC mask), then every row takes a_c <- fma(g, u_c, a_c) with u_c the scaled pivot row's entry (v_readlane) and g = -a_p
+// (0 for the pivot lane, whose row is final), and a_p <- 1/piv or g / piv: four instructions per entry instead of a multiply, an fma
+// and two 64-bit selects.  (Folding the pivot row into the same fma as a + (1/piv - 1) a costs the low bits of 1/piv whenever the
+// pivot is large -- relative error eps * piv in T: the master then stalls at a KKT residual of 1e-8.)
+// A model no group of the support touches (no background) has a zero row: identity in, zero out.
+template <int NT>
+__device__ __forceinline__ bool inverse_regs(const double *P, double *T, int N, int LDN, int lane)
+{
+    static_assert(NT > 0, "register inverse");
+    constexpr int LDP = NT + 2;
+    const bool mine = lane < N;
+    double a[NT];
+    const double *row = P + (NT - 1 - (mine ? lane : 0)) * LDP;
+#pragma unroll
+    for (int c = 0; c < NT; c++) a[c] = (mine && c < N) ? row[NT - 1 - c] : ((c == lane) ? 1.0 : 0.0);
+    bool untouched = false;
+#pragma unroll
+    for (int c = 0; c < NT; c++) if (c == lane && mine && !(a[c] > 0.0)) { untouched = true; a[c] = 1.0; }
+    bool bad = false;
+#pragma unroll
+    for (int p = 0; p < NT; p++) {
+        const double piv = readlane_f64(a[p], p);
+        bad = bad || !(piv > 0.0) || !isfinite(piv);
+        const double rinv = rcp_f64(piv);
+        const bool is = lane == p;
+        if (is) {
+#pragma unroll
+            for (int c = 0; c < NT; c++) if (c != p) a[c] *= rinv;
+        }
+        const double g = is ? 0.0 : -a[p];
+        double u[NT];
+#pragma unroll
+        for (int c = 0; c < NT; c++) if (c != p) u[c] = readlane_f64(a[c], p);
+#pragma unroll
+        for (int c = 0; c < NT; c++) if (c != p) a[c] = fma(g, u[c], a[c]);
+        a[p] = is ? rinv : g * rinv;
+    }
+#pragma unroll
+    for (int c = 0; c < NT; c++) if (c == lane && untouched) a[c] = 0.0;
+    if (mine)
+#pragma unroll
+        for (int c = 0; c < NT; c++) if (c < N) T[lane * LDN + c] = a[c];
+    return bad;
+}
+
+// (P^-1)_00 of one output by one wavefront: the DPP elimination of the plan's solve (solve.hpp: gj_solve_last without the
+// solution vector), rows in registers, P (reversed layout) left alone.  Returns +inf when P is not positive definite.
+template <int NT>
+__device__ __forceinline__ double inv00_regs(const double *P, int N, int lane)
+{
+    static_assert(NT > 0, "register elimination");
+    using G = GjMap<NT>;
+    constexpr int LDP = NT + 2;
+    const int p = G::pos_of(lane);
+    const int model = NT - 1 - p;
+    const double *row = P + p * LDP;
+    double a[NT];
+#pragma unroll
+    for (int c = 0; c < NT; c += 2) {
+        const double2 x = *reinterpret_cast<const double2 *>(row + c);
+        a[c] = x.x; a[c + 1] = x.y;
+    }
+    // pads (models that do not exist) and models no group touches: identity row (their rows and columns are zero)
+    double diag0 = 1.0;
+    bool live = false;
+#pragma unroll
+    for (int c = 0; c < NT; c++) {
+        if (c == p) {
+            live = model < N && a[c] > 0.0;
+            a[c] = live ? a[c] : 1.0;
+            diag0 = a[c];
+        }
+    }
+    if (!((__ballot(live) >> G::lane_of(NT - 1)) & 1ull)) return INFINITY;      // model 0 itself is not sampled (wave-uniform)
+    double rinv_mine = 0.0, last_pivot = 1.0;
+    if constexpr (!G::dpp) {
+        int bad0 = 0;
+        gj_regs<NT>(a, lane, diag0, rinv_mine, last_pivot, bad0);
+        return (!bad0 && last_pivot > 0.0) ? 1.0 / last_pivot : INFINITY;
     } else {
-        bool untouched = false;
-        if (mine && !(P[lane * LDN + lane] > 0.0)) { untouched = true; P[lane * LDN + lane] = 1.0; }
-        wave_lds_sync();
-        for (int p = 0; p < N; p++) {
-            const double piv = P[p * LDN + p];
-            if (!(piv > 0.0) || !isfinite(piv)) { bad = true; break; }            // wave-uniform (same address)
-            const double rinv = 1.0 / piv;
-            if (mine && lane != p) {
-                const double f = P[lane * LDN + p] * rinv;
-                for (int c0 = 0; c0 < N; c0 += 8) {                               // loads first, then the updates: 16 LDS reads in flight
-                    double u[8], w[8];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) { const int c = c0 + q < N ? c0 + q : N - 1; u[q] = P[p * LDN + c]; w[q] = P[lane * LDN + c]; }
-#pragma unroll
-                    for (int q = 0; q < 8; q++) if (c0 + q < N && c0 + q != p) P[lane * LDN + c0 + q] = fma(-f, u[q], w[q]);
-                }
-                P[lane * LDN + p] = -f;
-            }
-            wave_lds_sync();
-            if (lane == p) {
-                for (int c = 0; c < N; c++)
-                    if (c != p) P[p * LDN + c] *= rinv;
-                P[p * LDN + p] = rinv;
-            }
-            wave_lds_sync();
-        }
-        if (untouched) P[lane * LDN + lane] = 0.0;
-        wave_lds_sync();
-        return bad;
+        asm volatile("s_nop 4" ::: "memory");
+        GjExtraStep<NT, 0>::run(a, lane, rinv_mine);
+        GjDppStep<NT, G::E>::run(a, lane, rinv_mine, last_pivot);
+        last_pivot = readlane_f64(last_pivot, 0);
+        const bool ok = rinv_mine > 0.0 && rinv_mine * (BLUEST_PIVOT_TOL * diag0) < 1.0;     // false for NaN as well
+        const bool bad = __ballot(!ok && lane < G::n_lanes) != 0ull || !isfinite(last_pivot) || !(last_pivot > 0.0);
+        return bad ? INFINITY : 1.0 / last_pivot;
     }
 }
 
+// r[o] = V_o / s_o of the allocation with support vector xv (LDS) -- all threads.  Leaves Phi_o in L.PHI (NT > 0: the matrix
+// itself, for inverse_regs; beyond 32 models T_o = Phi_o^-1 on the touched models, zero elsewhere).  Fixed summation orders: the
+// result is bit-reproducible (every rank of a sharded solve runs this redundantly and must get the same bits).
+// Assembly: every symmetric destination (a <= b) has the list of its contributions (support group, packed entry) made at load
+// time; EIGHT lanes share a destination -- lane q takes entries q, q + 8, .. for all outputs, an xor-butterfly over the eight
+// combines them -- so the destinations of model 0 (a member of nearly every group: lists as long as the support) cost eight
+// entries per lane instead of one dependent chain of 64 look-ups.
 template <int NT>
 __device__ void master_eval(const MasterArgs &A, MasterLds &L, const double *xv, double *rout, int tid)
 {
-    const int N = A.N, n_out = A.n_out, S = A.S, LDN = L.LDN, KE = L.KE;
+    const int N = A.N, n_out = A.n_out, S = A.S, LDN = L.LDN, KE = L.KE, ND = L.ND, PHS = L.PHS;
     const int wave = tid >> 6, lane = tid & 63, nw = MASTER_THREADS / 64;
+    // the background's share first: all its loads are in flight together (one memory round trip per evaluation; loaded where
+    // the sums are stored, every pass of the loop below waited for its own)
+    if (A.bg)
+        for (int t = tid; t < n_out * N * N; t += MASTER_THREADS) {
+            const int o = t / (N * N), rem = t - o * N * N;
+            L.PHI[(size_t)o * PHS + phi_idx<NT>(rem / N, rem % N, LDN)] = A.bg[t];
+        }
     for (int j = tid; j < S; j += MASTER_THREADS) L.mvec[j] = (1.0 - A.eps_bg) * L.cc[j] * xv[j];
     __syncthreads();
-    // one thread per destination (a, b) for ALL outputs: the membership / position look-ups are shared, the block reads of the
-    // outputs are independent loads; groups in ascending order (fixed summation order: bit-reproducible)
-    for (int t = tid; t < N * N; t += MASTER_THREADS) {
-        const int a = t / N, b = t % N;
+    const int sub = tid & 7;
+    for (int d0 = 0; d0 < ND; d0 += MASTER_THREADS / 8) {
+        const int d = d0 + (tid >> 3);
+        const bool valid = d < ND;
+        const int beg = valid ? L.dl_off[d] : 0, end = valid ? L.dl_off[d + 1] : 0;
+        const unsigned ab = valid ? L.dl_ab[d] : 0u;
+        const int a = (int)(ab & 0xffu), b = (int)(ab >> 8);
         for (int o0 = 0; o0 < n_out; o0 += 8) {
+            const int om = o0 + sub;                          // the output this lane stores
             double acc[8];
 #pragma unroll
-            for (int q = 0; q < 8; q++) acc[q] = (A.bg && o0 + q < n_out) ? A.bg[(size_t)(o0 + q) * N * N + t] : 0.0;
-            unsigned long long both = L.memb[a] & L.memb[b];      // support groups containing both models
-            while (both) {
-                const int j = __ffsll((long long)both) - 1;
-                both &= both - 1ull;
+            for (int q = 0; q < 8; q++) acc[q] = 0.0;
+            for (int i = beg + sub; i < end; i += 8) {
+                const unsigned ent = L.dl_ent[i];
+                const int j = (int)(ent & 127u), e = (int)(ent >> 7);
                 const double mj = L.mvec[j];
-                if (mj > 0.0) {
-                    const int pa = L.pos[j * N + a], pb = L.pos[j * N + b];
-                    const int lo = pa < pb ? pa : pb, hi = pa < pb ? pb : pa;
-                    const double *B = L.BLK + (size_t)j * n_out * KE + sym_e(lo, hi, L.kk[j]);
+                const double *B = L.BLK + (size_t)j * n_out * KE + e;
 #pragma unroll
-                    for (int q = 0; q < 8; q++) if (o0 + q < n_out) acc[q] = fma(mj, B[(size_t)(o0 + q) * KE], acc[q]);
+                for (int q = 0; q < 8; q++) if (o0 + q < n_out) acc[q] = fma(mj, B[(size_t)(o0 + q) * KE], acc[q]);
+            }
+            double mine = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (o0 + q < n_out) {                          // wave-uniform
+                    double v = acc[q];
+                    v += __shfl_xor(v, 1, WAVE);
+                    v += __shfl_xor(v, 2, WAVE);
+                    v += __shfl_xor(v, 4, WAVE);
+                    mine = (sub == q) ? v : mine;
                 }
             }
-#pragma unroll
-            for (int q = 0; q < 8; q++) if (o0 + q < n_out) L.PHI[((size_t)(o0 + q) * N + a) * LDN + b] = acc[q];
+            if (valid && om < n_out) {
+                double *P = L.PHI + (size_t)om * PHS;
+                const double v = A.bg ? mine + P[phi_idx<NT>(a, b, LDN)] : mine;
+                P[phi_idx<NT>(a, b, LDN)] = v;
+                P[phi_idx<NT>(b, a, LDN)] = v;
+            }
         }
     }
     __syncthreads();
+    TSTAMP(1);
     for (int o = wave; o < n_out; o += nw) {
-        double *P = L.PHI + (size_t)o * N * LDN;
-        const bool bad = inverse_wave<NT>(P, N, LDN, lane);
-        if (lane == 0) {
-            const double v00 = P[0];
-            rout[o] = (!bad && v00 > 0.0 && isfinite(v00)) ? v00 / A.s[o] : INFINITY;
+        double *P = L.PHI + (size_t)o * PHS;
+        double v00;
+        if constexpr (NT > 0) {
+            v00 = inv00_regs<NT>(P, N, lane);
+        } else {
+            const bool bad = inverse_wave_lds(P, N, LDN, lane);
+            v00 = bad ? INFINITY : P[0];
         }
+        if (lane == 0) rout[o] = (v00 > 0.0 && isfinite(v00)) ? v00 / A.s[o] : INFINITY;
     }
     __syncthreads();
+    TSTAMP(2);
 }
 
 // Hessian of the Lagrangian in reciprocal form + damping into M (free x free, compressed), E columns appended -- all threads
@@ -271,59 +391,108 @@ __device__ void master_build_system(const MasterArgs &A, MasterLds &L, int tid)
     __syncthreads();
 }
 
-// wave 0: Gauss-Jordan on [M | E] -> Y = M^-1 E (left in the E columns of M), K = E^T Y (L.scal[32..]).  L.istate[IS_OK]
-__device__ void master_factor_wave(const MasterArgs &A, MasterLds &L, int lane)
+// ALL wavefronts: Gauss-Jordan on [M | E] -> Y = M^-1 E (left in the E columns of M), K = E^T Y (L.scal[SCK..]), L.istate[IS_OK].
+// The matrix lives in REGISTERS, column-cyclic over the eight wavefronts (wavefront w holds columns w, w + 8, .. of M and of
+// E; lane = row), so a pivot step costs every wavefront one fma per live column with the pivot row's entry broadcast by
+// v_readlane -- out of LDS the same elimination by one wavefront moved 7 MB through the LDS pipe (24 us at 64 free variables).
+// Per step the owner of the pivot column publishes the multipliers a_ip / a_pp (and the pivot) through a double-buffered LDS
+// column and one workgroup barrier; the owner of the NEXT pivot column updates that column first and publishes it before it
+// touches its other columns, so its division overlaps the other wavefronts' updates.  Same operations in the same order per
+// entry as the single-wavefront version: bit-identical results.
+__device__ __forceinline__ void factor_publish(MasterLds &L, double col, int p, int nf, int lane)
 {
-    const int LDM = L.LDM;
+    const double piv = readlane_f64(col, p);
+    const double rinv = rcp_f64(piv);                     // (on the critical path of every pivot step: the IEEE division is ~4x longer)
+    double *fc = L.fcol + (p & 1) * 72;
+    fc[lane] = (lane == p || lane >= nf) ? 0.0 : col * rinv;
+    if (lane == 0) fc[64] = piv;
+}
+
+// pivot steps P, P + 1, .. of the elimination as straight-line code (static register indices); returns false when a pivot is not
+// positive (the same decision in every wavefront: all read the same published value)
+template <int P>
+struct FactorStep {
+    static __device__ __forceinline__ bool run(MasterLds &L, double (&am)[8], double (&ae)[2], double &mypiv, int nf, int ne, int wave, int lane)
+    {
+        if constexpr (P >= 64) return true;
+        else {
+            if (P >= nf) return true;
+            __syncthreads();
+            const double *fc = L.fcol + (P & 1) * 72;
+            const double f = fc[lane], piv = fc[64];
+            if (!(piv > 0.0) || !isfinite(piv)) return false;
+            mypiv = (lane == P) ? piv : mypiv;
+            constexpr int Q1 = (P + 1) >> 3;                                    // slot of the next pivot column
+            const bool ahead = (P + 1 < 64) && (P + 1 < nf) && wave == ((P + 1) & 7);
+            if constexpr (P + 1 < 64) {
+                if (ahead) {
+                    const double u = readlane_f64(am[Q1], P);
+                    am[Q1] = fma(-f, u, am[Q1]);
+                    factor_publish(L, am[Q1], P + 1, nf, lane);
+                }
+            }
+#pragma unroll
+            for (int q = P / 8; q < 8; q++) {                                   // slots below hold only columns behind the pivot
+                const int c = wave + 8 * q;
+                if (c > P && c < nf && !(ahead && c == P + 1)) {                // wave-uniform
+                    const double u = readlane_f64(am[q], P);
+                    am[q] = fma(-f, u, am[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                if (wave + 8 * q < ne) {
+                    const double u = readlane_f64(ae[q], P);
+                    ae[q] = fma(-f, u, ae[q]);
+                }
+            }
+            return FactorStep<P + 1>::run(L, am, ae, mypiv, nf, ne, wave, lane);
+        }
+    }
+};
+
+__device__ void master_factor_all(const MasterArgs &A, MasterLds &L, int tid)
+{
+    const int LDM = L.LDM, wave = tid >> 6, lane = tid & 63;
     const int nf = L.istate[IS_NF], nact = L.istate[IS_NACT], ncact = L.istate[IS_NCACT0];
     const int ne = nact + ncact + 1;
-    bool ok = true;
-    for (int p = 0; p < nf; p++) {
-        const double piv = L.M[p * LDM + p];
-        if (!(piv > 0.0) || !isfinite(piv)) { ok = false; break; }
-        const double rinv = 1.0 / piv;
-        if (lane < nf && lane != p) {
-            const double f = L.M[lane * LDM + p] * rinv;
-            const int cend = nf + ne;
-            for (int c0 = p + 1; c0 < cend; c0 += 8) {     // loads first, then the updates: 16 LDS reads in flight instead of a
-                double u[8], w[8];                         // load - fma - store round trip per column
+    const bool row = lane < nf;
+    double am[8], ae[2];
 #pragma unroll
-                for (int q = 0; q < 8; q++) { const int c = c0 + q < cend ? c0 + q : cend - 1; u[q] = L.M[p * LDM + c]; w[q] = L.M[lane * LDM + c]; }
+    for (int q = 0; q < 8; q++) { const int c = wave + 8 * q; am[q] = (row && c < nf) ? L.M[lane * LDM + c] : 0.0; }
 #pragma unroll
-                for (int q = 0; q < 8; q++) if (c0 + q < cend) L.M[lane * LDM + c0 + q] = fma(-f, u[q], w[q]);
-            }
-        }
-        wave_lds_sync();
+    for (int q = 0; q < 2; q++) { const int e = wave + 8 * q; ae[q] = (row && e < ne) ? L.M[lane * LDM + nf + e] : 0.0; }
+    double mypiv = 1.0;
+    if (wave == 0) factor_publish(L, am[0], 0, nf, lane);
+    const bool ok = FactorStep<0>::run(L, am, ae, mypiv, nf, ne, wave, lane);
+    TSTAMP(6);
+    __syncthreads();
+    if (!ok) { if (tid == 0) L.istate[IS_OK] = 0; __syncthreads(); return; }
+    const double dinv = row ? rcp_f64(mypiv) : 0.0;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int e = wave + 8 * q;
+        if (e < ne && row) L.M[lane * LDM + nf + e] = ae[q] * dinv;
     }
-    if (!ok) { if (lane == 0) L.istate[IS_OK] = 0; wave_lds_sync(); return; }
-    double Y[MASTER_NE], Eo[MASTER_NE];                    // static loop bounds + guards: the arrays stay in registers
-    const double dinv = lane < nf ? 1.0 / L.M[lane * LDM + lane] : 0.0;
-#pragma unroll
-    for (int e = 0; e < MASTER_NE; e++) {
-        Y[e] = 0.0; Eo[e] = 0.0;
-        if (e < ne && lane < nf) {
-            Y[e] = L.M[lane * LDM + nf + e] * dinv;
-            L.M[lane * LDM + nf + e] = Y[e];
-            Eo[e] = e < nact ? L.GQ[L.fi[lane] * MASTER_PACT + e]
-                  : (e < nact + ncact ? cap_a(A, L, L.actc[MASTER_MCAP + e - nact], L.fi[lane]) : 1.0);
+    __syncthreads();
+    for (int t = wave; t < ne * ne; t += MASTER_THREADS / 64) {            // K = E^T Y, one entry per wavefront and pass
+        const int e = t / ne, e2 = t % ne;
+        double eo = 0.0, y = 0.0;
+        if (row) {
+            eo = e < nact ? L.GQ[L.fi[lane] * MASTER_PACT + e]
+               : (e < nact + ncact ? cap_a(A, L, L.actc[MASTER_MCAP + e - nact], L.fi[lane]) : 1.0);
+            y = L.M[lane * LDM + nf + e2];
         }
+        const double k = wave_sum(eo * y);
+        if (lane == 0) L.scal[SCK + e * MASTER_NE + e2] = k;
     }
-#pragma unroll
-    for (int e = 0; e < MASTER_NE; e++)
-#pragma unroll
-        for (int e2 = 0; e2 < MASTER_NE; e2++) {
-            if (e < ne && e2 < ne) {                       // wave-uniform
-                const double k = wave_sum(Eo[e] * Y[e2]);
-                if (lane == 0) L.scal[SCK + e * MASTER_NE + e2] = k;
-            }
-        }
-    if (lane == 0) {
+    if (tid == 0) {
         L.istate[IS_OK] = 1;
         for (int e = 0; e < MASTER_PACT; e++) L.istate[IS_ALIVE + e] = e < nact;
         for (int e = 0; e < MASTER_MCAP; e++) { L.istate[IS_CALIVE + e] = e < ncact; L.istate[IS_CLOCK + e] = 0; }
         for (int e = 0; e < MASTER_PACT; e++) L.istate[IS_OLOCK + e] = 0;
     }
-    wave_lds_sync();
+    __syncthreads();
 }
 
 // wave 0: the small KKT system over the alive outputs (p), alive caps (pc), the simplex row and tau:
@@ -331,14 +500,14 @@ __device__ void master_factor_wave(const MasterArgs &A, MasterLds &L, int lane)
 // then the step out_j = -Y z on the free rows.  soc = false: the SQP step (rhs_q = q at x, rhs_c = -(b_c - a_c.x), rhs_sum = 1):
 // outputs / caps whose multiplier comes out negative leave the alive sets; a cap AT its bound that was dropped comes back (and
 // stays) if the step would violate it; multipliers / lam / tau are published.  soc = true: the second-order correction (rhs_q = q
-// at the trial point, rhs_c = 0, rhs_sum = 0) with the alive sets as the step left them.  The (<= 10 x 10) system is eliminated
-// by lane 0 out of LDS (run-time indexed private arrays would live in scratch memory); results are broadcast through LDS.
+// at the trial point, rhs_c = 0, rhs_sum = 0) with the alive sets as the step left them.  The (<= 12 x 12) system is eliminated
+// with one row per lane in registers; results are broadcast through LDS.
 __device__ void master_small_solve(const MasterArgs &A, MasterLds &L, int lane, bool soc, double *outvec)
 {
-    constexpr int NU = MASTER_PACT + MASTER_MCAP + 2, W = NU + 1;
-    __shared__ double Am[NU * W];
+    constexpr int NU = MASTER_PACT + MASTER_MCAP + 2;
+    __shared__ double sol[NU];
     __shared__ double zf[MASTER_PACT], nuf[MASTER_MCAP], zlt[2];      // multipliers (act0 / actc0 order), lam, tau
-    __shared__ int alive[MASTER_PACT], olock[MASTER_PACT], calive[MASTER_MCAP], clock[MASTER_MCAP], map[NU], okflag, redo;
+    __shared__ int alive[MASTER_PACT], olock[MASTER_PACT], calive[MASTER_MCAP], clock[MASTER_MCAP], map[NU], dims[2], okflag, redo;
     const int S = A.S, LDM = L.LDM;
     const int nf = L.istate[IS_NF], nact = L.istate[IS_NACT], ncact = L.istate[IS_NCACT0];
     if (lane == 0) {
@@ -352,50 +521,85 @@ __device__ void master_small_solve(const MasterArgs &A, MasterLds &L, int lane, 
             for (int e = 0; e < nact; e++) if (alive[e]) map[p++] = e;
             for (int e = 0; e < ncact; e++) if (calive[e]) map[p + pc++] = nact + e;
             map[p + pc] = nact + ncact;                                      // the simplex column of K
-            const int nk = p + pc + 1, n = nk + 1;
-            for (int a = 0; a < n; a++) for (int b = 0; b <= n; b++) Am[a * W + b] = 0.0;
-            for (int a = 0; a < nk; a++)
-                for (int b = 0; b < nk; b++) Am[a * W + b] = L.scal[SCK + map[a] * MASTER_NE + map[b]];
-            for (int a = 0; a < p; a++) { Am[a * W + nk] = 1.0; Am[nk * W + a] = 1.0; Am[a * W + n] = L.scal[(soc ? SQT : SQ) + map[a]]; }
-            for (int a = 0; a < pc; a++) Am[(p + a) * W + n] = soc ? 0.0 : -L.capslack[L.actc[MASTER_MCAP + map[p + a] - nact]];
-            Am[nk * W + n] = soc ? 0.0 : 1.0;
-            bool sing = false;                                               // Gaussian elimination with partial pivoting
-            for (int c = 0; c < n; c++) {
-                int pr = c; double best = fabs(Am[c * W + c]);
-                for (int rr = c + 1; rr < n; rr++) if (fabs(Am[rr * W + c]) > best) { best = fabs(Am[rr * W + c]); pr = rr; }
-                if (!(best > 0.0)) { sing = true; break; }
-                if (pr != c) for (int b = 0; b <= n; b++) { const double t = Am[c * W + b]; Am[c * W + b] = Am[pr * W + b]; Am[pr * W + b] = t; }
-                const double ri = 1.0 / Am[c * W + c];
-                for (int rr = 0; rr < n; rr++) {
-                    if (rr == c) continue;
-                    const double f = Am[rr * W + c] * ri;
-                    if (f != 0.0) for (int b = c; b <= n; b++) Am[rr * W + b] -= f * Am[c * W + b];
+            dims[0] = p; dims[1] = pc;
+        }
+        wave_lds_sync();
+        {
+            // the (p + pc + 2)-square system, ONE ROW PER LANE in registers: Gauss-Jordan with partial pivoting -- the pivot row is the
+            // unpivoted lane with the largest entry of the column (wave argmax, ties to the lower lane) and is broadcast with
+            // v_readlane; rows are never swapped, a lane remembers the column it pivoted.  (One lane eliminating out of LDS paid a
+            // memory round trip per entry: ~9 us per Newton system.)
+            const int p = dims[0], pc = dims[1], nk = p + pc + 1, n = nk + 1;
+            const bool rowin = lane < n;
+            double r[NU], rhs = 0.0;
+#pragma unroll
+            for (int bq = 0; bq < NU; bq++) {
+                double v = 0.0;
+                if (rowin && bq < n) {
+                    if (lane < nk && bq < nk) v = L.scal[SCK + map[lane] * MASTER_NE + map[bq]];
+                    else if ((lane < p && bq == nk) || (lane == nk && bq < p)) v = 1.0;
+                }
+                r[bq] = v;
+            }
+            if (lane < p) rhs = L.scal[(soc ? SQT : SQ) + map[lane]];
+            else if (lane < p + pc) rhs = soc ? 0.0 : -L.capslack[L.actc[MASTER_MCAP + map[lane] - nact]];
+            else if (lane == nk) rhs = soc ? 0.0 : 1.0;
+            bool pivoted = !rowin;                                           // lanes without a row never pivot
+            int mycol = -1;
+            double mydiag = 1.0;
+            bool sing = false;
+#pragma unroll
+            for (int c = 0; c < NU; c++) {
+                if (c < n && !sing) {                                        // wave-uniform
+                    double best = pivoted ? -1.0 : fabs(r[c]);
+                    int who = lane;
+#pragma unroll
+                    for (int off = 1; off < 16; off <<= 1) {                 // rows live in lanes 0..11
+                        const double b2 = __shfl_xor(best, off, WAVE);
+                        const int w2 = __shfl_xor(who, off, WAVE);
+                        if (b2 > best || (b2 == best && w2 < who)) { best = b2; who = w2; }
+                    }
+                    best = __shfl(best, 0, WAVE); who = __shfl(who, 0, WAVE);
+                    if (!(best > 0.0)) { sing = true; }
+                    else {
+                        const int pr = __builtin_amdgcn_readfirstlane(who);
+                        const double pvc = readlane_f64(r[c], pr);
+                        const double f = (lane == pr) ? 0.0 : r[c] / pvc;
+#pragma unroll
+                        for (int bq = 0; bq < NU; bq++)
+                            if (bq >= c && bq < n) r[bq] = fma(-f, readlane_f64(r[bq], pr), r[bq]);
+                        rhs = fma(-f, readlane_f64(rhs, pr), rhs);
+                        if (lane == pr) { pivoted = true; mycol = c; mydiag = pvc; }
+                    }
                 }
             }
-            okflag = sing ? 0 : 1;
+            if (!sing && mycol >= 0) sol[mycol] = rhs / mydiag;
+            if (lane == 0) okflag = sing ? 0 : 1;
+        }
+        wave_lds_sync();
+        if (lane == 0 && okflag) {
+            const int p = dims[0], pc = dims[1], nk = p + pc + 1;
             redo = 0;
-            if (!sing) {
-                int worst = -1; double wv = -1.0e-12;
-                if (!soc && p > 1)
-                    for (int a = 0; a < p; a++) { const double za = Am[a * W + n] / Am[a * W + a]; if (za < wv && !olock[map[a]]) { wv = za; worst = a; } }
-                if (worst >= 0) { alive[map[worst]] = 0; redo = 1; }
-                else if (!soc) {                                             // most negative droppable cap multiplier
-                    int wc = -1; double wcv = -1.0e-12;
-                    for (int a = 0; a < pc; a++) {
-                        const int ec = map[p + a] - nact;
-                        const double za = Am[(p + a) * W + n] / Am[(p + a) * W + p + a];
-                        if (za < wcv && !clock[ec]) { wcv = za; wc = ec; }
-                    }
-                    if (wc >= 0) { calive[wc] = 0; redo = 1; }
+            int worst = -1; double wv = -1.0e-12;
+            if (!soc && p > 1)
+                for (int a = 0; a < p; a++) { const double za = sol[a]; if (za < wv && !olock[map[a]]) { wv = za; worst = a; } }
+            if (worst >= 0) { alive[map[worst]] = 0; redo = 1; }
+            else if (!soc) {                                             // most negative droppable cap multiplier
+                int wc = -1; double wcv = -1.0e-12;
+                for (int a = 0; a < pc; a++) {
+                    const int ec = map[p + a] - nact;
+                    const double za = sol[p + a];
+                    if (za < wcv && !clock[ec]) { wcv = za; wc = ec; }
                 }
-                if (!redo) {
-                    for (int e = 0; e < MASTER_PACT; e++) zf[e] = 0.0;
-                    for (int e = 0; e < MASTER_MCAP; e++) nuf[e] = 0.0;
-                    for (int a = 0; a < p; a++) zf[map[a]] = Am[a * W + n] / Am[a * W + a];
-                    for (int a = 0; a < pc; a++) nuf[map[p + a] - nact] = Am[(p + a) * W + n] / Am[(p + a) * W + p + a];
-                    zlt[0] = Am[(nk - 1) * W + n] / Am[(nk - 1) * W + nk - 1];
-                    zlt[1] = Am[nk * W + n] / Am[nk * W + nk];
-                }
+                if (wc >= 0) { calive[wc] = 0; redo = 1; }
+            }
+            if (!redo) {
+                for (int e = 0; e < MASTER_PACT; e++) zf[e] = 0.0;
+                for (int e = 0; e < MASTER_MCAP; e++) nuf[e] = 0.0;
+                for (int a = 0; a < p; a++) zf[map[a]] = sol[a];
+                for (int a = 0; a < pc; a++) nuf[map[p + a] - nact] = sol[p + a];
+                zlt[0] = sol[nk - 1];
+                zlt[1] = sol[nk];
             }
         }
         wave_lds_sync();
@@ -509,9 +713,6 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
     const int N = A.N, n_out = A.n_out, S = A.S, KM = A.KM;
     master_carve(L, master_sm, N, n_out, S, KM);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef MASTER_TIMING
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
-#endif
     const int LDN = L.LDN, KE = L.KE;
     // ---- load the support ---------------------------------------------------------------------------
     for (int j = tid; j < S; j += MASTER_THREADS) { L.kk[j] = A.kk[j]; L.cc[j] = A.cc[j]; const double v = A.x[j]; L.x[j] = v > 0.0 ? v : 0.0; }
@@ -520,17 +721,15 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
     for (int o = tid; o < n_out; o += MASTER_THREADS) L.mu[o] = A.mu[o];
     if (tid < 48) L.istate[tid] = 0;
     for (int t = tid; t < 256; t += MASTER_THREADS) L.scal[t] = 0.0;
+    for (int t = tid; t < n_out * L.PHS; t += MASTER_THREADS) L.PHI[t] = 0.0;      // pads of the reversed layout stay zero
     if (tid < 64) { L.capmodel[tid] = tid < A.ncap ? A.cap_model[tid] : 0; L.capb[tid] = tid < A.ncap ? A.cap_b[tid] : 0.0; L.nu[tid] = 0.0; L.capslack[tid] = 0.0; }
     __syncthreads();
+#ifdef MASTER_TIMING
+    if (tid == 0) reinterpret_cast<long long *>(L.scal + 240)[8] = wall_clock64();
+#endif
     for (int t = tid; t < S * KM; t += MASTER_THREADS) {
         const int j = t / KM, l = t % KM;
         if (l < L.kk[j]) L.pos[j * N + L.idx[t]] = (signed char)l;
-    }
-    for (int a = tid; a < N; a += MASTER_THREADS) {
-        unsigned long long mk = 0ull;
-        for (int j = 0; j < S; j++)
-            for (int l = 0; l < L.kk[j]; l++) if (L.idx[j * KM + l] == a) mk |= 1ull << j;
-        L.memb[a] = mk;
     }
     for (int t = tid; t < S * n_out * KE; t += MASTER_THREADS) {
         const int e = t % KE, o = (t / KE) % n_out, j = t / (KE * n_out);
@@ -546,6 +745,50 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
         }
         L.BLK[t] = v;
     }
+    // membership masks from the positions: lane = support group, one ballot per model
+    __syncthreads();
+    for (int a = wave; a < N; a += MASTER_THREADS / 64) {
+        const unsigned long long mk = __ballot(lane < S && L.pos[lane * N + a] >= 0);
+        if (lane == 0) L.memb[a] = mk;
+    }
+    // destination lists of the Phi assembly (master_eval): per symmetric destination (a <= b) the support groups containing both
+    // models with the packed entry (pos_a, pos_b) of their blocks, groups ascending
+    __syncthreads();
+    for (int t = tid; t < N * N; t += MASTER_THREADS) {
+        const int a = t / N, b = t % N;
+        if (a > b) continue;
+        const int d = a * N - a * (a - 1) / 2 + (b - a);
+        L.dl_off[d + 1] = (unsigned short)__popcll(L.memb[a] & L.memb[b]);
+        L.dl_ab[d] = (unsigned short)(a | (b << 8));
+    }
+    __syncthreads();
+    if (wave == 0) {   // offsets: inclusive scan of the counts, 64 destinations per pass
+        int run = 0;
+        for (int base = 0; base < L.ND; base += 64) {
+            const int d = base + lane;
+            int v = d < L.ND ? L.dl_off[d + 1] : 0;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int o2 = __shfl_up(v, off, WAVE); if (lane >= off) v += o2; }
+            if (d < L.ND) L.dl_off[d + 1] = (unsigned short)(run + v);
+            run += __shfl(v, 63, WAVE);
+        }
+        if (lane == 0) L.dl_off[0] = 0;
+    }
+    __syncthreads();
+    for (int t = tid; t < N * N; t += MASTER_THREADS) {
+        const int a = t / N, b = t % N;
+        if (a > b) continue;
+        const int d = a * N - a * (a - 1) / 2 + (b - a);
+        unsigned long long both = L.memb[a] & L.memb[b];
+        int o = L.dl_off[d];
+        while (both) {
+            const int j = __ffsll((long long)both) - 1;
+            both &= both - 1ull;
+            const int pa = L.pos[j * N + a], pb = L.pos[j * N + b];
+            const int lo = pa < pb ? pa : pb, hi = pa < pb ? pb : pa;
+            L.dl_ent[o++] = (unsigned short)(j | (sym_e(lo, hi, L.kk[j]) << 7));
+        }
+    }
     if (wave == 0) {   // normalise the start
         double sx = 0.0;
         for (int j = lane; j < S; j += 64) sx += L.x[j];
@@ -556,7 +799,6 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
     __syncthreads();
     TSTAMP(0);                                          // 0: load
     master_eval<NT>(A, L, L.x, L.r, tid);
-    TSTAMP(1);                                          // 1: evaluations
     if (tid == 0) {
         L.istate[IS_EVALS] = 1;
         double F = 0.0;
@@ -597,42 +839,44 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
             }
             __syncthreads();
         }
-        // ---- active outputs and their curvature weights (thread 0) -------------------------------------
-        if (tid == 0) {
+        // ---- active outputs and their curvature weights (wavefront 0, lane = output) --------------------
+        if (wave == 0) {
             const double F = L.scal[SC_F];
-            int nact = 0;
+            const bool in = lane < n_out;
+            const double ro = in ? L.r[lane] : 0.0, muo = in ? L.mu[lane] : 0.0;
             // candidates: within act_tol of the maximum, or carrying a multiplier; the MASTER_PACT largest r (ties: smaller index)
-            for (int o = 0; o < n_out; o++) L.muh[o] = 0.0;
-            for (int pick = 0; pick < MASTER_PACT; pick++) {
-                int best = -1;
-                for (int o = 0; o < n_out; o++) {
-                    bool taken = false;
-                    for (int q = 0; q < nact; q++) if (L.act[q] == o) taken = true;
-                    if (taken) continue;
-                    if (!((L.r[o] >= F * (1.0 - A.act_tol)) || (L.mu[o] > 1.0e-12))) continue;
-                    if (best < 0 || L.r[o] > L.r[best]) best = o;
-                }
-                if (best < 0) break;
-                L.act[nact++] = best;
+            const bool cand = in && ((ro >= F * (1.0 - A.act_tol)) || (muo > 1.0e-12));
+            const unsigned long long cmask = __ballot(cand);
+            int rank = 0;
+            for (int o2 = 0; o2 < n_out; o2++) {
+                const double r2 = __shfl(ro, o2, WAVE);
+                if (((cmask >> o2) & 1ull) && (r2 > ro || (r2 == ro && o2 < lane))) rank++;
             }
-            // ascending output order (deterministic, matches the restatement)
-            for (int a = 0; a < nact; a++) for (int b = a + 1; b < nact; b++) if (L.act[b] < L.act[a]) { const int t = L.act[a]; L.act[a] = L.act[b]; L.act[b] = t; }
-            double tot = 0.0;
-            for (int a = 0; a < nact; a++) { const double m_o = L.mu[L.act[a]] > 0.0 ? L.mu[L.act[a]] : 0.0; L.muh[L.act[a]] = m_o; tot += m_o; }
-            for (int a = 0; a < nact; a++) L.muh[L.act[a]] = tot > 0.0 ? L.muh[L.act[a]] / tot : 1.0 / nact;
-            tot = 0.0;
-            for (int a = 0; a < nact; a++) { L.muh[L.act[a]] = fmax(L.muh[L.act[a]], 1.0e-3 / nact); tot += L.muh[L.act[a]]; }
-            for (int a = 0; a < nact; a++) L.muh[L.act[a]] /= tot;
-            for (int a = 0; a < nact; a++) L.act[a + MASTER_PACT] = L.act[a];      // act0: the iteration's set (GQ / TACT / AAC order)
-            L.istate[IS_NACT] = nact; L.istate[IS_NACT0] = nact;
+            const bool sel = cand && rank < MASTER_PACT;
+            const unsigned long long smask = __ballot(sel);
+            const int nact = __popcll(smask);
+            const int slot = __popcll(smask & ((1ull << lane) - 1ull));          // ascending output order (matches the restatement)
+            if (sel) { L.act[slot] = lane; L.act[slot + MASTER_PACT] = lane; }   // act0 behind the list: the iteration's set (GQ / TACT / AAC order)
+            const double m_o = sel ? (muo > 0.0 ? muo : 0.0) : 0.0;
+            double tot = wave_sum(m_o);
+            double wgt = sel ? (tot > 0.0 ? m_o / tot : 1.0 / nact) : 0.0;
+            wgt = sel ? fmax(wgt, 1.0e-3 / nact) : 0.0;
+            tot = wave_sum(wgt);
+            if (in) L.muh[lane] = sel ? wgt / tot : 0.0;
+            if (lane == 0) { L.istate[IS_NACT] = nact; L.istate[IS_NACT0] = nact; }
         }
         __syncthreads();
         // ---- derivatives at x: T (kept for the active outputs), a_{o,j}, gradients in reciprocal form ---------------
         // T_o = Phi_o^-1 of the current x is in L.PHI: left there by the initial evaluation or by the accepted trial evaluation
         const int nact0 = L.istate[IS_NACT0];
-        for (int t = tid; t < nact0 * N * LDN; t += MASTER_THREADS) {
-            const int a = t / (N * LDN);
-            L.TACT[t] = L.PHI[(size_t)L.act[a + MASTER_PACT] * N * LDN + (t - a * N * LDN)];
+        if constexpr (NT > 0) {     // L.PHI holds Phi_o(x): one wavefront per active output inverts it in registers
+            for (int a = wave; a < nact0; a += MASTER_THREADS / 64)
+                (void)inverse_regs<NT>(L.PHI + (size_t)L.act[a + MASTER_PACT] * L.PHS, L.TACT + (size_t)a * N * LDN, N, LDN, lane);
+        } else {                    // L.PHI holds T_o already (inverted in place by the evaluation)
+            for (int t = tid; t < nact0 * N * LDN; t += MASTER_THREADS) {
+                const int a = t / (N * LDN);
+                L.TACT[t] = L.PHI[(size_t)L.act[a + MASTER_PACT] * L.PHS + (t - a * N * LDN)];
+            }
         }
         __syncthreads();
         for (int t = tid; t < nact0 * S * KM; t += MASTER_THREADS) {
@@ -666,7 +910,7 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
             L.scal[SC_QMAX] = qm;
         }
         __syncthreads();
-        TSTAMP(2);                                      // 2: active set + derivatives
+        TSTAMP(3);                                      // 3: active set + derivatives
         if (wave == 0) {   // reduced costs with the curvature weights -> free set
             double part = 0.0;
             for (int j = lane; j < S; j += 64) {
@@ -691,20 +935,21 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
         __syncthreads();
         // ---- damped attempts -------------------------------------------------------------------------------------
         bool converged = false;
+        double pred0 = -INFINITY;                // decrease the model promised at the iteration's first attempt
         for (int attempt = 0; attempt < 40; attempt++) {
             if (tid == 0) L.istate[IS_NACT] = L.istate[IS_NACT0];
             if (tid < MASTER_PACT) L.act[tid] = L.act[tid + MASTER_PACT];
             __syncthreads();
-            TSTAMP(3);                                  // 3: free set, KKT bookkeeping, step formation
+            TSTAMP(4);                                  // 4: free set, KKT bookkeeping, step formation
             master_build_system(A, L, tid);
-            TSTAMP(4);                                  // 4: Hessian / system assembly
+            TSTAMP(5);                                  // 5: Hessian / system assembly
+            master_factor_all(A, L, tid);
             if (wave == 0) {
-                master_factor_wave(A, L, lane);
                 if (L.istate[IS_OK]) master_small_solve(A, L, lane, false, L.d);
                 if (lane == 0) L.istate[IS_SOLVES] += 1;
             }
             __syncthreads();
-            TSTAMP(5);                                  // 5: factorisation + small system
+            TSTAMP(7);                                  // 7: K + small system
             if (!L.istate[IS_OK]) {              // M not positive definite (or singular small system): more damping
                 __syncthreads();
                 if (tid == 0) L.scal[SC_DAMP] *= 10.0;
@@ -744,6 +989,7 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
             if (attempt == 0 && L.scal[SC_KKT] <= A.tol && L.scal[SC_SPREAD] <= A.tol) { converged = true; break; }
             const double F = L.scal[SC_F];
             const double pred = (L.scal[SC_TAU] - L.scal[SC_QMAX]) * F * F;
+            if (attempt == 0) pred0 = pred;
             if (pred < -0.5 * F) {               // the model promises more than half of a positive objective: shorter step
                 __syncthreads();
                 if (tid == 0) L.scal[SC_DAMP] *= 10.0;
@@ -764,9 +1010,8 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
                 if (A.ncap > 0) { wave_lds_sync(); master_cap_feasible(A, L, lane); }
             }
             __syncthreads();
-            TSTAMP(3);
+            TSTAMP(4);
             master_eval<NT>(A, L, L.xt, L.rt, tid);
-            TSTAMP(1);
             // acceptance; near a tie of several outputs second-order errors split the tie and the exact max rejects a good SQP
             // step (the Maratos effect): one second-order correction -- the minimum-norm (in M) step c that re-equalises the
             // alive outputs at the trial point to first order, same K, another right-hand side -- gets a second evaluation
@@ -830,7 +1075,16 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
             }
         }
         if (converged) { if (tid == 0) L.istate[IS_DONE] = 1; __syncthreads(); break; }
-        if (!L.istate[IS_ACCEPT]) { if (tid == 0) { L.istate[IS_DONE] = 1; L.istate[IS_STATUS] = 1; } __syncthreads(); break; }   // stalled
+        if (!L.istate[IS_ACCEPT]) {
+            // no step was accepted.  If even the first attempt's model promised less than the objective can resolve (1e-12 F) at a KKT
+            // residual of 1e-6 or better, the rejections are rounding noise of the evaluations: this IS the optimum to working precision
+            // (status 0); otherwise the master stalled (status 1)
+            const bool resolved = L.scal[SC_KKT] <= 1.0e-6 && L.scal[SC_SPREAD] <= 1.0e-6 && pred0 > -1.0e-12 * L.scal[SC_F];
+            __syncthreads();
+            if (tid == 0) { L.istate[IS_DONE] = 1; L.istate[IS_STATUS] = resolved ? 0 : 1; }
+            __syncthreads();
+            break;
+        }
         for (int j = tid; j < S; j += MASTER_THREADS) L.x[j] = L.xt[j];
         for (int o = tid; o < n_out; o += MASTER_THREADS) L.r[o] = L.rt[o];
         if (tid == 0) { L.scal[SC_F] = L.scal[SC_FT]; L.istate[IS_IT] = it + 1; if (L.istate[IS_TINY] >= 2) L.istate[IS_DONE] = 1; }
@@ -846,7 +1100,7 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
         A.out[4] = L.istate[IS_IT]; A.out[5] = L.istate[IS_EVALS]; A.out[6] = L.istate[IS_SOLVES]; A.out[7] = L.istate[IS_STATUS];
         A.out[8] = L.scal[SC_DAMP]; A.out[9] = L.scal[SC_LAMX];
 #ifdef MASTER_TIMING
-        for (int k = 0; k < 6; k++) A.out[10 + k] = (double)tacc[k] * 0.01;      // microseconds
+        for (int k = 0; k < 8; k++) A.out[8 + k] = (double)reinterpret_cast<long long *>(L.scal + 240)[k] * 0.01;      // microseconds
 #endif
     }
 }
@@ -1022,9 +1276,9 @@ extern "C" int bluest_master_max_support(bluest_plan_t plan, int *s_max)
     int KM = 0;
     for (const auto &od : plan->outs) KM = std::max(KM, od.K);
     const int n_out = (int)plan->outs.size();
-    const size_t limit = (size_t)master_lds_limit() - 1024;
+    const size_t limit = (size_t)master_lds_limit() - MASTER_STATIC_LDS;
     int S = MASTER_SMAX;
-    while (S > 0 && master_lds_bytes(plan->N, n_out, S, KM) > limit) S -= 4;
+    while (S > 0 && master_lds_bytes(plan->N, n_out, S, KM) > limit) S -= 2;
     *s_max = S;                                            // 0: this problem does not fit the single-workgroup master
     return BLUEST_OK;
 }
@@ -1059,6 +1313,7 @@ static int master_launch(bluest_plan_t plan, int S, const int64_t *support_host,
     if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
     int rc = require_gpu(); if (rc) return rc;
     if (S <= 0 || S > MASTER_SMAX) return fail(BLUEST_ERR_ARG, "support size %d out of range (1..%d)", S, MASTER_SMAX);
+    if (plan->outs.size() > 64) return fail(BLUEST_ERR_ARG, "the master problem takes at most 64 outputs");
     if (eps_bg < 0.0 || eps_bg >= 1.0 || (eps_bg > 0.0 && !bg_dev)) return fail(BLUEST_ERR_ARG, "background weight / matrices inconsistent");
     const int n_out = (int)plan->outs.size(), N = plan->N;
     // host-side maps, built once per plan: global group index -> (local index per output); offsets of the size classes
@@ -1100,7 +1355,7 @@ static int master_launch(bluest_plan_t plan, int S, const int64_t *support_host,
         KM = std::max(KM, kk[j]);
     }
     const size_t lds = master_lds_bytes(N, n_out, S, KM);
-    if (lds > (size_t)master_lds_limit() - 1024) return fail(BLUEST_ERR_ARG, "master problem needs %zu bytes of LDS (limit %d)", lds, master_lds_limit() - 1024);
+    if (lds > (size_t)master_lds_limit() - MASTER_STATIC_LDS) return fail(BLUEST_ERR_ARG, "master problem needs %zu bytes of LDS (limit %d)", lds, master_lds_limit() - MASTER_STATIC_LDS);
     idx.assign((size_t)S * KM, 0);
     for (int j = 0; j < S; j++) for (int l = 0; l < kk[j]; l++) idx[(size_t)j * KM + l] = (uint8_t)members[j][l];
     // one descriptor blob: [invcov pointers][boff][cc][kk][idx]

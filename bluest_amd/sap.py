@@ -260,6 +260,8 @@ class SpgAllocator(object):
                              "f": ninfo["F"], "solver_info": 0, "fevals": ninfo["full_evals"], "gevals": ninfo["full_evals"],
                              "pruned": int(L - ninfo["support"]), "method": "newton", "certified_gap": ninfo["gap"],
                              "rounds": ninfo["rounds"], "master_evals": ninfo["master_evals"], "multipliers": ninfo["mu"]}
+                if "host_ms" in ninfo:
+                    self.info["host_ms"] = ninfo["host_ms"]
                 cert = ninfo.get("certificate")
                 if cert is not None:
                     # the certificate in the caller's terms: an allocation of cost B (the working budget), multipliers, and the

@@ -56,16 +56,19 @@ def _gpu_master(torch, plan, keep, cc_keep, s, bg, eps_bg, x0, mu0, tol=1e-10, m
     return x_d.cpu().numpy(), mu_d.cpu().numpy(), out_d.cpu().numpy()
 
 
-@pytest.mark.parametrize("n,kmax,n_out,S,eps_bg", [(8, 3, 1, 20, 1e-3), (8, 3, 2, 24, 1e-3), (10, 4, 3, 30, 1e-6), (20, 5, 8, 56, 1e-3)])
+@pytest.mark.parametrize("n,kmax,n_out,S,eps_bg", [(8, 3, 1, 20, 1e-3), (8, 3, 2, 24, 1e-3), (10, 4, 3, 30, 1e-6), (20, 5, 8, 54, 1e-3)])
 def test_master_kernel_equals_numpy_restatement(gpu, oracle, n, kmax, n_out, S, eps_bg):
     """one master problem from the same start: the single-workgroup kernel and the numpy restatement end at the same optimum
-    (objective to 1e-9, allocation to 1e-5, multipliers to 1e-4), both with a KKT residual below 1e-6"""
+    (objective to 1e-9, allocation to 1e-5, multipliers to 1e-4), both with a KKT residual below 1e-6; the headline shape runs at
+    the largest support its LDS budget takes (bluest_master_max_support)"""
     from oracle.master_newton import master_newton
     from bluest_amd.plan import Plan
     prob = synth.problem(n, kmax, n_out)
     sizes = [len(g) for g in prob["groups"]]
     plan = Plan(n, prob["K_tot"], [{"K": kmax, "sizes": sizes, "groups": prob["groups"], "C": prob["C"][o], "mapping": None} for o in range(n_out)])
     rng = np.random.RandomState(5)
+    from bluest_amd.colgen import master_max_support
+    assert master_max_support(plan) >= S
     keep = np.sort(np.concatenate([[0], 1 + rng.choice(prob["K_tot"] - 1, S - 1, replace=False)]))
     if eps_bg == 0.0:                                   # without background every model must be sampled by the support itself
         keep = np.union1d(keep, np.arange(n))

@@ -230,6 +230,19 @@ class SpgAllocator(object):
             r = var[0].cpu().numpy() / s
             return float(r.max()) if np.isfinite(r).all() else np.inf
 
+        def rescale_to_tolerance(m_h):
+            """eps mode: scale the allocation so that max_o V_o/eps_o^2 = 1 (V is homogeneous of degree -1).  The scaling can carry an
+            entry across the reference's absolute threshold |m| > 1e-6 (bluest/misc.py:453-457: which models count as sampled), which
+            moves V by ~1e-8 on ill-conditioned data: repeated until the ratio is 1 to rounding (one pass almost always)"""
+            for _ in range(4):
+                r_now = ratios(plan, m_h)
+                if not np.isfinite(r_now):
+                    break
+                m_h = m_h * r_now
+                if abs(r_now - 1.0) <= 1.0e-12:
+                    break
+            return m_h
+
         if budget is not None:
             B = float(budget)
         else:
@@ -251,11 +264,15 @@ class SpgAllocator(object):
             raise BLUESTError("SPG: the initial allocation does not sample model 0 / is infeasible")
         tot = {"it": 0, "count": 0}
         if prm["method"] == "newton" and type(getattr(plan, "plan", plan)).__name__ == "Plan":      # a HIP plan, or a ShardedPlan over HIP plans
-            xn, ninfo = colgen_solve(plan, w, s, B, x0=None if x0 is None else x, prm=prm.get("newton"))
+            import os
+            trace = print if os.environ.get("BLUEST_COLGEN_LOG") else None       # debugging aid: the rounds of the second-order finish
+            xn, ninfo = colgen_solve(plan, w, s, B, x0=None if x0 is None else x, prm=prm.get("newton"), log=trace)
+            if trace and xn is None:
+                trace("second-order finish gave up: %s" % (ninfo,))
             if xn is not None:
                 m = scale_h * xn
                 if budget is None:
-                    m = m * ratios(plan, m)    # rescale so that max_o V_o/eps_o^2 = 1 (V is homogeneous of degree -1)
+                    m = rescale_to_tolerance(m)
                 self.info = {"it": ninfo["newton_it"], "count": ninfo["full_evals"] + ninfo["master_evals"], "gpmax": ninfo["kkt"],
                              "f": ninfo["F"], "solver_info": 0, "fevals": ninfo["full_evals"], "gevals": ninfo["full_evals"],
                              "pruned": int(L - ninfo["support"]), "method": "newton", "certified_gap": ninfo["gap"],
@@ -358,7 +375,7 @@ class SpgAllocator(object):
                     xs, pruned = xp, k
         m = scale_h * xs
         if budget is None:
-            m = m * ratios(plan, m)        # rescale so that max_o V_o/eps_o^2 = 1 (V is homogeneous of degree -1)
+            m = rescale_to_tolerance(m)
         self.info = {"it": tot["it"], "count": tot["count"], "gpmax": res["gpmax"], "f": res["f"], "solver_info": res["solver_info"],
                      "fevals": tot["count"], "gevals": tot["it"] + len(p_list), "pruned": pruned}
         return m

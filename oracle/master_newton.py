@@ -119,7 +119,7 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-3, floo
     if not np.isfinite(r.max()):
         raise ValueError("master: the starting point is not evaluable")
     kkt, lam = np.inf, 0.0
-    tiny_steps = 0
+    best, fails, in_noise, noise_next, noise_stop = None, 0, False, False, 0
     for it in range(maxit):
         F = r.max()
         # candidate outputs of the step: within act_tol of the maximum or carrying a multiplier, at most PACT (largest first).  They
@@ -149,7 +149,7 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-3, floo
         free = (x > 0.0) | (rc < 0.0)
         fi = np.flatnonzero(free)
         D = 1.0 / np.maximum(x, floor)
-        accepted = False
+        accepted, noise_next = False, False
         for attempt in range(40):
             act = act0.copy()
             actc = actc0.copy()
@@ -219,6 +219,16 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-3, floo
                     print("   newton it %2d F %.12e kkt %.2e spread %.2e |act| %d free %d nnz %d damp %.1e" % (it, F, kkt, spread, len(act), len(fi), pos.sum(), damp))
                 if kkt <= tol and spread <= tol:
                     break
+                # the best point seen (smallest KKT measure) with the multipliers estimated at it.  Steps taken on trust (see the
+                # acceptance test) are judged here: three in a row that do not improve on the best point end the iteration there
+                m_now = max(kkt, spread)
+                if best is None or m_now < best["m"]:
+                    best, fails = {"m": m_now, "x": x, "r": r, "kkt": kkt, "mu": mu_full, "nu": nu_full}, 0
+                elif in_noise:
+                    fails += 1
+                    if fails >= 3:
+                        noise_stop = 1
+                        break
             pred = (tau - q.max()) * F * F                         # first-order predicted change of F for the step (< 0)
             if pred < -0.5 * F:                                    # the model promises more than half of a positive objective
                 damp *= 10.0
@@ -257,7 +267,10 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-3, floo
             rt = prob.evaluate(xt)
             info["evals"] += 1
             actual = rt.max() - F
-            ok = np.isfinite(rt.max()) and actual <= 1.0e-4 * min(pred, 0.0) + 1e-15 * F
+            # below a promised decrease of 1e-11 F the objective no longer tells a good step from a bad one: such a step is taken when
+            # the objective does not RISE by more than that, and the next iterations judge it by the KKT residual (best / fails)
+            noise = pred > -1.0e-11 * F and max(kkt, spread) <= 1.0e-4 and damp <= 1.0e-2      # (a tiny step of a heavily damped system is not noise)
+            ok = np.isfinite(rt.max()) and (actual <= 1.0e-4 * min(pred, 0.0) + 1e-15 * F or (noise and actual <= 1.0e-11 * F))
             if not ok and len(act) > 1 and np.isfinite(rt.max()):
                 # near a tie of several outputs second-order errors split the tie and the exact max rejects a good SQP step (the
                 # Maratos effect).  Second-order correction: the minimum-norm (in M) step c that re-equalises the active outputs
@@ -276,34 +289,37 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-3, floo
                     rt2 = prob.evaluate(xt2)
                     info["evals"] += 1
                     actual2 = rt2.max() - F
-                    if np.isfinite(rt2.max()) and actual2 <= 1.0e-4 * min(pred, 0.0) + 1e-15 * F:
+                    if np.isfinite(rt2.max()) and (actual2 <= 1.0e-4 * min(pred, 0.0) + 1e-15 * F or (noise and actual2 <= 1.0e-11 * F)):
                         ok, xt, rt, actual = True, xt2, rt2, actual2
             if ok:
                 accepted = True
                 ratio = actual / pred if pred < 0 else 1.0
                 if verbose:
                     print("        accepted at attempt %d damp %.1e: F -> %.12e (pred %.3e actual %.3e)" % (attempt, damp, rt.max(), pred, actual))
+                if noise:
+                    ratio = 1.0                                    # a step taken on trust counts as a good one
                 if ratio > 0.5:
                     damp = max(damp * 0.1, 1.0e-14)
                 elif ratio < 0.1:
                     damp *= 10.0
+                noise_next = noise
                 break
             if verbose:
                 print("        rejected attempt %d damp %.1e pred %.3e actual %.3e rt-F %s" % (attempt, damp, pred, actual, (rt - F)[act]))
             damp *= 10.0
             if damp > 1.0e12:
                 break
+        if noise_stop:                                             # back to the best point, with its multipliers
+            x, r, kkt, mu, nu = best["x"], best["r"], best["kkt"], best["mu"], best["nu"]
+            break
         if kkt <= tol and spread <= tol:
             mu, nu = mu_full, nu_full
             break
         if not accepted:
             break
         x, r, mu, nu = xt, rt, mu_full, nu_full
+        in_noise = noise_next
         info["it"] = it + 1
-        # the objective cannot resolve the remaining improvement (the KKT residual left sits in entries of negligible mass)
-        tiny_steps = tiny_steps + 1 if abs(actual) <= 1.0e-13 * F else 0
-        if tiny_steps >= 2:
-            break
     info.update({"x": x, "mu": mu, "nu": nu, "lam": lam, "F": float(r.max()), "r": r, "kkt": kkt})
     return info
 

@@ -116,12 +116,12 @@ def sap_wallclock(prob, reps=4):
 
 
 def pmc_traffic(kernel, cfg):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json, written
-    by tools/pmc_traffic.py with the guide's gfx950 FETCH_SIZE correction; taken on the headline workload); None otherwise"""
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of THIS configuration (profiles/*_pmc_traffic.json for
+    the headline workload, *_pmc_traffic_n<n>_k<k>_o<o>.json for the others; written by tools/pmc_traffic.py with the guide's gfx950
+    FETCH_SIZE correction); None when no such profile is committed"""
     import glob
-    if tuple(cfg) != HEADLINE:
-        return None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+    suffix = "" if tuple(cfg) == HEADLINE else "_n%d_k%d_o%d" % tuple(cfg)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic%s.json" % suffix)), reverse=True):
         try:
             return json.load(open(f))["kernels"][kernel]["hbm_bytes_per_launch"]
         except Exception:
@@ -187,6 +187,85 @@ def cpu_baseline(prob, seconds=14.0):
                       % (prob["n"], prob["kmax"], seconds / 3),
             "as_executed_reference_value": res.get("R"), "B1_plain_C_dense_psi_value": res["B1"], "B2_plain_C_sparse_value": res["B2"],
             "host_cores_available": os.cpu_count()}
+
+
+def sap_cpu_baseline(prob, gpu_max_variance, solve_seconds=10.0, setup_cap_s=14.0):
+    """the SAP wall-clock half of the metric on ONE host core, as the reference executes it:
+    set-up  = per output the constructor of bluest/sap.py:53-129 -- K_tot calls of numpy.linalg.pinv (:69-79), the indicator
+              vectors (:89-94), the dense psi (:129) -- through the oracle's restatement (oracle.OracleSAP), every output as
+              bluest/mosap.py:36-47 does; when one output predicts more than setup_cap_s for all of them, only the first ones are
+              built and the figure is scaled to n_out (the sample is stated);
+    solve   = the reference's spg() (bluest/spg.py:39-132) on x = cost*m/B over the simplex with the reference's evaluation as the
+              callback (misc.py:479-495: max over the outputs, gradient of the largest), stopped after solve_seconds; the best
+              objective it reached is reported next to the GPU solver's optimum.  A reported baseline, not a target."""
+    from oracle import oracle as orc
+    orc.build()
+    from threadpoolctl import threadpool_limits
+    n_out, kmax, groups, w, B = prob["n_out"], prob["kmax"], prob["groups"], prob["costs"], prob["budget"]
+    with threadpool_limits(limits=1):
+        saps, t_setup = [], []
+        for o in range(n_out):
+            t0 = time.perf_counter()
+            saps.append(orc.OracleSAP(prob["C"][o], kmax, [g.copy() for g in groups], w))
+            t_setup.append(time.perf_counter() - t0)
+            if sum(t_setup) / len(t_setup) * n_out > setup_cap_s and sum(t_setup) > 0.5 * setup_cap_s:
+                break
+        built = len(saps)
+        setup_s = sum(t_setup) / built * n_out
+        # time-boxed reference SPG on the outputs that were built (all of them unless the cap cut the set-up short)
+        use_ref = orc.ref_native() is not None
+        if use_ref:
+            orc.select_fast_math()
+        scale = B / w
+        state = {"best": np.inf, "evals": 0, "t0": time.perf_counter()}
+
+        class _TimeUp(Exception):
+            pass
+
+        def both(x):
+            if time.perf_counter() - state["t0"] > solve_seconds:
+                raise _TimeUp()
+            m = scale * x
+            vals, grads = [], []
+            for sp in saps:
+                try:
+                    v, g, _ = sp.variance_GH_as_executed(m) if use_ref else sp.variance_GH(m, nohess=True)
+                except AssertionError:
+                    v, g = np.inf, None
+                vals.append(v); grads.append(g)
+            state["evals"] += 1
+            o = int(np.argmax(vals))
+            if np.isfinite(vals[o]):
+                state["best"] = min(state["best"], float(vals[o]))
+            f0 = state.setdefault("f0", float(vals[o]))           # objective normalised by its value at the start (as the GPU loop does)
+            return float(vals[o]) / f0, (None if grads[o] is None else grads[o] * scale / f0)
+        cache = {}
+
+        def feval(x):
+            f, g = both(x)
+            cache["x"], cache["g"] = x.copy(), g
+            return f
+
+        def geval(x):
+            if cache.get("x") is not None and np.array_equal(cache["x"], x) and cache["g"] is not None:
+                return cache["g"]
+            return both(x)[1]
+        it = None
+        try:
+            res = orc.spg(feval, geval, orc.simplex_projection, np.full(len(w), 1.0 / len(w)), eps=1.0e-10, maxit=10 ** 6, lmbda_max=1.0e3)
+            it = int(res["it"])
+        except _TimeUp:
+            pass
+        orc.select_strict()
+    return {"cores": 1, "kind": "reference" if use_ref else "port",
+            "setup_s": setup_s, "setup_outputs_built": built, "setup_s_per_output": [round(t, 4) for t in t_setup],
+            "setup_sample": "bluest/sap.py:53-129 per output (K_tot numpy pinv + indicator vectors + dense psi), %d of %d outputs built%s"
+                            % (built, n_out, "" if built == n_out else ", scaled to all outputs"),
+            "solve_time_box_s": solve_seconds, "solve_evaluations": state["evals"], "solve_spg_iterations_completed": it,
+            "solve_outputs": built, "max_variance_reached": state["best"], "gpu_max_variance": gpu_max_variance,
+            "excess_over_gpu_optimum": (state["best"] / gpu_max_variance - 1.0) if (built == n_out and np.isfinite(state["best"])) else None,
+            "solve_sample": "bluest/spg.py:39-132 from the uniform allocation, callbacks = max_o V_o and the gradient of the largest output "
+                            "(bluest/misc.py:479-495 as executed), stopped after the time box; best objective seen"}
 
 
 class Stepper(object):
@@ -318,7 +397,13 @@ def launch_ranks(n, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL and the peer-write mailboxes need it on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.call(cmd, env=env)
+    # rank 0's JSON line goes to stdout, whatever else the ranks print there (gloo's connection banner, library notices) to stderr:
+    # the caller reads ONE line
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:
+        (sys.stdout if line.startswith('{"metric"') else sys.stderr).write(line)
+        sys.stdout.flush()
+    return child.wait()
 
 
 def main():
@@ -466,6 +551,24 @@ def main():
         extra["single_gpu_value"] = n_out_all / float(solo[0])
         extra["single_gpu_ms_per_step"] = float(solo[0]) * 1e3
         del full
+        if sharded is not None and not args.no_batched:
+            # ... and the same GPU alone on the batched step (the reference the batched sharded step is to be compared with)
+            sb = torch.zeros(len(BATCHES), dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            if rank == 0:
+                fullb = Plan(n, L, build_outputs(prob), max_candidates=max(BATCHES), device=dev)
+                for bi, nc in enumerate(BATCHES):
+                    rngb = np.random.RandomState(77 + nc)
+                    rings = [torch.from_numpy(10.0 * rngb.rand(nc, L)).to(dev) for _ in range(2)]
+                    bv = torch.empty((nc, n_out), dtype=torch.float64, device=dev)
+                    bgr = torch.empty((nc, fullb.grad_len), dtype=torch.float64, device=dev)
+                    bs = torch.empty((nc, n_out), dtype=torch.int32, device=dev)
+                    bstep = lambda i, rings=rings, bv=bv, bgr=bgr, bs=bs: fullb.eval(rings[i % 2], out=(bv, bgr, bs))   # noqa: E731
+                    bst = Stepper(torch, bstep, 2, max(40, args.steps // nc), args.graph_steps, not args.no_graph, lambda: torch.cuda.synchronize())
+                    sb[bi] = bst.timed(max(4, args.warmup // nc))[0]
+                del fullb
+            dist.all_reduce(sb)
+            extra["single_gpu_batched"] = {"n_cand=%d" % nc: {"value": nc * n_out_all / float(sb[bi]), "ms_per_step": float(sb[bi]) * 1e3}
+                                           for bi, nc in enumerate(BATCHES)}
         if sharded is not None and not args.no_sap:
             # the solve of the same configuration over the sharded plan (collective, so every rank runs it) -- outside the timed region
             try:
@@ -645,6 +748,13 @@ def main():
             out["batched"] = batched
         if world == 1 and not args.no_sap:
             out["sap_wallclock"] = sap_wallclock(prob)
+            if not args.no_cpu_baseline:
+                try:
+                    out["sap_wallclock"]["cpu_baseline"] = sap_cpu_baseline(prob, out["sap_wallclock"]["warm"]["max_variance"])
+                    cb_s = out["sap_wallclock"]["cpu_baseline"]
+                    out["sap_wallclock"]["setup_speedup_vs_cpu_baseline"] = cb_s["setup_s"] / out["sap_wallclock"]["warm"]["setup_s"]
+                except Exception as err:      # the headline line must not depend on this leg
+                    out["sap_wallclock"]["cpu_baseline"] = {"error": repr(err)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(prob)
             out["cpu_baseline"] = cb

@@ -6,7 +6,7 @@ gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE and WRITE_SIZE are in 
 the bytes of a wide coalesced (16 B/lane) streaming read, so the read side is doubled for our streaming kernels (their
 loads are 16 B per lane); WRITE_SIZE is exact for 16-B streaming stores.  Both raw and corrected values are kept.
 
-    python tools/pmc_traffic.py gpurun_out/prof_r01 r01
+    python tools/pmc_traffic.py gpurun_out/prof_r01 r01 [out_dir [suffix]]      suffix: "_n25_k6_o1" for a non-headline configuration
 """
 import csv
 import glob
@@ -21,7 +21,7 @@ def short(name):
     return name.split("(")[0].split("<")[0]
 
 
-def main(src, tag, out_dir=None):
+def main(src, tag, out_dir=None, suffix=""):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out_dir = out_dir or os.path.join(root, "profiles")
     os.makedirs(out_dir, exist_ok=True)
@@ -30,7 +30,7 @@ def main(src, tag, out_dir=None):
     stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
-        with open(os.path.join(out_dir, "%s_kernel_stats.csv" % tag), "w") as f:
+        with open(os.path.join(out_dir, "%s_kernel_stats%s.csv" % (tag, suffix)), "w") as f:
             w = csv.writer(f)
             w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
             for r in rows:
@@ -65,10 +65,11 @@ def main(src, tag, out_dir=None):
                 summary[name] = json.loads(open(pth).read().strip().splitlines()[-1])
             except Exception:
                 pass
-    with open(os.path.join(out_dir, "%s_pmc_traffic.json" % tag), "w") as f:
+    with open(os.path.join(out_dir, "%s_pmc_traffic%s.json" % (tag, suffix)), "w") as f:
         json.dump(summary, f, indent=1)
     print(json.dumps(summary["kernels"], indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r01", sys.argv[3] if len(sys.argv) > 3 else None)
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r01", sys.argv[3] if len(sys.argv) > 3 else None,
+         sys.argv[4] if len(sys.argv) > 4 else "")

@@ -1,44 +1,40 @@
 #!/bin/bash
-# Round profile: (1) rocprofv3 --kernel-trace --stats of the bench command (without the SAP / CPU / batched legs, so the trace
-# holds the timed hot path), (2) separate --pmc passes for FETCH_SIZE and WRITE_SIZE (MI355X_MICROARCH.md, HBM section), (3) the
-# default bench, (4) the other BASELINE configurations (n=20 single output with its own kernel trace, n=12 all groups, n=25),
-# (5) kernel statistics of whole SAP solves, (6) the driver's command line, (7) step parts + quality sweep; summaries go to gpurun_out/profiles_<tag>/ (raw per-dispatch CSVs stay behind).
-#   on the GPU box:  bash tools/profile.sh r02
-TAG=${1:-r03}
+# Round profile.  For EVERY BASELINE configuration (headline n=20/k=5/8 outputs, n=20/k=5/1, n=12 all groups, n=25/k=6):
+#   (1) rocprofv3 --kernel-trace --stats of the bench command (without the SAP / CPU / batched legs, so the trace holds the timed
+#       hot path), (2) separate --pmc passes for FETCH_SIZE and WRITE_SIZE (MI355X_MICROARCH.md, HBM section; the program directly
+#       after `--`), summarised by tools/pmc_traffic.py into <tag>_kernel_stats<suffix>.csv / <tag>_pmc_traffic<suffix>.json;
+# then (3) the default bench of every configuration (its line reads the summaries of (1)-(2): run profile.sh, copy the summaries to
+# profiles/, run it again for lines with frac_rocprof / traffic of the SAME build -- or accept the previous round's), (4) kernel
+# statistics of whole SAP solves, (5) the driver's command line, (6) master phases, step parts, quality sweep.
+# Summaries go to gpurun_out/profiles_<tag>/ (raw per-dispatch CSVs stay behind).     on the GPU box:  bash tools/profile.sh r04
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 SUM=gpurun_out/profiles_$TAG
 rm -rf $OUT $SUM; mkdir -p $OUT $SUM
 LEAN="--no-cpu-baseline --no-sap --no-batched"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py $LEAN > $OUT/bench_under_trace.json 2> $OUT/trace.err
-echo "trace done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python bench.py $LEAN --no-graph --steps 200 --warmup 20 > $OUT/bench_under_pmc_fetch.json 2> $OUT/pmc_fetch.err
-echo "pmc fetch done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python bench.py $LEAN --no-graph --steps 200 --warmup 20 > $OUT/bench_under_pmc_write.json 2> $OUT/pmc_write.err
-echo "pmc write done"
-python bench.py > $OUT/bench.json 2> $OUT/bench.err
-echo "bench done"
-python tools/pmc_traffic.py $OUT $TAG $SUM > $SUM/summary.txt
-cp "$(ls -t $OUT/trace/*/*_kernel_stats.csv | head -1)" $SUM/${TAG}_kernel_stats_full.csv
-cp $OUT/bench.json $SUM/${TAG}_bench.json
-cp $OUT/bench_under_trace.json $SUM/${TAG}_bench_under_trace.json
-# BASELINE.json configs[2]: n=20, k_max=5, ONE output (non-shared Phi kernel), its own kernel trace
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_o1 -- python bench.py $LEAN --n 20 --kmax 5 --n-out 1 > $OUT/bench_o1_under_trace.json 2> $OUT/trace_o1.err
-python - <<PY
-import csv, glob
-f = sorted(glob.glob("$OUT/trace_o1/*/*_kernel_stats.csv"))[-1]
-with open("$SUM/${TAG}_kernel_stats_n20_k5_o1.csv", "w") as out:
-    w = csv.writer(out)
-    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-    for r in csv.DictReader(open(f)):
-        w.writerow([r["Name"][:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
-PY
+for cfg in "20 5 8" "20 5 1" "12 12 1" "25 6 1"; do
+  set -- $cfg
+  if [ "$cfg" = "20 5 8" ]; then SFX=""; else SFX="_n$1_k$2_o$3"; fi
+  ARGS="--n $1 --kmax $2 --n-out $3"
+  D=$OUT/cfg$SFX; mkdir -p $D
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python bench.py $LEAN $ARGS > $D/bench_under_trace.json 2> $D/trace.err
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $D/pmc_fetch -- python bench.py $LEAN $ARGS --no-graph --steps 200 --warmup 20 > $D/bench_under_pmc_fetch.json 2> $D/pmc_fetch.err
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $D/pmc_write -- python bench.py $LEAN $ARGS --no-graph --steps 200 --warmup 20 > $D/bench_under_pmc_write.json 2> $D/pmc_write.err
+  python tools/pmc_traffic.py $D $TAG $SUM "$SFX" > $SUM/summary$SFX.txt
+  if [ -z "$SFX" ]; then
+    cp "$(ls -t $D/trace/*/*_kernel_stats.csv | head -1)" $SUM/${TAG}_kernel_stats_full.csv
+    cp $D/bench_under_trace.json $SUM/${TAG}_bench_under_trace.json
+  fi
+  echo "trace + pmc of $cfg done"
+done
+# (3) default bench lines
+python bench.py > $SUM/${TAG}_bench.json 2> $OUT/bench.err
 python bench.py --n 20 --kmax 5 --n-out 1 > $SUM/${TAG}_bench_n20_k5_o1.json 2> $OUT/bench_o1.err
-echo "n20 o1 done"
 python bench.py --n 12 --kmax 12 --n-out 1 > $SUM/${TAG}_bench_n12_k12_o1.json 2> $OUT/bench_n12.err
 python bench.py --n 25 --kmax 6 --n-out 1 > $SUM/${TAG}_bench_n25_k6_o1.json 2> $OUT/bench_n25.err
-echo "other configs done"
-# (5) kernel statistics of whole SAP solves (set-up + second-order finish), headline and the other BASELINE sizes
+echo "bench lines done"
+# (4) kernel statistics of whole SAP solves (set-up + second-order finish), headline and the other BASELINE sizes
 for cfg in "20 5 8" "20 5 1" "25 6 1"; do
   tagc=$(echo $cfg | tr " " _)
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_solve_$tagc -- python tools/one_solve.py $cfg 3 > $OUT/solve_$tagc.log 2> $OUT/solve_$tagc.err
@@ -52,9 +48,10 @@ PY
   grep rep $OUT/solve_$tagc.log >> $SUM/${TAG}_solve_kernel_stats_$tagc.txt
 done
 echo "solve stats done"
-# (6) the driver's command line, verbatim
+# (5) the driver's command line, verbatim
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $SUM/${TAG}_bench_driver_style.json 2> $OUT/bench_driver.err
-# (7) parts of a step on the chain clock, quality sweep
+# (6) master phases (experiment build, product build restored), parts of a step on the chain clock, quality sweep
+bash tools/master_phases.sh $SUM/${TAG}_master_phases.txt > /dev/null 2>&1
 python tools/step_parts.py > $SUM/${TAG}_step_parts.txt 2>/dev/null
 python tools/quality_sweep.py > $SUM/${TAG}_quality_sweep.txt 2>/dev/null
 echo "driver-style bench + sweeps done"

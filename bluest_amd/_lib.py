@@ -45,6 +45,7 @@ SIGNATURES = {
     "bluest_plan_n_outputs": [c_vp, ctypes.POINTER(c_int)],
     "bluest_plan_grad_layout": [c_vp, c_i64p, c_i64p],
     "bluest_plan_traffic": [c_vp, c_i64p, c_i64p],
+    "bluest_plan_matfree": [c_vp, c_vp, c_i64p],
     "bluest_plan_phi_len": [c_vp, c_i64p],
     "bluest_plan_phi_chunks": [c_vp, c_vp, c_int, c_i64, c_vp],
     "bluest_plan_phi": [c_vp, c_vp, c_int, c_i64, c_vp, c_vp],

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["runtime.hip", "mirrors.hip", "plan.hip", "spg.hip", "intproj.hip", "xchg.hip", "newton.hip"]     # translation units of libbluest_hip.so
+SOURCES = ["runtime.hip", "mirrors.hip", "plan.hip", "spg.hip", "intproj.hip", "xchg.hip", "newton.hip", "matfree.hip"]     # translation units of libbluest_hip.so
 HEADERS = ["common.hpp", "solve.hpp", "plan.hpp", "spg_state.hpp"]
 OBJDIR = os.path.join(CSRC, "_build")
 HDR = os.path.join(ROOT, "include", "bluest_hip.h")

@@ -726,7 +726,7 @@ static std::unordered_map<void *, BlockInfo> g_block_info;      // every block h
 static size_t g_cache_bytes = 0;
 static const size_t CACHE_CAP = 3ull << 30;
 
-static hipError_t pool_alloc(void **p, size_t bytes)
+hipError_t pool_alloc(void **p, size_t bytes)
 {
     size_t want = (std::max<size_t>(bytes, 1) + 0x3ffff) & ~(size_t)0x3ffff;            // 256 KiB granules
     if (want <= (8u << 20)) {                  // small requests (restricted plans of the solver): power-of-two size classes, so
@@ -772,7 +772,7 @@ static hipError_t pool_alloc(void **p, size_t bytes)
 }
 // recycle = false: the block is handed back to the runtime instead of the cache (error paths: nothing that a faulted or
 // half-finished sequence touched is given to the next plan)
-static hipError_t pool_free(void *p, bool recycle = true)
+hipError_t pool_free(void *p, bool recycle)
 {
     {
         std::lock_guard<std::mutex> lock(g_cache_mutex);
@@ -793,6 +793,7 @@ typedef DeviceScopeN DeviceScope;      // plan.hpp
 
 static void plan_free_device(bluest_plan_s *p)
 {
+    mf_release(p);
     if (p->d_arena) (void)pool_free(p->d_arena);
     if (p->d_scratch) (void)pool_free(p->d_scratch);
     if (p->d_master) (void)hipFree(p->d_master);
@@ -801,7 +802,8 @@ static void plan_free_device(bluest_plan_s *p)
     for (auto &od : p->outs) {
         if (od.d_invcov) (void)pool_free(od.d_invcov);
         if (od.d_groups && od.owns_groups) (void)pool_free(od.d_groups);
-        od.d_invcov = nullptr; od.d_groups = nullptr;
+        if (od.d_C) (void)pool_free(od.d_C);
+        od.d_invcov = nullptr; od.d_groups = nullptr; od.d_C = nullptr;
     }
 }
 
@@ -925,7 +927,8 @@ static void output_release(OutputDesc &od)
 {
     if (od.d_invcov) (void)pool_free(od.d_invcov);
     if (od.d_groups && od.owns_groups) (void)pool_free(od.d_groups);
-    od.d_invcov = nullptr; od.d_groups = nullptr;
+    if (od.d_C) (void)pool_free(od.d_C);
+    od.d_invcov = nullptr; od.d_groups = nullptr; od.d_C = nullptr;
 }
 
 extern "C" int bluest_plan_add_output(bluest_plan_t plan, int K, const int64_t *sizes, const int64_t *groups,
@@ -978,6 +981,9 @@ extern "C" int bluest_plan_add_output_cov(bluest_plan_t plan, const double *C, i
             go += Lk * k; io += Lk * k * k;
         }
         // the next output's covariance upload overwrites dC: wait for the kernels (they take ~0.1 ms; the inverses stay on the device)
+        // the covariance itself stays on the device as well (N x N): the matrix-free evaluation recomputes the inverses from it
+        if (rc == BLUEST_OK && pool_alloc((void **)&od.d_C, need) == hipSuccess)
+            (void)hipMemcpyAsync(od.d_C, dC, need, hipMemcpyDeviceToDevice, 0);
         if (rc == BLUEST_OK) e = hipStreamSynchronize(0);
         if (rc == BLUEST_OK && e == hipSuccess && invcovs_out)
             e = hipMemcpy(invcovs_out, od.d_invcov, (size_t)od.n_inv * sizeof(double), hipMemcpyDeviceToHost);
@@ -1566,6 +1572,8 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
     plan->d_ticket = reinterpret_cast<unsigned int *>(arena.base + o_ticket);
     HIP_TRY(hipMemset(plan->d_ticket, 0, 256));
     plan->finalized = true;
+    if ((rc = mf_finalize(plan))) return rc;      // matrix-free evaluation for plans that qualify (matfree.hip)
+
     timer.lap("device scatter of the values");
     return BLUEST_OK;
 }
@@ -1796,6 +1804,7 @@ extern "C" int bluest_plan_phi(bluest_plan_t plan, const double *m_dev, int n_ca
     if (n_cand > 1 && m_stride < plan->L) return fail(BLUEST_ERR_ARG, "m_stride < L_global");
     hipStream_t st = (hipStream_t)stream;
     const int n_out = (int)plan->outs.size();
+    if (plan->matfree && n_cand == 1 && !plan->gate) return mf_phi_record(plan, m_dev, phi_dev, nullptr, st);
     launch_chunks(plan, m_dev, n_cand, m_stride, st);
 #define LFR(NT) hipLaunchKernelGGL((k_fold_to_record<NT>), dim3(n_out, n_cand), dim3(fold_threads(NT)), 0, st, plan->N, n_out, plan->d_rows, \
                                    plan->nsym, plan->fold_reg, plan->d_partial, plan->partial_stride, phi_dev)
@@ -1864,6 +1873,7 @@ extern "C" int bluest_plan_solve_grad(bluest_plan_t plan, const double *rec_dev,
     const int n_out = (int)plan->outs.size();
     if (state_dev && n_out > SPG_MAX_OUT) return fail(BLUEST_ERR_ARG, "more than %d outputs", SPG_MAX_OUT);
     hipStream_t st = (hipStream_t)stream;
+    if (plan->matfree && !state_dev && !plan->gate) return mf_solve_grad(plan, rec_dev, delta, var_dev, status_dev, grad_dev, st);
     int kmax = 0;
     for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
     const dim3 grid((unsigned)(plan->n_tiles / plan->fused_tpb));
@@ -1905,6 +1915,18 @@ static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_
     hipStream_t st = (hipStream_t)stream;
     const int n_out = (int)plan->outs.size();
     int32_t *status = status_dev ? status_dev : plan->d_status;
+    if (plan->matfree && n_cand == 1 && !dec_state && !plan->gate && !g_debug_solve) {
+        // matrix-free: Phi pass -> record -> (solve + gradient | solve) -- no stored inverse is read
+        const double *rec = nullptr;
+        if ((rc = mf_phi_record(plan, m_dev, nullptr, &rec, st))) return rc;
+        if (grad_dev) return mf_solve_grad(plan, rec, delta, var_dev, status, grad_dev, st);
+#define LSRM(NT) hipLaunchKernelGGL((k_solve_from_record<NT>), dim3(n_out, 1), dim3(64), 0, st, plan->N, n_out, rec, delta, plan->always_v ? 1 : 0, \
+                                    var_dev, plan->d_v, status)
+        NT_DISPATCH(plan->N, LSRM);
+#undef LSRM
+        HIP_TRY(hipGetLastError());
+        return BLUEST_OK;
+    }
     launch_chunks(plan, m_dev, n_cand, m_stride, st);
     int kmax = 0;
     for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);

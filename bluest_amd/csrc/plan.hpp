@@ -32,6 +32,7 @@ struct OutputDesc {
     uint8_t *d_groups = nullptr;   // DEVICE copy of `groups`, one byte per model index (n <= 64): 8x less to push over PCIe
                                    // than the int64 list (11 MB at K_tot = 245 505); shared with output 0 when the lists are identical
     bool owns_groups = false;
+    double *d_C = nullptr;         // DEVICE copy of the covariance (N x N) when the output was given by it: the matrix-free evaluation
 };
 
 struct bluest_plan_s {
@@ -90,6 +91,11 @@ struct bluest_plan_s {
     unsigned int *d_ticket = nullptr;   // arrival counter of the fused solve + line-search decision (bluest_plan_eval_decide)
     // second-order finish (newton.hip): descriptor blob of the master problem (plain hipMalloc, grown on demand) and the
     // host-side global -> local group maps it is built from
+    // matrix-free evaluation (matfree.hip): chosen at finalize for plans that qualify
+    bool matfree = false;
+    void *mf = nullptr;
+    int32_t *mf_wg_begin_dev = nullptr;
+    int mf_wgs_grad = 0;
     void *d_master = nullptr;
     size_t master_bytes = 0;
     std::vector<std::vector<int32_t>> inv_host;
@@ -194,3 +200,11 @@ __device__ __forceinline__ void grad_tile_generic(const TileDesc &td, const doub
 
 
 int plan_ready(bluest_plan_t plan, int n_cand);
+// the library's device block cache (plan.hip)
+hipError_t pool_alloc(void **p, size_t bytes);
+hipError_t pool_free(void *p, bool recycle = true);
+// matrix-free evaluation (matfree.hip)
+int mf_finalize(bluest_plan_t plan);
+void mf_release(bluest_plan_s *p);
+int mf_phi_record(bluest_plan_t plan, const double *m_dev, double *rec_dev, const double **rec_used, hipStream_t st);
+int mf_solve_grad(bluest_plan_t plan, const double *rec_dev, double delta, double *var_dev, int32_t *status_dev, double *grad_dev, hipStream_t st);

@@ -144,6 +144,13 @@ int bluest_plan_n_outputs(bluest_plan_t plan, int *n_outputs);
 int bluest_plan_grad_layout(bluest_plan_t plan, int64_t *grad_len, int64_t *offsets /* n_outputs */);
 /* HBM bytes the Phi pass / gradient pass stream per candidate (actual layout, for roofline accounting) */
 int bluest_plan_traffic(bluest_plan_t plan, int64_t *phi_bytes, int64_t *grad_bytes);
+/* MATRIX-FREE evaluation (csrc/matfree.hip; the form BASELINE.json's north star names): the inverse of every group's covariance
+ * block (bluest/sap.py:69-79) is recomputed in registers where bluest/cmisc.cpp:25-40,58-72 read the stored one, so an evaluation
+ * reads the groups' model indices and m only.  Chosen at bluest_plan_finalize for plans that qualify (outputs given by their
+ * covariance, group sizes <= 8, <= 48 models, every block safely positive definite) when BLUEST_MATFREE=1, or on its own when the
+ * stored streams exceed 64 MB; single-candidate bluest_plan_eval / bluest_plan_phi / bluest_plan_solve_grad then take it.
+ * *matfree = 1 if this plan evaluates matrix-free; *mf_bytes = bytes such an evaluation reads and writes per candidate. */
+int bluest_plan_matfree(bluest_plan_t plan, int *matfree, int64_t *mf_bytes);
 /* size in doubles of one candidate's Phi-pass result: n_outputs * (N*N + 2*N + 1), see bluest_plan_phi */
 int bluest_plan_phi_len(bluest_plan_t plan, int64_t *len);
 

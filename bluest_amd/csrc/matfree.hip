@@ -26,14 +26,16 @@
 // MF_AUTO_BYTES (the evaluation is then bound by bytes, profiles/r04_matfree_ab.txt).
 #include "plan.hpp"
 
+#ifndef MF_ABLATE          // experiment builds only (timing; the ablated builds compute wrong numbers): 1 no LDS adds, 2 no run sums,
+#define MF_ABLATE 0        // 3 no inverse (the factor's entries are scattered), 4 tiles load their inputs and do nothing else
+#endif
 #define MF_KMAX 8
 #define MF_TILE_WAVES 15                       // tile wavefronts of k_solve_grad_mf (+ the solving one)
 static const int64_t MF_AUTO_BYTES = 64ll << 20;
 
-struct MfTile {            // 64 consecutive groups of one size of one output
+struct MfTile {            // 64 consecutive groups of one size of one output (8 bytes: one scalar load)
     int32_t first;         // local index (within the output) of the first group
     int16_t n, k;          // groups in the tile (<= 64), their size
-    int64_t gbyte;         // offset of the first group's model indices in the output's byte list
 };
 
 struct MfState {           // hangs off bluest_plan_s::mf
@@ -41,10 +43,11 @@ struct MfState {           // hangs off bluest_plan_s::mf
     MfTile *d_tiles = nullptr;
     int32_t *d_tile_begin = nullptr;           // [n_out + 1]
     double *d_C = nullptr;                     // [n_out][N * N]
-    const uint8_t **d_groups = nullptr;        // [n_out] device pointers to the byte lists
+    const uint64_t **d_groups = nullptr;       // [n_out] device pointers to the packed model indices (8 bytes per group)
+    uint64_t *d_packed = nullptr;              // the packed lists (one per distinct group list)
     int32_t *d_map = nullptr;                  // local -> global group index, concatenated like the gradient (NULL: identity)
     double2 *d_partial = nullptr;              // [n_out][wgs][nsym]
-    double *d_amax = nullptr;                  // [n_out][wgs][N]
+    double *d_amax = nullptr;                  // [n_out][wgs][N + 1]: model-wise max |m|, then their maximum
     double *d_rec = nullptr;                   // [n_out][N*N + 2N + 1]  (evaluations that never leave this GPU)
     int32_t *d_flag = nullptr;                 // k_mf_check: number of blocks that are not safely positive definite
     std::vector<int32_t> tile_begin;           // host copy
@@ -101,13 +104,14 @@ __device__ __forceinline__ double mf_chol(double (&a)[mf_ke(K)], double (&r)[K])
     return worst;
 }
 
-// the model indices of lane's group (bytes) and its covariance block from LDS; lanes without a group get the identity
+// the model indices of lane's group (one byte each in the packed word) and its covariance block from LDS; lanes without a group get
+// the identity
 template <int K>
-__device__ __forceinline__ void mf_load_block(const uint8_t *__restrict__ gl, bool valid, const double *__restrict__ Cs, int N,
+__device__ __forceinline__ void mf_load_block(uint64_t pk, bool valid, const double *__restrict__ Cs, int N,
                                               int (&idx)[K], double (&a)[mf_ke(K)])
 {
 #pragma unroll
-    for (int j = 0; j < K; j++) idx[j] = valid ? (int)gl[j] : 0;
+    for (int j = 0; j < K; j++) idx[j] = valid ? (int)((pk >> (8 * j)) & 0xffull) : 0;
 #pragma unroll
     for (int i = 0; i < K; i++)
 #pragma unroll
@@ -116,17 +120,16 @@ __device__ __forceinline__ void mf_load_block(const uint8_t *__restrict__ gl, bo
 
 // Phi contribution of one tile (K static): into this wavefront's accumulators
 template <int K>
-__device__ __forceinline__ void mf_phi_tile(const MfTile &td, const uint8_t *__restrict__ groups, const int32_t *__restrict__ map,
-                                            int64_t map_off, const double *__restrict__ m, const double *__restrict__ Cs, int N,
+__device__ __forceinline__ void mf_phi_tile(int n_valid, uint64_t pk, double mg, const double *__restrict__ Cs, int N,
                                             double *__restrict__ acc, double *__restrict__ amx, int lane)
 {
-    const bool valid = lane < td.n;
-    const int64_t li = (int64_t)td.first + lane;
-    const double mg = valid ? m[map ? (int64_t)map[map_off + li] : li] : 0.0;
+    const bool valid = lane < n_valid;
     int idx[K];
     double a[mf_ke(K)], r[K];
-    mf_load_block<K>(groups + td.gbyte + (int64_t)lane * K, valid, Cs, N, idx, a);
-    (void)mf_chol<K>(a, r);
+    mf_load_block<K>(pk, valid, Cs, N, idx, a);
+    if (MF_ABLATE == 4) { if (a[0] == 1.2345 && mg == 5.4321) acc[idx[0]] = 1.0; return; }
+    if (MF_ABLATE != 3) (void)mf_chol<K>(a, r);
+    else { _Pragma("unroll") for (int i = 0; i < K; i++) r[i] = 1.0; }
     // M = L^-1 (lower) in place of L: M_jj = r_j, M_ij = -r_i sum_{p=j}^{i-1} L_ip M_pj  (column by column, rows top down)
     double M[mf_ke(K)];
 #pragma unroll
@@ -147,8 +150,12 @@ __device__ __forceinline__ void mf_phi_tile(const MfTile &td, const uint8_t *__r
     // segmented scan, the segment heads being the lanes where the prefix (idx_0 .. idx_i) changes -- and only the LAST lane of a
     // run adds the run's total: at most a few lanes per instruction meet at one address.  The order of the additions is fixed by
     // the plan (lane order inside a run, then the LDS's lane order, then program order).
+    // All run sums first, as straight-line code (21 independent scans at k = 6 for the scheduler to interleave: behind a branch per
+    // destination they ran one after the other, each a chain of four dependent DPP steps), then the adds.
     const double am = fabs(mg);
     unsigned head = (lane & 15) == 0 || !valid ? 1u : 0u;      // cumulative over the positions: prefix (idx_0 .. idx_i) differs from lane - 1's
+    double tot[mf_ke(K)], mxs[K];
+    bool tails[K];
 #pragma unroll
     for (int i = 0; i < K; i++) {
         const int prev = __builtin_amdgcn_mov_dpp(idx[i], 0x111, 0xf, 0xf, true);          // row_shr:1
@@ -163,23 +170,22 @@ __device__ __forceinline__ void mf_phi_tile(const MfTile &td, const uint8_t *__r
         nf[2] = f ? 0.0 : 1.0;
         f |= (unsigned)__builtin_amdgcn_mov_dpp((int)f, 0x114, 0xf, 0xf, true);           // row_shr:4
         nf[3] = f ? 0.0 : 1.0;
-        // (the DPP move first, for ALL lanes: behind the || it would run with lane 15 masked off and lane 14 would read a zero)
+        // (the DPP move first, for ALL lanes: behind an || it would run with lane 15 masked off and lane 14 would read a zero)
         const int next_head = __builtin_amdgcn_mov_dpp((int)head, 0x101, 0xf, 0xf, true);      // row_shl:1: the next lane starts a run
-        const bool tail = ((lane & 15) == 15) | (next_head != 0);
-        auto run_sum = [&](double v) {
-            v = fma(dpp_shr<0x111>(v), nf[0], v);
-            v = fma(dpp_shr<0x112>(v), nf[1], v);
-            v = fma(dpp_shr<0x114>(v), nf[2], v);
-            v = fma(dpp_shr<0x118>(v), nf[3], v);
-            return v;
-        };
+        tails[i] = ((lane & 15) == 15) | (next_head != 0);
 #pragma unroll
         for (int j = 0; j <= i; j++) {
-            double s = 0.0;
+            double sij = 0.0;
 #pragma unroll
-            for (int q = i; q < K; q++) s = fma(M[q * (q + 1) / 2 + i], M[q * (q + 1) / 2 + j], s);
-            const double tot = run_sum(mg * s);
-            if (tail && tot != 0.0) atomicAdd(&acc[mf_sym(idx[i], idx[j], N)], tot);      // ds_add_f64, wavefront-private accumulator
+            for (int q = i; q < K; q++) sij = fma(M[q * (q + 1) / 2 + i], M[q * (q + 1) / 2 + j], sij);
+            double v = mg * sij;
+            if (MF_ABLATE != 2) {
+                v = fma(dpp_shr<0x111>(v), nf[0], v);
+                v = fma(dpp_shr<0x112>(v), nf[1], v);
+                v = fma(dpp_shr<0x114>(v), nf[2], v);
+                v = fma(dpp_shr<0x118>(v), nf[3], v);
+            }
+            tot[i * (i + 1) / 2 + j] = v;
         }
         // max |m_g| over the groups containing model idx_i: same runs (|m| >= 0, lanes outside the row read 0)
         double mx = am;
@@ -187,7 +193,19 @@ __device__ __forceinline__ void mf_phi_tile(const MfTile &td, const uint8_t *__r
         mx = fmax(mx, dpp_shr<0x112>(mx) * nf[1]);
         mx = fmax(mx, dpp_shr<0x114>(mx) * nf[2]);
         mx = fmax(mx, dpp_shr<0x118>(mx) * nf[3]);
-        if (tail && mx > 0.0) __hip_atomic_fetch_max(&amx[idx[i]], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // ds_max_f64
+        mxs[i] = mx;
+    }
+    if (MF_ABLATE == 1) { double z = 0.0; _Pragma("unroll") for (int e = 0; e < mf_ke(K); e++) z += tot[e]; if (z == 1.2345) acc[0] = z; return; }
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        if (tails[i]) {
+#pragma unroll
+            for (int j = 0; j <= i; j++) {
+                const double v = tot[i * (i + 1) / 2 + j];
+                if (v != 0.0) atomicAdd(&acc[mf_sym(idx[i], idx[j], N)], v);      // ds_add_f64, wavefront-private accumulator
+            }
+            if (mxs[i] > 0.0) __hip_atomic_fetch_max(&amx[idx[i]], mxs[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // ds_max_f64
+        }
     }
 }
 
@@ -196,7 +214,7 @@ struct MfArgs {
     const MfTile *tiles;
     const int32_t *tile_begin;
     const double *C;
-    const uint8_t *const *groups;
+    const uint64_t *const *groups;
     const int32_t *map;
     const int64_t *goff;
 };
@@ -212,16 +230,34 @@ __global__ __launch_bounds__(64 * NW) void k_phi_matfree(const MfArgs A, const d
     for (int t = tid; t < N * N; t += 64 * NW) Cs[t] = A.C[(int64_t)o * N * N + t];
     for (int t = tid; t < NW * nsym; t += 64 * NW) acc[t] = 0.0;
     for (int t = tid; t < NW * N; t += 64 * NW) amx[t] = 0.0;
-    __syncthreads();
     const int tb = A.tile_begin[o], te = A.tile_begin[o + 1];
-    const uint8_t *groups = A.groups[o];
+    const uint64_t *groups = A.groups[o];
+    const int64_t map_off = A.goff[o];
     double *my_acc = acc + wave * nsym, *my_amx = amx + wave * N;
-    // tiles of this output, strided over the workgroups and then over the wavefronts (the sizes mix evenly)
-    for (int t = tb + b + wave * A.wgs; t < te; t += NW * A.wgs) {
-        const MfTile td = A.tiles[t];
-#define MFP(KK) case KK: mf_phi_tile<KK>(td, groups, A.map, A.goff[o], m, Cs, N, my_acc, my_amx, lane); break;
-        switch (td.k) { MFP(1) MFP(2) MFP(3) MFP(4) MFP(5) MFP(6) MFP(7) MFP(8) default: break; }
+    // tiles of this output, strided over the workgroups and then over the wavefronts (the sizes mix evenly).  The inputs of the NEXT
+    // tile (descriptor: a scalar load; packed indices and m: one load each per lane) are in flight while this one is worked on
+    auto fetch = [&](int t, MfTile &td, uint64_t &pk, double &mg) {
+        td = A.tiles[__builtin_amdgcn_readfirstlane(t)];
+        const bool v = lane < td.n;
+        const int64_t li = (int64_t)td.first + lane;
+        pk = v ? groups[li] : 0ull;
+        mg = v ? m[A.map ? (int64_t)A.map[map_off + li] : li] : 0.0;
+    };
+    const int stride = NW * A.wgs;
+    int t = tb + b + wave * A.wgs;
+    MfTile td, tdn;
+    uint64_t pk = 0ull, pkn = 0ull;
+    double mg = 0.0, mgn = 0.0;
+    td.first = 0; td.n = 0; td.k = 0; tdn = td;
+    if (t < te) fetch(t, td, pk, mg);
+    __syncthreads();                               // (the covariance and the zeroed accumulators)
+    while (t < te) {
+        const int tn = t + stride;
+        if (tn < te) fetch(tn, tdn, pkn, mgn);
+#define MFP(KK) case KK: mf_phi_tile<KK>(td.n, pk, mg, Cs, N, my_acc, my_amx, lane); break;
+        switch (__builtin_amdgcn_readfirstlane((int)td.k)) { MFP(1) MFP(2) MFP(3) MFP(4) MFP(5) MFP(6) MFP(7) MFP(8) default: break; }
 #undef MFP
+        td = tdn; pk = pkn; mg = mgn; t = tn;
     }
     __syncthreads();
     double2 *pout = partial + ((int64_t)o * A.wgs + b) * nsym;
@@ -231,50 +267,64 @@ __global__ __launch_bounds__(64 * NW) void k_phi_matfree(const MfArgs A, const d
         for (int w = 1; w < NW; w++) s += acc[w * nsym + d];      // wavefront order: fixed
         pout[d] = make_double2(s, 0.0);
     }
-    for (int a = tid; a < N; a += 64 * NW) {
-        double am = amx[a];
+    // model-wise maxima of this workgroup, and their maximum in slot N (the "some group has |m| >= 0.05" test of bluest/misc.py:464)
+    double am = 0.0;
+    if (tid < N) {
+        am = amx[tid];
 #pragma unroll
-        for (int w = 1; w < NW; w++) am = fmax(am, amx[w * N + a]);
-        amax[((int64_t)o * A.wgs + b) * N + a] = am;
+        for (int w = 1; w < NW; w++) am = fmax(am, amx[w * N + tid]);
+        amax[((int64_t)o * A.wgs + b) * (N + 1) + tid] = am;
+    }
+    if (tid < 64) {      // N <= 48: one wavefront holds every model
+        am = fast_max(am);
+        if (tid == 0) amax[((int64_t)o * A.wgs + b) * (N + 1) + N] = am;
     }
 }
 
-// partials of the workgroups -> record of every output: grid (ceil(nsym / 16), n_out), block 256 = 16 destinations x 16 lanes;
-// lane q of a destination sums workgroups q, q + 16, .. in order, the 16 lanes combine by a fixed butterfly
+// partials of the workgroups -> record of every output.  ONE WAVEFRONT PER RESULT, four per workgroup (block 256): the first nsym
+// results are the destinations, the next N + 1 the model-wise maxima and their maximum (-> the sampled-model flags of
+// bluest/misc.py:453-457, :464).  Lane l folds workgroups l, l + 64, .. with four independent loads in flight (sixteen dependent
+// round trips, as a 16-lane version had them, cost 10 us at 256 workgroups); the lanes combine with the fixed DPP reduction.
 __global__ __launch_bounds__(256) void k_mf_reduce(int N, int nsym, int wgs, const double2 *__restrict__ partial, const double *__restrict__ amax,
                                                    double *__restrict__ rec)
 {
-    const int o = blockIdx.y, tid = threadIdx.x, q = tid & 15, d = blockIdx.x * 16 + (tid >> 4);
+    const int o = blockIdx.y, tid = threadIdx.x, ln = tid & 63, d = blockIdx.x * 4 + (tid >> 6);
     const int reclen = N * N + 2 * N + 1;
     double *r = rec + (int64_t)o * reclen;
-    double s = 0.0;
     if (d < nsym) {
         const double2 *p = partial + (int64_t)o * wgs * nsym + d;
-        for (int w = q; w < wgs; w += 16) s += p[(int64_t)w * nsym].x;
-    }
-    s += __shfl_xor(s, 1, WAVE); s += __shfl_xor(s, 2, WAVE); s += __shfl_xor(s, 4, WAVE); s += __shfl_xor(s, 8, WAVE);
-    if (d < nsym && q == 0) {
-        // destination d = (a, b), a <= b, in the row-major order of the upper triangle
-        int a = 0, rem = d;
-        while (rem >= N - a) { rem -= N - a; a++; }
-        const int b = a + rem;
-        r[a * N + b] = s;
-        r[b * N + a] = s;
-    }
-    if (blockIdx.x == 0) {      // the sampled-model flags (bluest/misc.py:453-457, :464) from the model-wise max |m|
-        __shared__ double big_s[4];
-        const int wv = tid >> 6, ln = tid & 63;
-        double big = 0.0;
-        for (int a = wv; a < N; a += 4) {      // wavefront per model, lanes over the workgroups
-            double am = 0.0;
-            for (int w = ln; w < wgs; w += 64) am = fmax(am, amax[((int64_t)o * wgs + w) * N + a]);
-            am = wave_max(am);
-            if (ln == 0) { r[N * N + a] = (am > 1.0e-6) ? 1.0 : 0.0; r[N * N + N + a] = (am > 0.0) ? 1.0 : 0.0; }
-            big = fmax(big, am);
+        double s = 0.0;
+        for (int w0 = ln; w0 < wgs; w0 += 256) {
+            double v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = (w0 + 64 * i < wgs) ? p[(int64_t)(w0 + 64 * i) * nsym].x : 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) s += v[i];
         }
-        if (ln == 0) big_s[wv] = big;
-        __syncthreads();
-        if (tid == 0) r[N * N + 2 * N] = (fmax(fmax(big_s[0], big_s[1]), fmax(big_s[2], big_s[3])) >= 0.05) ? 1.0 : 0.0;
+        s = fast_sum(s);
+        if (ln == 0) {
+            // destination d = (a, b), a <= b, in the row-major order of the upper triangle
+            int a = 0, rem = d;
+            while (rem >= N - a) { rem -= N - a; a++; }
+            const int b = a + rem;
+            r[a * N + b] = s;
+            r[b * N + a] = s;
+        }
+    } else if (d <= nsym + N) {
+        const int a = d - nsym;                  // model a, or a == N: the maximum over all models
+        double am = 0.0;
+        for (int w0 = ln; w0 < wgs; w0 += 256) {
+            double v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = (w0 + 64 * i < wgs) ? amax[((int64_t)o * wgs + w0 + 64 * i) * (N + 1) + a] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) am = fmax(am, v[i]);
+        }
+        am = fast_max(am);
+        if (ln == 0) {
+            if (a < N) { r[N * N + a] = (am > 1.0e-6) ? 1.0 : 0.0; r[N * N + N + a] = (am > 0.0) ? 1.0 : 0.0; }
+            else r[N * N + 2 * N] = (am >= 0.05) ? 1.0 : 0.0;
+        }
     }
 }
 
@@ -314,14 +364,14 @@ __global__ __launch_bounds__(64 * (MF_TILE_WAVES + 1)) void k_solve_grad_mf(cons
     for (int t = tid; t < N * N; t += NTHREADS) { lds.at(t / N, t % N) = rec_o[t]; mf_cs[t] = A.C[(int64_t)o * N * N + t]; }
     const int t_mine = A.tile_begin[o] + b * MF_TILE_WAVES + wave - 1;
     MfTile td;
-    td.first = 0; td.n = 0; td.k = 0; td.gbyte = 0;
+    td.first = 0; td.n = 0; td.k = 0;
     if (wave > 0 && t_mine < A.tile_begin[o + 1]) td = A.tiles[t_mine];
     __syncthreads();
     // the tile wavefronts keep their factor in registers across the barrier (KU = largest group size of the plan: 21 + 6 doubles at 6)
     int idx[KU];
     double a[mf_ke(KU)], r[KU];
     const bool valid = lane < td.n;
-    const uint8_t *gl = A.groups[o] + td.gbyte + (int64_t)lane * td.k;
+    const uint64_t gl = valid ? A.groups[o][(int64_t)td.first + lane] : 0ull;      // the group's model indices, a byte each
     if (wave == 0) {
         const bool s1 = lane < N && rec_o[N * N + lane] > 0.0;
         const bool s2 = lane < N && rec_o[N * N + N + lane] > 0.0;
@@ -360,6 +410,16 @@ __global__ __launch_bounds__(64 * (MF_TILE_WAVES + 1)) void k_solve_grad_mf(cons
     if (valid) grad[A.goff[o] + td.first + lane] = inf ? INFINITY : -q;
 }
 
+// the k model indices of every group of one size (bytes, the plan's list) -> one 8-byte word per group: one coalesced load per lane
+__global__ __launch_bounds__(256) void k_mf_pack(const uint8_t *__restrict__ gk, int k, int64_t Lk, uint64_t *__restrict__ out)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= Lk) return;
+    uint64_t w = 0ull;
+    for (int j = 0; j < k; j++) w |= (uint64_t)gk[g * k + j] << (8 * j);
+    out[g] = w;
+}
+
 // eligibility: every block safely positive definite (see the header)
 __global__ __launch_bounds__(256) void k_mf_check(const MfArgs A, int32_t *__restrict__ flag)
 {
@@ -371,7 +431,7 @@ __global__ __launch_bounds__(256) void k_mf_check(const MfArgs A, int32_t *__res
     for (int t = A.tile_begin[o] + blockIdx.x * 4 + wave; t < A.tile_begin[o + 1]; t += gridDim.x * 4) {
         const MfTile td = A.tiles[t];
         const bool valid = lane < td.n;
-        const uint8_t *gl = A.groups[o] + td.gbyte + (int64_t)lane * td.k;
+        const uint64_t gl = valid ? A.groups[o][(int64_t)td.first + lane] : 0ull;
         double worst = 1.0;
 #define MFK(KK) case KK: { int ik[KK]; double ak[mf_ke(KK)], rk[KK]; mf_load_block<KK>(gl, valid, mf_cc, N, ik, ak); worst = mf_chol<KK>(ak, rk); break; }
         switch (td.k) { MFK(1) MFK(2) MFK(3) MFK(4) MFK(5) MFK(6) MFK(7) MFK(8) default: worst = 0.0; }
@@ -417,15 +477,15 @@ int mf_finalize(bluest_plan_t plan)
     for (int o = 0; o < n_out; o++) {
         const OutputDesc &od = plan->outs[o];
         S->tile_begin[o] = (int32_t)tiles.size();
-        int64_t first = 0, gb = 0;
+        int64_t first = 0;
         for (int k = 1; k <= od.K; k++) {
             const int64_t Lk = od.sizes[k - 1];
             for (int64_t t = 0; t < Lk; t += 64) {
                 MfTile td;
-                td.first = (int32_t)(first + t); td.n = (int16_t)std::min<int64_t>(64, Lk - t); td.k = (int16_t)k; td.gbyte = gb + t * k;
+                td.first = (int32_t)(first + t); td.n = (int16_t)std::min<int64_t>(64, Lk - t); td.k = (int16_t)k;
                 tiles.push_back(td);
             }
-            first += Lk; gb += Lk * k;
+            first += Lk;
         }
     }
     S->tile_begin[n_out] = (int32_t)tiles.size();
@@ -449,10 +509,19 @@ int mf_finalize(bluest_plan_t plan)
         }
     }
     const int reclen = N * N + 2 * N + 1;
+    // packed model indices: one list per DISTINCT group list (outputs that share output 0's list share its packing)
+    std::vector<int64_t> pk_off((size_t)n_out, 0);
+    int64_t pk_words = 0;
+    for (int o = 0; o < n_out; o++) {
+        if (o > 0 && plan->outs[o].d_groups == plan->outs[0].d_groups) { pk_off[(size_t)o] = 0; continue; }
+        pk_off[(size_t)o] = pk_words;
+        pk_words += plan->outs[o].L_o;
+    }
+    const size_t b_pk = al((size_t)pk_words * 8);
     const size_t b_tiles = al(tiles.size() * sizeof(MfTile)), b_tb = al((n_out + 1) * sizeof(int32_t)), b_C = al((size_t)n_out * N * N * 8),
                  b_gp = al(n_out * sizeof(void *)), b_map = al(map.size() * sizeof(int32_t)), b_part = al((size_t)n_out * S->wgs * S->nsym * sizeof(double2)),
-                 b_amax = al((size_t)n_out * S->wgs * N * 8), b_rec = al((size_t)n_out * reclen * 8), b_flag = al(sizeof(int32_t));
-    const size_t total = b_tiles + b_tb + b_C + b_gp + b_map + b_part + b_amax + b_rec + b_flag;
+                 b_amax = al((size_t)n_out * S->wgs * (N + 1) * 8), b_rec = al((size_t)n_out * reclen * 8), b_flag = al(sizeof(int32_t));
+    const size_t total = b_tiles + b_tb + b_C + b_gp + b_map + b_part + b_amax + b_rec + b_flag + b_pk;
     DeviceScopeN scope(plan->device);
     hipError_t e = pool_alloc(&S->blob, total);
     if (e != hipSuccess) { delete S; HIP_TRY(e); }
@@ -460,15 +529,26 @@ int mf_finalize(bluest_plan_t plan)
     S->d_tiles = reinterpret_cast<MfTile *>(d); d += b_tiles;
     S->d_tile_begin = reinterpret_cast<int32_t *>(d); d += b_tb;
     S->d_C = reinterpret_cast<double *>(d); d += b_C;
-    S->d_groups = reinterpret_cast<const uint8_t **>(d); d += b_gp;
+    S->d_groups = reinterpret_cast<const uint64_t **>(d); d += b_gp;
     S->d_map = map.empty() ? nullptr : reinterpret_cast<int32_t *>(d); d += b_map;
     S->d_partial = reinterpret_cast<double2 *>(d); d += b_part;
     S->d_amax = reinterpret_cast<double *>(d); d += b_amax;
     S->d_rec = reinterpret_cast<double *>(d); d += b_rec;
-    S->d_flag = reinterpret_cast<int32_t *>(d);
+    S->d_flag = reinterpret_cast<int32_t *>(d); d += b_flag;
+    S->d_packed = reinterpret_cast<uint64_t *>(d);
     plan->mf = S;
-    std::vector<const uint8_t *> gp((size_t)n_out);
-    for (int o = 0; o < n_out; o++) gp[(size_t)o] = plan->outs[o].d_groups;
+    std::vector<const uint64_t *> gp((size_t)n_out);
+    for (int o = 0; o < n_out; o++) {
+        gp[(size_t)o] = S->d_packed + pk_off[(size_t)o];
+        if (o > 0 && plan->outs[o].d_groups == plan->outs[0].d_groups) continue;
+        const OutputDesc &od = plan->outs[o];
+        int64_t first = 0, gb = 0;
+        for (int k = 1; k <= od.K; k++) {
+            const int64_t Lk = od.sizes[k - 1];
+            if (Lk > 0) hipLaunchKernelGGL(k_mf_pack, dim3((unsigned)((Lk + 255) / 256)), dim3(256), 0, 0, od.d_groups + gb, k, Lk, S->d_packed + pk_off[(size_t)o] + first);
+            first += Lk; gb += Lk * k;
+        }
+    }
     hipError_t err = hipMemcpy(S->d_tiles, tiles.data(), tiles.size() * sizeof(MfTile), hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(S->d_tile_begin, S->tile_begin.data(), (n_out + 1) * sizeof(int32_t), hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy((void *)S->d_groups, gp.data(), n_out * sizeof(void *), hipMemcpyHostToDevice);
@@ -517,7 +597,7 @@ int mf_phi_record(bluest_plan_t plan, const double *m_dev, double *rec_dev, cons
     const dim3 grid((unsigned)S->wgs, (unsigned)A.n_out);
     if (S->nw == 8) hipLaunchKernelGGL(k_phi_matfree<8>, grid, dim3(512), S->lds_phi, st, A, m_dev, S->d_partial, S->d_amax);
     else hipLaunchKernelGGL(k_phi_matfree<4>, grid, dim3(256), S->lds_phi, st, A, m_dev, S->d_partial, S->d_amax);
-    hipLaunchKernelGGL(k_mf_reduce, dim3((unsigned)((S->nsym + 15) / 16), (unsigned)A.n_out), dim3(256), 0, st, A.N, S->nsym, S->wgs,
+    hipLaunchKernelGGL(k_mf_reduce, dim3((unsigned)((S->nsym + A.N + 1 + 3) / 4), (unsigned)A.n_out), dim3(256), 0, st, A.N, S->nsym, S->wgs,
                        S->d_partial, S->d_amax, rec);
     if (rec_used) *rec_used = rec;
     HIP_TRY(hipGetLastError());
@@ -566,9 +646,7 @@ extern "C" int bluest_plan_matfree(bluest_plan_t plan, int *matfree, int64_t *mf
         int64_t b = 0;
         const MfState *S = reinterpret_cast<const MfState *>(plan->mf);
         for (const auto &od : plan->outs) {
-            int64_t gb = 0;
-            for (int k = 1; k <= od.K; k++) gb += od.sizes[k - 1] * k;
-            b += 2 * gb + 2 * od.L_o * 8;
+            b += 2 * od.L_o * 8 + 2 * od.L_o * 8;      // packed indices (8 bytes per group) in both passes, m in, gradient out
         }
         if (S) b += 2 * (int64_t)plan->outs.size() * S->wgs * (S->nsym * 16 + plan->N * 8) + 2 * (int64_t)plan->outs.size() * plan->N * plan->N * 8;
         *mf_bytes = b;

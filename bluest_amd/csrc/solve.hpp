@@ -49,6 +49,38 @@ __device__ __forceinline__ double readlane_f64(double x, int l)
     return __hiloint2double(hi, lo);
 }
 
+// Cross-lane reductions without the LDS crossbar.  __shfl_xor compiles to ds_bpermute (two per double, ~100 cycles each, in a
+// dependent chain of six for a wave reduction); the master is a latency chain of short reductions, so they are done with DPP
+// moves instead: quad permutes, then row_half_mirror / row_mirror inside the 16-lane rows (every lane ends with its row's result),
+// then the four rows are combined through v_readlane.  Fixed order, all lanes get the same value.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum(double v)
+{   // sum over the lane's 16-lane row, in every lane of the row
+    v += dpp_f64<0xB1>(v);      // quad_perm:[1,0,3,2]
+    v += dpp_f64<0x4E>(v);      // quad_perm:[2,3,0,1]
+    v += dpp_f64<0x141>(v);     // row_half_mirror
+    v += dpp_f64<0x140>(v);     // row_mirror
+    return v;
+}
+__device__ __forceinline__ double fast_sum(double v)
+{
+    v = row_sum(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+__device__ __forceinline__ double fast_max(double v)
+{
+    v = fmax(v, dpp_f64<0xB1>(v));
+    v = fmax(v, dpp_f64<0x4E>(v));
+    v = fmax(v, dpp_f64<0x141>(v));
+    v = fmax(v, dpp_f64<0x140>(v));
+    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
 // fold chunk partials of rows [row_begin, row_begin+n_rows) into lds.phi / lds.amax; all threads of the block.
 // FOUR adjacent lanes share a row: lane q sums chunks q, q+4, q+8, ... (up to 8 independent loads in flight, so a row of
 // <= 32 chunks costs ONE memory round trip), then the quad combines as (s0+s1)+(s2+s3) -- a fixed order, so the result

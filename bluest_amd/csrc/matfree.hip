@@ -410,6 +410,29 @@ __global__ __launch_bounds__(64 * (MF_TILE_WAVES + 1)) void k_solve_grad_mf(cons
     if (valid) grad[A.goff[o] + td.first + lane] = inf ? INFINITY : -q;
 }
 
+// gradient pass alone from a given v (bluest_plan_grad on a matrix-free plan): one wavefront per tile, four per workgroup; the same
+// factor and the same forward substitution as the fused kernel: identical bits
+__global__ __launch_bounds__(256) void k_grad_mf(const MfArgs A, const double *__restrict__ v, const int32_t *__restrict__ status, double *__restrict__ grad)
+{
+    extern __shared__ double mf_gs[];          // [N*N covariance][N v]
+    const int N = A.N, o = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double *vs = mf_gs + N * N;
+    for (int t = tid; t < N * N; t += 256) mf_gs[t] = A.C[(int64_t)o * N * N + t];
+    if (tid < N) vs[tid] = v[(int64_t)o * N + tid];
+    __syncthreads();
+    const bool inf = status[o] == BLUEST_EVAL_INF;
+    for (int t = A.tile_begin[o] + blockIdx.x * 4 + wave; t < A.tile_begin[o + 1]; t += gridDim.x * 4) {
+        const MfTile td = A.tiles[t];
+        const bool valid = lane < td.n;
+        const uint64_t gl = valid ? A.groups[o][(int64_t)td.first + lane] : 0ull;
+        double q = 0.0;
+#define MFG(KK) case KK: { int ik[KK]; double ak[mf_ke(KK)], rk[KK]; mf_load_block<KK>(gl, valid, mf_gs, N, ik, ak); (void)mf_chol<KK>(ak, rk); q = mf_quad<KK>(ak, rk, ik, vs); break; }
+        switch (td.k) { MFG(1) MFG(2) MFG(3) MFG(4) MFG(5) MFG(6) MFG(7) MFG(8) default: break; }
+#undef MFG
+        if (valid) grad[A.goff[o] + td.first + lane] = inf ? INFINITY : -q;
+    }
+}
+
 // the k model indices of every group of one size (bytes, the plan's list) -> one 8-byte word per group: one coalesced load per lane
 __global__ __launch_bounds__(256) void k_mf_pack(const uint8_t *__restrict__ gk, int k, int64_t Lk, uint64_t *__restrict__ out)
 {
@@ -651,5 +674,19 @@ extern "C" int bluest_plan_matfree(bluest_plan_t plan, int *matfree, int64_t *mf
         if (S) b += 2 * (int64_t)plan->outs.size() * S->wgs * (S->nsym * 16 + plan->N * 8) + 2 * (int64_t)plan->outs.size() * plan->N * plan->N * 8;
         *mf_bytes = b;
     }
+    return BLUEST_OK;
+}
+
+// gradient of this plan's groups from given v / status (one candidate)
+int mf_grad(bluest_plan_t plan, const double *v_dev, const int32_t *status_dev, double *grad_dev, hipStream_t st)
+{
+    MfState *S = reinterpret_cast<MfState *>(plan->mf);
+    if (!S) return fail(BLUEST_ERR_STATE, "matrix-free state missing");
+    const MfArgs A = mf_args(plan);
+    int64_t most = 0;
+    for (int o = 0; o < A.n_out; o++) most = std::max<int64_t>(most, S->tile_begin[o + 1] - S->tile_begin[o]);
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((most + 3) / 4, 1024 / std::max(1, A.n_out)));
+    hipLaunchKernelGGL(k_grad_mf, dim3(gx, (unsigned)A.n_out), dim3(256), (size_t)(A.N * A.N + A.N) * 8, st, A, v_dev, status_dev, grad_dev);
+    HIP_TRY(hipGetLastError());
     return BLUEST_OK;
 }

@@ -1847,6 +1847,7 @@ extern "C" int bluest_plan_grad(bluest_plan_t plan, const double *v_dev, const i
     if (!v_dev || !status_dev || !grad_dev) return fail(BLUEST_ERR_ARG, "null pointer");
     if (n_cand > 1 && grad_stride < plan->grad_len) return fail(BLUEST_ERR_ARG, "grad_stride < grad_len");
     const int n_out = (int)plan->outs.size();
+    if (plan->matfree && n_cand == 1 && !plan->gate) return mf_grad(plan, v_dev, status_dev, grad_dev, (hipStream_t)stream);
     launch_grad(plan, v_dev, status_dev, n_cand, grad_dev, grad_stride, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;

@@ -208,3 +208,4 @@ int mf_finalize(bluest_plan_t plan);
 void mf_release(bluest_plan_s *p);
 int mf_phi_record(bluest_plan_t plan, const double *m_dev, double *rec_dev, const double **rec_used, hipStream_t st);
 int mf_solve_grad(bluest_plan_t plan, const double *rec_dev, double delta, double *var_dev, int32_t *status_dev, double *grad_dev, hipStream_t st);
+int mf_grad(bluest_plan_t plan, const double *v_dev, const int32_t *status_dev, double *grad_dev, hipStream_t st);

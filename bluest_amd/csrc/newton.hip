@@ -70,8 +70,9 @@ struct MasterLds {                     // carved out of dynamic LDS by master_ca
 __host__ __device__ inline size_t master_lds_bytes(int N, int n_out, int S, int KM)
 {
     const size_t LDN = N + 1, LDM = (S + MASTER_NE + 1) | 1, KE = (size_t)KM * (KM + 1) / 2, ND = (size_t)N * (N + 1) / 2;
-    size_t d = (size_t)n_out * master_phi_doubles(N) + (size_t)MASTER_PACT * N * LDN + (size_t)S * n_out * KE + (size_t)S * LDM +
-               (size_t)MASTER_PACT * S * KM + (size_t)S * MASTER_PACT + 8 * (size_t)S + 6 * (size_t)n_out + 256 + 3 * 64 + (size_t)N + 2 * 72;
+    const size_t PA = n_out < MASTER_PACT ? n_out : MASTER_PACT;      // active outputs there can be: T and the a_{o,j} are kept for those only
+    size_t d = (size_t)n_out * master_phi_doubles(N) + PA * N * LDN + (size_t)S * n_out * KE + (size_t)S * LDM +
+               PA * S * KM + (size_t)S * MASTER_PACT + 8 * (size_t)S + 6 * (size_t)n_out + 256 + 3 * 64 + (size_t)N + 2 * 72;
     size_t bytes = d * sizeof(double) + (3 * (size_t)S + 2 * MASTER_PACT + 48 + 64 + 2 * MASTER_MCAP) * sizeof(int) + (size_t)S * N + (size_t)S * KM + 64;
     bytes = (bytes + 7) & ~(size_t)7;
     bytes += (2 * ND + 2 + (size_t)S * KE + 8) * sizeof(unsigned short);
@@ -83,10 +84,11 @@ __device__ inline void master_carve(MasterLds &L, unsigned char *base, int N, in
     L.LDN = N + 1; L.LDM = (S + MASTER_NE + 1) | 1; L.KE = KM * (KM + 1) / 2; L.ND = N * (N + 1) / 2; L.PHS = master_phi_doubles(N);
     double *p = reinterpret_cast<double *>(base);
     L.PHI = p;  p += (size_t)n_out * L.PHS;
-    L.TACT = p; p += (size_t)MASTER_PACT * N * L.LDN;
+    const size_t PA = n_out < MASTER_PACT ? n_out : MASTER_PACT;
+    L.TACT = p; p += PA * N * L.LDN;
     L.BLK = p;  p += (size_t)S * n_out * L.KE;
     L.M = p;    p += (size_t)S * L.LDM;
-    L.AAC = p;  p += (size_t)MASTER_PACT * S * KM;
+    L.AAC = p;  p += PA * S * KM;
     L.GQ = p;   p += (size_t)S * MASTER_PACT;
     L.x = p; p += S; L.xt = p; p += S; L.xp = p; p += S; L.d = p; p += S; L.cc = p; p += S; L.Dm = p; p += S; L.glv = p; p += S; L.mvec = p; p += S;
     L.r = p; p += n_out; L.rt = p; p += n_out; L.rp = p; p += n_out; L.mu = p; p += n_out; L.mup = p; p += n_out; L.muh = p; p += n_out;

@@ -348,8 +348,11 @@ def test_spg_beats_the_reference_spg_and_is_certified_n12_all_groups(oracle):
     V = sap.variance(m)
     assert V < float(golden("spg_bound_n12_all.npz")["best_f"])
     gap, Vs, _ = _certify(oracle, prob["C"], 12, prob["groups"], prob["costs"], m)
-    assert abs(V / Vs[0] - 1) < 1e-10 and gap <= 1e-6, gap
-    assert _check_solver_certificate(oracle, prob["C"], 12, prob["groups"], prob["costs"], m, sap.solver_info) <= 1e-6
+    assert abs(V / Vs[0] - 1) < 1e-10 and gap <= 1e-6, gap            # (the CPU dual solve itself stops at SLSQP's accuracy)
+    # the solver's own certificate, and the same bound re-evaluated with oracle arithmetic: round 4 reaches 3e-11 here; 1e-9 is the
+    # arithmetic floor of these problems (cond(Phi(m*)) * eps: the evaluated objective itself is no more accurate)
+    assert sap.solver_info["certified_gap"] <= 1e-9, sap.solver_info["certified_gap"]
+    assert _check_solver_certificate(oracle, prob["C"], 12, prob["groups"], prob["costs"], m, sap.solver_info) <= 2e-9
 
 
 def test_spg_optimum_is_certified_n20_k5_single_output(oracle):
@@ -362,6 +365,8 @@ def test_spg_optimum_is_certified_n20_k5_single_output(oracle):
     gap, Vs, _ = _certify(oracle, prob["C"], 5, prob["groups"], prob["costs"], m)
     assert abs(sap.variance(m) / Vs[0] - 1) < 1e-10
     assert 0 <= gap + 1e-12 and gap <= 1e-6, (gap, sap.solver_info)
+    assert sap.solver_info["certified_gap"] <= 1e-9, sap.solver_info["certified_gap"]
+    assert _check_solver_certificate(oracle, prob["C"], 5, prob["groups"], prob["costs"], m, sap.solver_info) <= 2e-9
 
 
 def test_spg_optimum_is_certified_n20_k5_o8(oracle):
@@ -377,7 +382,8 @@ def test_spg_optimum_is_certified_n20_k5_o8(oracle):
     gap, Vs, mu = _certify(oracle, prob["C"], kmax, groups, prob["costs"], m)
     assert np.abs(np.array(mos.variances(m)) / Vs - 1).max() < 1e-10
     assert gap <= 1e-6, (gap, Vs.max(), mu, mos.solver_info)
-    assert _check_solver_certificate(oracle, prob["C"], kmax, groups, prob["costs"], m, mos.solver_info) <= 1e-6
+    assert mos.solver_info["certified_gap"] <= 2e-9, mos.solver_info["certified_gap"]
+    assert _check_solver_certificate(oracle, prob["C"], kmax, groups, prob["costs"], m, mos.solver_info) <= 3e-9
 
 
 def test_spg_optimum_is_certified_n25_k6(oracle):
@@ -389,6 +395,31 @@ def test_spg_optimum_is_certified_n25_k6(oracle):
     gap, Vs, _ = _certify(oracle, prob["C"], 6, prob["groups"], prob["costs"], m)
     assert abs(sap.variance(m) / Vs[0] - 1) < 1e-10
     assert gap <= 1e-6, (gap, sap.solver_info)
+    assert sap.solver_info["certified_gap"] <= 1e-8, sap.solver_info["certified_gap"]      # 4.8e-9 in round 4
+
+
+def test_ns_paper_ragged_certificate_under_perturbed_parameters(oracle):
+    """the ragged Navier-Stokes problem in eps mode (five of six outputs tie, cond(Phi) up to 1.5e11) under small changes of the
+    multiplicative phase's parameters: the allocation's cost moves in the 8th digit and the CERTIFIED gap stays below 5e-6 -- the
+    arithmetic floor of this problem is cond * eps = 1.7e-5 (round 3: up to 4e-5; tools/ns_robustness.py prints the whole table)"""
+    from bluest_amd.mosap import MOSAP
+    from conftest import golden
+    from test_oracle import _ns_case
+    G = golden("ns_paper_known_answer.npz")
+    n_out, kmax = int(G["n_out"]), int(G["kmax"])
+    groups, maps, multi = _ns_case(G, "ragged")
+    Cs = [G["C%d" % o] for o in range(n_out)]
+    costs = synth.group_costs(groups, G["costs"])
+    seen = []
+    for prm in ({}, {"ma_p": 31.0}, {"ma_p": 33.0}, {"ma_p": 28.0}, {"ma_iterations": 190}, {"ma_iterations": 210}):
+        mos = MOSAP(Cs, kmax, [kmax] * n_out, [g.tolist() for g in groups], [[g.tolist() for g in mg] for mg in multi], costs,
+                    [synth.group_costs(mg, G["costs"]) for mg in multi], verbose=False)
+        m = mos.solve(eps=list(G["eps"]), solver="spg", continuous_relaxation=True, solver_params={"newton": prm})
+        assert m is not None and mos.solver_info.get("method") == "newton", (prm, mos.solver_info)
+        seen.append((float(m @ costs), float(mos.solver_info["certified_gap"])))
+        assert mos.solver_info["certified_gap"] <= 5e-6, (prm, mos.solver_info["certified_gap"])
+    cost0 = seen[0][0]
+    assert max(abs(c / cost0 - 1) for c, _ in seen) < 5e-6, seen
 
 
 def test_ns_paper_eps_mode_end_to_end_is_certified(oracle):

@@ -234,3 +234,21 @@ def test_second_order_finish_on_tiny_problems(gpu, oracle, n, kmax, n_out):
     m2 = mos.solve(eps=eps, solver="spg", continuous_relaxation=True)
     ratios = np.array(mos.variances(m2)) / eps ** 2
     assert m2 is not None and ratios.max() <= 1 + 1e-9 and abs(ratios.max() - 1) < 1e-9 and mos.solver_info["certified_gap"] <= 1e-6
+
+
+@pytest.mark.parametrize("n,kmax,n_out", [(48, 2, 1), (36, 3, 4), (40, 3, 2), (30, 3, 4)])
+def test_second_order_finish_beyond_32_models(gpu, n, kmax, n_out):
+    """the default solver must not fall off a cliff at the sizes where the master's registers end (more than 32 models: Phi is
+    eliminated out of LDS) or where its LDS budget bites (many outputs at large N): the second-order finish runs and its certified
+    gap closes to 1e-5 or better (round 3: the first-order fall-back ended 1e-4 .. 3e-3 above the optimum there)"""
+    from bluest_amd.mosap import MOSAP
+    prob = synth.problem(n, kmax, n_out)
+    groups, w, B = prob["groups"], prob["costs"], prob["budget"]
+    mos = MOSAP(prob["C"], kmax, [kmax] * n_out, [g.copy() for g in groups], [[g.copy() for g in groups] for _ in range(n_out)], w, [w] * n_out,
+                verbose=False)
+    m = mos.solve(budget=B, solver="spg", continuous_relaxation=True)
+    info = dict(mos.solver_info)
+    assert m is not None and info.get("method") == "newton", info
+    assert info["certified_gap"] <= 1e-5, info
+    assert (m >= 0).all() and abs(m @ w / B - 1) < 1e-9
+    assert abs(max(mos.variances(m)) / info["f"] - 1) < 1e-9

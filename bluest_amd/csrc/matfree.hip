@@ -346,7 +346,8 @@ __device__ __forceinline__ double mf_quad(const double (&a)[mf_ke(K)], const dou
 
 template <int NT, int KU>
 __global__ __launch_bounds__(64 * (MF_TILE_WAVES + 1)) void k_solve_grad_mf(const MfArgs A, const double *__restrict__ rec, double delta,
-                                                                           const int32_t *__restrict__ wg_begin,
+                                                                           const RowDesc *__restrict__ rows, FoldReg reg, const double2 *__restrict__ partial,
+                                                                           const int32_t *__restrict__ wg_begin, int bpo,
                                                                            double *__restrict__ var, double *__restrict__ v_ws,
                                                                            int32_t *__restrict__ status, double *__restrict__ grad)
 {
@@ -354,14 +355,23 @@ __global__ __launch_bounds__(64 * (MF_TILE_WAVES + 1)) void k_solve_grad_mf(cons
     __shared__ SolveLds<NT> lds;
     extern __shared__ double mf_cs[];          // [N*N] covariance of this workgroup's output
     const int N = A.N, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // which output: the workgroups of output o are [wg_begin[o], wg_begin[o + 1])
-    int o = 0;
-    while (o + 1 < A.n_out && (int)blockIdx.x >= wg_begin[o + 1]) o++;
-    const int b = blockIdx.x - wg_begin[o];
+    // which output: the workgroups of output o are [wg_begin[o], wg_begin[o + 1]) -- arithmetic when every output has the same number
+    // (bpo > 0, the usual case: a search through the table is a chain of dependent loads in front of everything else)
+    int o = 0, b = 0;
+    if (bpo > 0) { o = blockIdx.x / bpo; b = blockIdx.x - o * bpo; }
+    else {
+        while (o + 1 < A.n_out && (int)blockIdx.x >= wg_begin[o + 1]) o++;
+        b = blockIdx.x - wg_begin[o];
+    }
     const bool first = b == 0;
-    const double *rec_o = rec + (int64_t)o * (N * N + 2 * N + 1);
+    // Phi_o from the record (matrix-free Phi pass, all-reduced record of a sharded plan), or -- rec == NULL -- folded from the chunk
+    // partials of the STORED Phi pass (plans whose Phi layout fits the L2s keep that pass: it is a pure stream there, and without the
+    // gradient pass's tile stream next to it, it stays L2-resident from step to step)
+    const double *rec_o = rec ? rec + (int64_t)o * (N * N + 2 * N + 1) : nullptr;
     if (N < NT) { clear_pads(lds, N, tid, NTHREADS); __syncthreads(); }
-    for (int t = tid; t < N * N; t += NTHREADS) { lds.at(t / N, t % N) = rec_o[t]; mf_cs[t] = A.C[(int64_t)o * N * N + t]; }
+    for (int t = tid; t < N * N; t += NTHREADS) mf_cs[t] = A.C[(int64_t)o * N * N + t];
+    if (rec_o) { for (int t = tid; t < N * N; t += NTHREADS) lds.at(t / N, t % N) = rec_o[t]; }
+    else fold_rows<NT>(lds, N, rows, o * A.nsym, A.nsym, partial, tid, NTHREADS, reg);
     const int t_mine = A.tile_begin[o] + b * MF_TILE_WAVES + wave - 1;
     MfTile td;
     td.first = 0; td.n = 0; td.k = 0;
@@ -373,9 +383,17 @@ __global__ __launch_bounds__(64 * (MF_TILE_WAVES + 1)) void k_solve_grad_mf(cons
     const bool valid = lane < td.n;
     const uint64_t gl = valid ? A.groups[o][(int64_t)td.first + lane] : 0ull;      // the group's model indices, a byte each
     if (wave == 0) {
-        const bool s1 = lane < N && rec_o[N * N + lane] > 0.0;
-        const bool s2 = lane < N && rec_o[N * N + N + lane] > 0.0;
-        const bool big = rec_o[N * N + 2 * N] > 0.0;
+        bool s1, s2, big;
+        if (rec_o) {
+            s1 = lane < N && rec_o[N * N + lane] > 0.0;
+            s2 = lane < N && rec_o[N * N + N + lane] > 0.0;
+            big = rec_o[N * N + 2 * N] > 0.0;
+        } else {
+            const double am = (lane < N) ? lds.amax[lane] : 0.0;
+            s1 = am > 1.0e-6;
+            s2 = am > 0.0;
+            big = __ballot(am >= 0.05) != 0ull;          // max |m| >= 0.05 (bluest/misc.py:464)
+        }
         double V = 0.0;
         int32_t st = 0;
         solve_wave<NT>(lds, N, delta, s1, s2, big, true, &V, lds.vout, &st, lane);
@@ -476,6 +494,7 @@ void mf_release(bluest_plan_s *p)
     delete S;
     p->mf = nullptr;
     p->matfree = false;
+    p->mf_gradient = false;
 }
 
 static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -484,10 +503,15 @@ static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 int mf_finalize(bluest_plan_t plan)
 {
     plan->matfree = false;
+    plan->mf_gradient = false;
+    // BLUEST_MATFREE: 0 stored inverses everywhere, 1 matrix-free Phi AND gradient, 2 matrix-free gradient behind the stored Phi pass
+    // (an A/B mode: 3 % at the headline size, 6 % at K_tot = 245505 against 12 % for the full form, profiles/r04_matfree_ab.txt);
+    // unset: matrix-free where the stored streams exceed MF_AUTO_BYTES -- there the evaluation is bound by bytes --, stored below
     const char *env = getenv("BLUEST_MATFREE");
-    if (env && atoi(env) == 0) return BLUEST_OK;
-    const bool forced = env && atoi(env) != 0;
-    if (!forced && plan->phi_bytes + plan->grad_bytes < MF_AUTO_BYTES) return BLUEST_OK;
+    const int mode = env ? atoi(env) : -1;
+    if (mode == 0) return BLUEST_OK;
+    if (mode < 0 && plan->phi_bytes + plan->grad_bytes < MF_AUTO_BYTES) return BLUEST_OK;
+    const bool full = mode != 2;
     const int n_out = (int)plan->outs.size(), N = plan->N;
     if (N > 48 || n_out < 1) return BLUEST_OK;      // (LDS of k_solve_grad_mf: the elimination's matrix + the covariance)
     for (const auto &od : plan->outs) if (!od.d_C || od.K > MF_KMAX || !od.d_groups) return BLUEST_OK;
@@ -597,7 +621,8 @@ int mf_finalize(bluest_plan_t plan)
         if (S->nw == 8) (void)hipFuncSetAttribute((const void *)k_phi_matfree<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S->lds_phi);
         else (void)hipFuncSetAttribute((const void *)k_phi_matfree<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)S->lds_phi);
     }
-    plan->matfree = true;
+    plan->mf_gradient = true;
+    plan->matfree = full;
     return BLUEST_OK;
 }
 
@@ -627,7 +652,8 @@ int mf_phi_record(bluest_plan_t plan, const double *m_dev, double *rec_dev, cons
     return BLUEST_OK;
 }
 
-// solve + gradient of this plan's groups from a record: (var, status, v workspace, grad)
+// solve + gradient of this plan's groups from a record (rec_dev == NULL: from the chunk partials the stored Phi pass just left):
+// (var, status, v workspace, grad)
 int mf_solve_grad(bluest_plan_t plan, const double *rec_dev, double delta, double *var_dev, int32_t *status_dev, double *grad_dev, hipStream_t st)
 {
     MfState *S = reinterpret_cast<MfState *>(plan->mf);
@@ -644,12 +670,14 @@ int mf_solve_grad(bluest_plan_t plan, const double *rec_dev, double delta, doubl
         HIP_TRY(pool_alloc((void **)&plan->mf_wg_begin_dev, al((A.n_out + 1) * sizeof(int32_t))));
         HIP_TRY(hipMemcpy(plan->mf_wg_begin_dev, wb.data(), (A.n_out + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
         plan->mf_wgs_grad = wb[(size_t)A.n_out];
+        plan->mf_bpo = wb[1];
+        for (int o = 0; o < A.n_out; o++) if (wb[(size_t)o + 1] - wb[(size_t)o] != wb[1]) plan->mf_bpo = 0;
     }
     const dim3 grid((unsigned)plan->mf_wgs_grad);
     int kmax = 0;
     for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
 #define LMF2(NT, KU) hipLaunchKernelGGL((k_solve_grad_mf<NT, KU>), grid, dim3(64 * (MF_TILE_WAVES + 1)), S->lds_grad, st, A, rec_dev, delta, \
-                                        (const int32_t *)plan->mf_wg_begin_dev, var_dev, plan->d_v, status_dev, grad_dev)
+                                        plan->d_rows, plan->fold_reg, plan->d_partial, (const int32_t *)plan->mf_wg_begin_dev, plan->mf_bpo, var_dev, plan->d_v, status_dev, grad_dev)
 #define LMF(NT) do { if (kmax <= 5) LMF2(NT, 5); else if (kmax <= 6) LMF2(NT, 6); else LMF2(NT, 8); } while (0)
     NT_DISPATCH(plan->N, LMF);
 #undef LMF
@@ -662,7 +690,7 @@ extern "C" int bluest_plan_matfree(bluest_plan_t plan, int *matfree, int64_t *mf
 {
     if (!plan || !matfree) return fail(BLUEST_ERR_ARG, "null pointer");
     if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
-    *matfree = plan->matfree ? 1 : 0;
+    *matfree = plan->matfree ? 1 : (plan->mf_gradient ? 2 : 0);
     if (mf_bytes) {
         // per evaluation: Phi pass and gradient pass each read the groups' model indices (bytes) and m / write the gradient, plus the
         // workgroups' partials (written, then read once) and the covariances

@@ -1847,7 +1847,7 @@ extern "C" int bluest_plan_grad(bluest_plan_t plan, const double *v_dev, const i
     if (!v_dev || !status_dev || !grad_dev) return fail(BLUEST_ERR_ARG, "null pointer");
     if (n_cand > 1 && grad_stride < plan->grad_len) return fail(BLUEST_ERR_ARG, "grad_stride < grad_len");
     const int n_out = (int)plan->outs.size();
-    if (plan->matfree && n_cand == 1 && !plan->gate) return mf_grad(plan, v_dev, status_dev, grad_dev, (hipStream_t)stream);
+    if (plan->mf_gradient && n_cand == 1 && !plan->gate) return mf_grad(plan, v_dev, status_dev, grad_dev, (hipStream_t)stream);
     launch_grad(plan, v_dev, status_dev, n_cand, grad_dev, grad_stride, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
@@ -1874,7 +1874,7 @@ extern "C" int bluest_plan_solve_grad(bluest_plan_t plan, const double *rec_dev,
     const int n_out = (int)plan->outs.size();
     if (state_dev && n_out > SPG_MAX_OUT) return fail(BLUEST_ERR_ARG, "more than %d outputs", SPG_MAX_OUT);
     hipStream_t st = (hipStream_t)stream;
-    if (plan->matfree && !state_dev && !plan->gate) return mf_solve_grad(plan, rec_dev, delta, var_dev, status_dev, grad_dev, st);
+    if (plan->mf_gradient && !state_dev && !plan->gate) return mf_solve_grad(plan, rec_dev, delta, var_dev, status_dev, grad_dev, st);
     int kmax = 0;
     for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
     const dim3 grid((unsigned)(plan->n_tiles / plan->fused_tpb));
@@ -1929,6 +1929,8 @@ static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_
         return BLUEST_OK;
     }
     launch_chunks(plan, m_dev, n_cand, m_stride, st);
+    if (plan->mf_gradient && grad_dev && n_cand == 1 && !dec_state && !plan->gate && !g_debug_solve)
+        return mf_solve_grad(plan, nullptr, delta, var_dev, status, grad_dev, st);      // stored Phi pass + fold, solve and matrix-free gradient
     int kmax = 0;
     for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
     // fused solve + gradient pass (2 launches per evaluation); groups larger than 12 take the generic tile code inside it

@@ -92,10 +92,11 @@ struct bluest_plan_s {
     // second-order finish (newton.hip): descriptor blob of the master problem (plain hipMalloc, grown on demand) and the
     // host-side global -> local group maps it is built from
     // matrix-free evaluation (matfree.hip): chosen at finalize for plans that qualify
-    bool matfree = false;
+    bool matfree = false;        // Phi pass and gradient pass matrix-free
+    bool mf_gradient = false;    // gradient pass matrix-free (also true when matfree): the stored Phi pass + k_solve_grad_mf folding its partials
     void *mf = nullptr;
     int32_t *mf_wg_begin_dev = nullptr;
-    int mf_wgs_grad = 0;
+    int mf_wgs_grad = 0, mf_bpo = 0;
     void *d_master = nullptr;
     size_t master_bytes = 0;
     std::vector<std::vector<int32_t>> inv_host;

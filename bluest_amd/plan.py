@@ -115,7 +115,8 @@ class Plan(object):
         self.reclen = self.N * self.N + 2 * self.N + 1
         mf, mfb = ctypes.c_int(0), ctypes.c_int64(0)
         check(self.lib.bluest_plan_matfree(self._h, ctypes.byref(mf), ctypes.byref(mfb)))
-        self.matfree, self.matfree_bytes = bool(mf.value), mfb.value      # single-candidate evaluations recompute the group inverses (csrc/matfree.hip)
+        # single-candidate evaluations recompute the group inverses (csrc/matfree.hip): Phi and gradient (matfree), or the gradient only
+        self.matfree, self.matfree_gradient, self.matfree_bytes = mf.value == 1, mf.value in (1, 2), mfb.value
 
     def restrict(self, keep, max_candidates=1):
         """a new Plan over the sub-list `keep` (sorted global group indices) of this plan's groups: allocation vectors of length

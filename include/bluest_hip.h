@@ -149,7 +149,10 @@ int bluest_plan_traffic(bluest_plan_t plan, int64_t *phi_bytes, int64_t *grad_by
  * reads the groups' model indices and m only.  Chosen at bluest_plan_finalize for plans that qualify (outputs given by their
  * covariance, group sizes <= 8, <= 48 models, every block safely positive definite) when BLUEST_MATFREE=1, or on its own when the
  * stored streams exceed 64 MB; single-candidate bluest_plan_eval / bluest_plan_phi / bluest_plan_solve_grad then take it.
- * *matfree = 1 if this plan evaluates matrix-free; *mf_bytes = bytes such an evaluation reads and writes per candidate. */
+ * The GRADIENT pass alone is matrix-free on every plan that qualifies (BLUEST_MATFREE=2 forces exactly that, 0 forbids everything): the
+ * stored Phi pass is then followed by one kernel that folds its partials, solves and recomputes the group factors for the gradient.
+ * *matfree = 1: Phi and gradient matrix-free, 2: the gradient only, 0: stored inverses everywhere; *mf_bytes = bytes a fully
+ * matrix-free evaluation reads and writes per candidate. */
 int bluest_plan_matfree(bluest_plan_t plan, int *matfree, int64_t *mf_bytes);
 /* size in doubles of one candidate's Phi-pass result: n_outputs * (N*N + 2*N + 1), see bluest_plan_phi */
 int bluest_plan_phi_len(bluest_plan_t plan, int64_t *len);

@@ -400,8 +400,10 @@ def test_spg_optimum_is_certified_n25_k6(oracle):
 
 def test_ns_paper_ragged_certificate_under_perturbed_parameters(oracle):
     """the ragged Navier-Stokes problem in eps mode (five of six outputs tie, cond(Phi) up to 1.5e11) under small changes of the
-    multiplicative phase's parameters: the allocation's cost moves in the 8th digit and the CERTIFIED gap stays below 5e-6 -- the
-    arithmetic floor of this problem is cond * eps = 1.7e-5 (round 3: up to 4e-5; tools/ns_robustness.py prints the whole table)"""
+    multiplicative phase's parameters: the allocation's cost moves in the 6th digit at most and the CERTIFIED gap stays at or below
+    the arithmetic floor of this problem, cond * eps = 1.5e11 * 1.1e-16 = 1.7e-5 (measured 1e-8 .. 7e-6 depending on the last bits
+    of the trajectory -- any change of rounding, e.g. the matrix-free gradient, reshuffles which; round 3: up to 4e-5;
+    tools/ns_robustness.py prints the whole table)"""
     from bluest_amd.mosap import MOSAP
     from conftest import golden
     from test_oracle import _ns_case
@@ -417,9 +419,9 @@ def test_ns_paper_ragged_certificate_under_perturbed_parameters(oracle):
         m = mos.solve(eps=list(G["eps"]), solver="spg", continuous_relaxation=True, solver_params={"newton": prm})
         assert m is not None and mos.solver_info.get("method") == "newton", (prm, mos.solver_info)
         seen.append((float(m @ costs), float(mos.solver_info["certified_gap"])))
-        assert mos.solver_info["certified_gap"] <= 5e-6, (prm, mos.solver_info["certified_gap"])
+        assert mos.solver_info["certified_gap"] <= 2e-5, (prm, mos.solver_info["certified_gap"])
     cost0 = seen[0][0]
-    assert max(abs(c / cost0 - 1) for c, _ in seen) < 5e-6, seen
+    assert max(abs(c / cost0 - 1) for c, _ in seen) < 2e-5, seen
 
 
 def test_ns_paper_eps_mode_end_to_end_is_certified(oracle):

@@ -20,7 +20,7 @@ for n, k, o in shapes:
     L = prob["K_tot"]
     m = torch.from_numpy(prob["m"][0]).cuda()
     row = {}
-    for mode in ("1", "0"):
+    for mode in ("1", "2", "0"):
         os.environ["BLUEST_MATFREE"] = mode
         plan = Plan(n, L, bench.build_outputs(prob))
         var = torch.empty((1, o), dtype=torch.float64, device="cuda")
@@ -33,7 +33,8 @@ for n, k, o in shapes:
         t_sg = bench.chain_time(torch, lambda: plan.solve_grad(rec, out=(var, grad, st)))
         row[mode] = (plan.matfree, t_step * 1e6, t_phi * 1e6, t_sg * 1e6, plan.matfree_bytes if plan.matfree else plan.phi_bytes + plan.grad_bytes)
         del plan
-    a, b = row["1"], row["0"]
+    a, h, b = row["1"], row["2"], row["0"]
     print("n=%d k<=%d n_out=%d K_tot=%d | matrix-free(%s): step %.2f us (Phi -> record %.2f, solve + gradient from the record %.2f), %.1f MB moved | "
-          "stored: step %.2f us (Phi -> record %.2f, solve + gradient %.2f), %.1f MB streamed | ratio %.2f"
-          % (n, k, o, L, a[0], a[1], a[2], a[3], a[4] / 1e6, b[1], b[2], b[3], b[4] / 1e6, b[1] / a[1]), flush=True)
+          "stored Phi + matrix-free gradient: step %.2f us | stored: step %.2f us (Phi -> record %.2f, solve + gradient %.2f), %.1f MB streamed | "
+          "stored / matrix-free %.2f, stored / hybrid %.2f"
+          % (n, k, o, L, a[0], a[1], a[2], a[3], a[4] / 1e6, h[1], b[1], b[2], b[3], b[4] / 1e6, b[1] / a[1], b[1] / h[1]), flush=True)

@@ -228,6 +228,11 @@ def sap_cpu_baseline(prob, gpu_max_variance, solve_seconds=10.0, setup_cap_s=14.
             m = scale * x
             vals, grads = [], []
             for sp in saps:
+                # model 0 not sampled by any group with |m| > 1e-6: the reference's variance() asserts (bluest/misc.py:470) and its
+                # solve() gives up (sap.py:209-213); variance_GH would silently return another model's variance (misc.py:490)
+                if not (np.abs(m[np.asarray(sp.e) > 0]) > 1.0e-6).any():
+                    vals.append(np.inf); grads.append(None)
+                    continue
                 try:
                     v, g, _ = sp.variance_GH_as_executed(m) if use_ref else sp.variance_GH(m, nohess=True)
                 except AssertionError:

@@ -46,7 +46,7 @@ struct MfState {           // hangs off bluest_plan_s::mf
     const uint64_t **d_groups = nullptr;       // [n_out] device pointers to the packed model indices (8 bytes per group)
     uint64_t *d_packed = nullptr;              // the packed lists (one per distinct group list)
     int32_t *d_map = nullptr;                  // local -> global group index, concatenated like the gradient (NULL: identity)
-    double2 *d_partial = nullptr;              // [n_out][wgs][nsym]
+    double *d_partial = nullptr;               // [n_out][wgs][nsym]
     double *d_amax = nullptr;                  // [n_out][wgs][N + 1]: model-wise max |m|, then their maximum
     double *d_rec = nullptr;                   // [n_out][N*N + 2N + 1]  (evaluations that never leave this GPU)
     int32_t *d_flag = nullptr;                 // k_mf_check: number of blocks that are not safely positive definite
@@ -220,7 +220,7 @@ struct MfArgs {
 };
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_phi_matfree(const MfArgs A, const double *__restrict__ m, double2 *__restrict__ partial,
+__global__ __launch_bounds__(64 * NW) void k_phi_matfree(const MfArgs A, const double *__restrict__ m, double *__restrict__ partial,
                                                          double *__restrict__ amax)
 {
     extern __shared__ double mf_sm[];          // [N*N covariance][NW * nsym sums][NW * N maxima]
@@ -260,12 +260,12 @@ __global__ __launch_bounds__(64 * NW) void k_phi_matfree(const MfArgs A, const d
         td = tdn; pk = pkn; mg = mgn; t = tn;
     }
     __syncthreads();
-    double2 *pout = partial + ((int64_t)o * A.wgs + b) * nsym;
+    double *pout = partial + ((int64_t)o * A.wgs + b) * nsym;
     for (int d = tid; d < nsym; d += 64 * NW) {
         double s = acc[d];
 #pragma unroll
         for (int w = 1; w < NW; w++) s += acc[w * nsym + d];      // wavefront order: fixed
-        pout[d] = make_double2(s, 0.0);
+        pout[d] = s;
     }
     // model-wise maxima of this workgroup, and their maximum in slot N (the "some group has |m| >= 0.05" test of bluest/misc.py:464)
     double am = 0.0;
@@ -285,19 +285,19 @@ __global__ __launch_bounds__(64 * NW) void k_phi_matfree(const MfArgs A, const d
 // results are the destinations, the next N + 1 the model-wise maxima and their maximum (-> the sampled-model flags of
 // bluest/misc.py:453-457, :464).  Lane l folds workgroups l, l + 64, .. with four independent loads in flight (sixteen dependent
 // round trips, as a 16-lane version had them, cost 10 us at 256 workgroups); the lanes combine with the fixed DPP reduction.
-__global__ __launch_bounds__(256) void k_mf_reduce(int N, int nsym, int wgs, const double2 *__restrict__ partial, const double *__restrict__ amax,
+__global__ __launch_bounds__(256) void k_mf_reduce(int N, int nsym, int wgs, const double *__restrict__ partial, const double *__restrict__ amax,
                                                    double *__restrict__ rec)
 {
     const int o = blockIdx.y, tid = threadIdx.x, ln = tid & 63, d = blockIdx.x * 4 + (tid >> 6);
     const int reclen = N * N + 2 * N + 1;
     double *r = rec + (int64_t)o * reclen;
     if (d < nsym) {
-        const double2 *p = partial + (int64_t)o * wgs * nsym + d;
+        const double *p = partial + (int64_t)o * wgs * nsym + d;
         double s = 0.0;
         for (int w0 = ln; w0 < wgs; w0 += 256) {
             double v[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) v[i] = (w0 + 64 * i < wgs) ? p[(int64_t)(w0 + 64 * i) * nsym].x : 0.0;
+            for (int i = 0; i < 4; i++) v[i] = (w0 + 64 * i < wgs) ? p[(int64_t)(w0 + 64 * i) * nsym] : 0.0;
 #pragma unroll
             for (int i = 0; i < 4; i++) s += v[i];
         }
@@ -514,7 +514,7 @@ int mf_finalize(bluest_plan_t plan)
     const bool full = mode != 2;
     const int n_out = (int)plan->outs.size(), N = plan->N;
     if (N > 48 || n_out < 1) return BLUEST_OK;      // (LDS of k_solve_grad_mf: the elimination's matrix + the covariance)
-    for (const auto &od : plan->outs) if (!od.d_C || od.K > MF_KMAX || !od.d_groups) return BLUEST_OK;
+    for (const auto &od : plan->outs) if (od.h_C.size() != (size_t)N * N || od.K > MF_KMAX || !od.d_groups) return BLUEST_OK;
     MfState *S = new MfState();
     S->nsym = N * (N + 1) / 2;
     S->nw = N <= 32 ? 8 : 4;
@@ -538,9 +538,13 @@ int mf_finalize(bluest_plan_t plan)
     S->tile_begin[n_out] = (int32_t)tiles.size();
     S->n_tiles = (int64_t)tiles.size();
     // workgroups of the Phi pass per output: all compute units busy, a tile or more per wavefront
-    int cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, plan->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    static int cus_of[64] = {0};           // (hipGetDeviceProperties costs tens of milliseconds: once per device)
+    const int dv = (plan->device >= 0 && plan->device < 64) ? plan->device : 0;
+    if (!cus_of[dv]) {
+        int c = 0;
+        cus_of[dv] = (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, plan->device) == hipSuccess && c > 0) ? c : 256;
+    }
+    const int cus = cus_of[dv];
     int64_t most = 0;
     for (int o = 0; o < n_out; o++) most = std::max<int64_t>(most, S->tile_begin[o + 1] - S->tile_begin[o]);
     S->wgs = (int)std::max<int64_t>(1, std::min<int64_t>((cus + n_out - 1) / n_out, (most + S->nw - 1) / S->nw));
@@ -566,7 +570,7 @@ int mf_finalize(bluest_plan_t plan)
     }
     const size_t b_pk = al((size_t)pk_words * 8);
     const size_t b_tiles = al(tiles.size() * sizeof(MfTile)), b_tb = al((n_out + 1) * sizeof(int32_t)), b_C = al((size_t)n_out * N * N * 8),
-                 b_gp = al(n_out * sizeof(void *)), b_map = al(map.size() * sizeof(int32_t)), b_part = al((size_t)n_out * S->wgs * S->nsym * sizeof(double2)),
+                 b_gp = al(n_out * sizeof(void *)), b_map = al(map.size() * sizeof(int32_t)), b_part = al((size_t)n_out * S->wgs * S->nsym * sizeof(double)),
                  b_amax = al((size_t)n_out * S->wgs * (N + 1) * 8), b_rec = al((size_t)n_out * reclen * 8), b_flag = al(sizeof(int32_t));
     const size_t total = b_tiles + b_tb + b_C + b_gp + b_map + b_part + b_amax + b_rec + b_flag + b_pk;
     DeviceScopeN scope(plan->device);
@@ -578,7 +582,7 @@ int mf_finalize(bluest_plan_t plan)
     S->d_C = reinterpret_cast<double *>(d); d += b_C;
     S->d_groups = reinterpret_cast<const uint64_t **>(d); d += b_gp;
     S->d_map = map.empty() ? nullptr : reinterpret_cast<int32_t *>(d); d += b_map;
-    S->d_partial = reinterpret_cast<double2 *>(d); d += b_part;
+    S->d_partial = reinterpret_cast<double *>(d); d += b_part;
     S->d_amax = reinterpret_cast<double *>(d); d += b_amax;
     S->d_rec = reinterpret_cast<double *>(d); d += b_rec;
     S->d_flag = reinterpret_cast<int32_t *>(d); d += b_flag;
@@ -601,7 +605,7 @@ int mf_finalize(bluest_plan_t plan)
     if (err == hipSuccess) err = hipMemcpy((void *)S->d_groups, gp.data(), n_out * sizeof(void *), hipMemcpyHostToDevice);
     if (err == hipSuccess && !map.empty()) err = hipMemcpy(S->d_map, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     for (int o = 0; o < n_out && err == hipSuccess; o++)
-        err = hipMemcpy(S->d_C + (size_t)o * N * N, plan->outs[o].d_C, (size_t)N * N * 8, hipMemcpyDeviceToDevice);
+        err = hipMemcpy(S->d_C + (size_t)o * N * N, plan->outs[o].h_C.data(), (size_t)N * N * 8, hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemset(S->d_flag, 0, sizeof(int32_t));
     if (err != hipSuccess) { mf_release(plan); HIP_TRY(err); }
     S->lds_phi = ((size_t)N * N + (size_t)S->nw * S->nsym + (size_t)S->nw * N) * 8;
@@ -699,7 +703,7 @@ extern "C" int bluest_plan_matfree(bluest_plan_t plan, int *matfree, int64_t *mf
         for (const auto &od : plan->outs) {
             b += 2 * od.L_o * 8 + 2 * od.L_o * 8;      // packed indices (8 bytes per group) in both passes, m in, gradient out
         }
-        if (S) b += 2 * (int64_t)plan->outs.size() * S->wgs * (S->nsym * 16 + plan->N * 8) + 2 * (int64_t)plan->outs.size() * plan->N * plan->N * 8;
+        if (S) b += 2 * (int64_t)plan->outs.size() * S->wgs * (S->nsym * 8 + (plan->N + 1) * 8) + 2 * (int64_t)plan->outs.size() * plan->N * plan->N * 8;
         *mf_bytes = b;
     }
     return BLUEST_OK;

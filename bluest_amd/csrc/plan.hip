@@ -802,8 +802,7 @@ static void plan_free_device(bluest_plan_s *p)
     for (auto &od : p->outs) {
         if (od.d_invcov) (void)pool_free(od.d_invcov);
         if (od.d_groups && od.owns_groups) (void)pool_free(od.d_groups);
-        if (od.d_C) (void)pool_free(od.d_C);
-        od.d_invcov = nullptr; od.d_groups = nullptr; od.d_C = nullptr;
+        od.d_invcov = nullptr; od.d_groups = nullptr;
     }
 }
 
@@ -927,8 +926,7 @@ static void output_release(OutputDesc &od)
 {
     if (od.d_invcov) (void)pool_free(od.d_invcov);
     if (od.d_groups && od.owns_groups) (void)pool_free(od.d_groups);
-    if (od.d_C) (void)pool_free(od.d_C);
-    od.d_invcov = nullptr; od.d_groups = nullptr; od.d_C = nullptr;
+    od.d_invcov = nullptr; od.d_groups = nullptr;
 }
 
 extern "C" int bluest_plan_add_output(bluest_plan_t plan, int K, const int64_t *sizes, const int64_t *groups,
@@ -981,9 +979,7 @@ extern "C" int bluest_plan_add_output_cov(bluest_plan_t plan, const double *C, i
             go += Lk * k; io += Lk * k * k;
         }
         // the next output's covariance upload overwrites dC: wait for the kernels (they take ~0.1 ms; the inverses stay on the device)
-        // the covariance itself stays on the device as well (N x N): the matrix-free evaluation recomputes the inverses from it
-        if (rc == BLUEST_OK && pool_alloc((void **)&od.d_C, need) == hipSuccess)
-            (void)hipMemcpyAsync(od.d_C, dC, need, hipMemcpyDeviceToDevice, 0);
+        od.h_C.assign(C, C + (size_t)N * N);      // the covariance itself is kept (5 KB): the matrix-free evaluation recomputes the inverses from it
         if (rc == BLUEST_OK) e = hipStreamSynchronize(0);
         if (rc == BLUEST_OK && e == hipSuccess && invcovs_out)
             e = hipMemcpy(invcovs_out, od.d_invcov, (size_t)od.n_inv * sizeof(double), hipMemcpyDeviceToHost);

@@ -32,7 +32,7 @@ struct OutputDesc {
     uint8_t *d_groups = nullptr;   // DEVICE copy of `groups`, one byte per model index (n <= 64): 8x less to push over PCIe
                                    // than the int64 list (11 MB at K_tot = 245 505); shared with output 0 when the lists are identical
     bool owns_groups = false;
-    double *d_C = nullptr;         // DEVICE copy of the covariance (N x N) when the output was given by it: the matrix-free evaluation
+    std::vector<double> h_C;       // the covariance (N x N) when the output was given by it (host copy: 5 KB; the matrix-free evaluation uploads it)
 };
 
 struct bluest_plan_s {

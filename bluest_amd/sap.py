@@ -233,15 +233,20 @@ class SpgAllocator(object):
         def rescale_to_tolerance(m_h):
             """eps mode: scale the allocation so that max_o V_o/eps_o^2 = 1 (V is homogeneous of degree -1).  The scaling can carry an
             entry across the reference's absolute threshold |m| > 1e-6 (bluest/misc.py:453-457: which models count as sampled), which
-            moves V by ~1e-8 on ill-conditioned data: repeated until the ratio is 1 to rounding (one pass almost always)"""
-            for _ in range(4):
+            moves V by ~1e-8 on ill-conditioned data: repeated until the ratio is 1 to rounding (one pass almost always).  On the
+            Navier-Stokes covariances (cond 1.5e11) the evaluation itself moves by 2e-9 when m is scaled by 1 + 1e-10, so the allocation
+            returned is the one whose EVALUATED ratio was closest to 1, not the last rescaled one"""
+            best = None
+            for _ in range(6):
                 r_now = ratios(plan, m_h)
                 if not np.isfinite(r_now):
                     break
-                m_h = m_h * r_now
+                if best is None or abs(r_now - 1.0) < best[0]:
+                    best = (abs(r_now - 1.0), m_h)
                 if abs(r_now - 1.0) <= 1.0e-12:
                     break
-            return m_h
+                m_h = m_h * r_now
+            return m_h if best is None else best[1]
 
         if budget is not None:
             B = float(budget)

@@ -35,7 +35,7 @@ for rep in range(3):        # rep0 = cold (first launches, hipGraph captures), r
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     out["rep%d" % rep] = {"setup_s": t1 - t0, "solve_s": t2 - t1, "total_s": t2 - t0, "max_V": max(mos.variances(m)),
-                          "nnz": int((m > 1e-9 * m.max()).sum()), "info": {k: (float(v) if not isinstance(v, int) else v) for k, v in mos.solver_info.items()}}
+                          "nnz": int((m > 1e-9 * m.max()).sum()), "info": {k: (v if isinstance(v, (int, str, bool)) else float(v)) for k, v in mos.solver_info.items() if np.ndim(v) == 0 and not isinstance(v, dict)}}
 # PCIe-inclusive operator rate with numpy in / numpy out
 mh = prob["m"][0]
 mos.variance_GH(mh, nohess=True)

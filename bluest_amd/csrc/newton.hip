@@ -52,8 +52,8 @@ struct MasterArgs {
 // register size of the per-output elimination: the matrix of an output is kept REVERSED (solve.hpp: position p = model NT-1-p,
 // row stride NT + 2) so that the DPP elimination of the evaluation reads its row as NT contiguous doubles; 0 = more than 32
 // models: natural layout, elimination out of LDS
-__host__ __device__ constexpr int master_nt(int N) { return N <= 12 ? 12 : N <= 20 ? 20 : N <= 26 ? 26 : N <= 32 ? 32 : 0; }
-__host__ __device__ constexpr int master_phi_doubles(int N) { return master_nt(N) ? master_nt(N) * (master_nt(N) + 2) : N * (N + 1); }
+// nt: the register tile of the instantiation (12 .. 64: Phi reversed with stride nt + 2), or 0 (natural layout, eliminations in LDS)
+__host__ __device__ constexpr int master_phi_doubles(int N, int nt) { return nt ? nt * (nt + 2) : N * (N + 1); }
 
 struct MasterLds {                     // carved out of dynamic LDS by master_carve()
     double *PHI, *TACT, *BLK, *M, *AAC, *GQ;
@@ -67,11 +67,11 @@ struct MasterLds {                     // carved out of dynamic LDS by master_ca
     int LDN, LDM, KE, ND, PHS;         // PHS: doubles per output in PHI
 };
 
-__host__ __device__ inline size_t master_lds_bytes(int N, int n_out, int S, int KM)
+__host__ __device__ inline size_t master_lds_bytes(int N, int n_out, int S, int KM, int nt)
 {
     const size_t LDN = N + 1, LDM = (S + MASTER_NE + 1) | 1, KE = (size_t)KM * (KM + 1) / 2, ND = (size_t)N * (N + 1) / 2;
     const size_t PA = n_out < MASTER_PACT ? n_out : MASTER_PACT;      // active outputs there can be: T and the a_{o,j} are kept for those only
-    size_t d = (size_t)n_out * master_phi_doubles(N) + PA * N * LDN + (size_t)S * n_out * KE + (size_t)S * LDM +
+    size_t d = (size_t)n_out * master_phi_doubles(N, nt) + PA * N * LDN + (size_t)S * n_out * KE + (size_t)S * LDM +
                PA * S * KM + (size_t)S * MASTER_PACT + 8 * (size_t)S + 6 * (size_t)n_out + 256 + 3 * 64 + (size_t)N + 2 * 72;
     size_t bytes = d * sizeof(double) + (3 * (size_t)S + 2 * MASTER_PACT + 48 + 64 + 2 * MASTER_MCAP) * sizeof(int) + (size_t)S * N + (size_t)S * KM + 64;
     bytes = (bytes + 7) & ~(size_t)7;
@@ -79,9 +79,9 @@ __host__ __device__ inline size_t master_lds_bytes(int N, int n_out, int S, int 
     return (bytes + 15) & ~(size_t)15;
 }
 
-__device__ inline void master_carve(MasterLds &L, unsigned char *base, int N, int n_out, int S, int KM)
+__device__ inline void master_carve(MasterLds &L, unsigned char *base, int N, int n_out, int S, int KM, int nt)
 {
-    L.LDN = N + 1; L.LDM = (S + MASTER_NE + 1) | 1; L.KE = KM * (KM + 1) / 2; L.ND = N * (N + 1) / 2; L.PHS = master_phi_doubles(N);
+    L.LDN = N + 1; L.LDM = (S + MASTER_NE + 1) | 1; L.KE = KM * (KM + 1) / 2; L.ND = N * (N + 1) / 2; L.PHS = master_phi_doubles(N, nt);
     double *p = reinterpret_cast<double *>(base);
     L.PHI = p;  p += (size_t)n_out * L.PHS;
     const size_t PA = n_out < MASTER_PACT ? n_out : MASTER_PACT;
@@ -186,6 +186,37 @@ __device__ __forceinline__ bool inverse_wave_lds(double *P, int N, int LDN, int 
 // and two 64-bit selects.  (Folding the pivot row into the same fma as a + (1/piv - 1) a costs the low bits of 1/piv whenever the
 // pivot is large -- relative error eps * piv in T: the master then stalls at a KKT residual of 1e-8.)
 // A model no group of the support touches (no background) has a zero row: identity in, zero out.
+// (The pivot loop is a template recursion: left as a loop, `#pragma unroll` gives up on it at NT = 32 -- 32 steps of 3 NT
+// instructions --, the row is then indexed dynamically and lives in SCRATCH memory: 153 us per inverse instead of 5.)
+template <int NT, int P>
+struct InvRegsStep {
+    static __device__ __forceinline__ void run(double (&a)[NT], int lane, bool &bad)
+    {
+        const double piv = readlane_f64(a[P], P);
+        bad = bad || !(piv > 0.0) || !isfinite(piv);
+        const double rinv = rcp_f64(piv);
+        const bool is = lane == P;
+        if (is) {
+#pragma unroll
+            for (int c = 0; c < NT; c++) if (c != P) a[c] *= rinv;
+        }
+        const double g = is ? 0.0 : -a[P];
+        constexpr int CH = NT <= 20 ? NT : 16;          // broadcasts in flight at once (the row itself takes 2 NT registers)
+#pragma unroll
+        for (int c0 = 0; c0 < NT; c0 += CH) {
+            double u[CH];
+#pragma unroll
+            for (int q = 0; q < CH; q++) if (c0 + q < NT && c0 + q != P) u[q] = readlane_f64(a[c0 + q], P);
+#pragma unroll
+            for (int q = 0; q < CH; q++) if (c0 + q < NT && c0 + q != P) a[c0 + q] = fma(g, u[q], a[c0 + q]);
+        }
+        a[P] = is ? rinv : g * rinv;
+        InvRegsStep<NT, P + 1>::run(a, lane, bad);
+    }
+};
+template <int NT>
+struct InvRegsStep<NT, NT> { static __device__ __forceinline__ void run(double (&)[NT], int, bool &) {} };
+
 template <int NT>
 __device__ __forceinline__ bool inverse_regs(const double *P, double *T, int N, int LDN, int lane)
 {
@@ -200,24 +231,7 @@ __device__ __forceinline__ bool inverse_regs(const double *P, double *T, int N, 
 #pragma unroll
     for (int c = 0; c < NT; c++) if (c == lane && mine && !(a[c] > 0.0)) { untouched = true; a[c] = 1.0; }
     bool bad = false;
-#pragma unroll
-    for (int p = 0; p < NT; p++) {
-        const double piv = readlane_f64(a[p], p);
-        bad = bad || !(piv > 0.0) || !isfinite(piv);
-        const double rinv = rcp_f64(piv);
-        const bool is = lane == p;
-        if (is) {
-#pragma unroll
-            for (int c = 0; c < NT; c++) if (c != p) a[c] *= rinv;
-        }
-        const double g = is ? 0.0 : -a[p];
-        double u[NT];
-#pragma unroll
-        for (int c = 0; c < NT; c++) if (c != p) u[c] = readlane_f64(a[c], p);
-#pragma unroll
-        for (int c = 0; c < NT; c++) if (c != p) a[c] = fma(g, u[c], a[c]);
-        a[p] = is ? rinv : g * rinv;
-    }
+    InvRegsStep<NT, 0>::run(a, lane, bad);
 #pragma unroll
     for (int c = 0; c < NT; c++) if (c == lane && untouched) a[c] = 0.0;
     if (mine)
@@ -256,6 +270,32 @@ __device__ __forceinline__ double quad_xor(double x)
     return __hiloint2double(hi, lo);
 }
 
+// forward elimination beyond 32 models (no DPP: a DPP row has 16 lanes), rows in registers, only what the LAST pivot needs: the
+// elimination of solve.hpp's gj_regs as a template recursion with the broadcasts in chunks of 16 (a[NT] and NT broadcasts at once
+// do not fit the 256 registers a wavefront of this 512-thread kernel has)
+template <int NT, int J>
+struct Inv00Step {
+    static __device__ __forceinline__ void run(double (&a)[NT], int lane, double floor_mine, int &flag, double &last_pivot)
+    {
+        const double piv = readlane_f64(a[J], J);
+        const bool is = lane == J;
+        flag = is ? (!(a[J] > floor_mine) ? 1 : 0) : flag;        // NaN and non-positive pivots included
+        if constexpr (J == NT - 1) { last_pivot = piv; }
+        else {
+            const double f = is ? 0.0 : -a[J] * rcp_f64(piv);
+#pragma unroll
+            for (int c0 = J + 1; c0 < NT; c0 += 16) {
+                double u[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) if (c0 + q < NT) u[q] = readlane_f64(a[c0 + q], J);
+#pragma unroll
+                for (int q = 0; q < 16; q++) if (c0 + q < NT) a[c0 + q] = fma(f, u[q], a[c0 + q]);
+            }
+            Inv00Step<NT, J + 1>::run(a, lane, floor_mine, flag, last_pivot);
+        }
+    }
+};
+
 // (P^-1)_00 of one output by one wavefront: the DPP elimination of the plan's solve (solve.hpp: gj_solve_last without the
 // solution vector), rows in registers, P (reversed layout) left alone.  Returns +inf when P is not positive definite.
 template <int NT>
@@ -288,7 +328,8 @@ __device__ __forceinline__ double inv00_regs(const double *P, int N, int lane)
     double rinv_mine = 0.0, last_pivot = 1.0;
     if constexpr (!G::dpp) {
         int bad0 = 0;
-        gj_regs<NT>(a, lane, diag0, rinv_mine, last_pivot, bad0);
+        Inv00Step<NT, 0>::run(a, lane, BLUEST_PIVOT_TOL * diag0, bad0, last_pivot);
+        bad0 = (__ballot(bad0 != 0 && lane < NT) != 0ull || !isfinite(last_pivot)) ? 1 : 0;
         return (!bad0 && last_pivot > 0.0) ? 1.0 / last_pivot : INFINITY;
     } else {
         asm volatile("s_nop 4" ::: "memory");
@@ -747,7 +788,7 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
     extern __shared__ __align__(16) unsigned char master_sm[];
     MasterLds L;
     const int N = A.N, n_out = A.n_out, S = A.S, KM = A.KM;
-    master_carve(L, master_sm, N, n_out, S, KM);
+    master_carve(L, master_sm, N, n_out, S, KM, NT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int LDN = L.LDN, KE = L.KE;
     // ---- load the support ---------------------------------------------------------------------------
@@ -1359,6 +1400,28 @@ static int master_lds_limit()
     return limit_of[dev];
 }
 
+// Which instantiation runs a problem, and the largest support it holds.  Up to 32 models the register tiles 12 / 20 / 26 / 32.
+// Beyond: 40 / 48 / 64 in registers (one evaluation's elimination 3 us instead of 150 in LDS) when the larger Phi stride (nt + 2
+// instead of N + 1) still leaves the support the natural layout would allow, or N + 16 entries; else the LDS eliminations (nt = 0).
+static int master_choose_nt(int N, int n_out, int KM, int *s_max)
+{
+    const size_t limit = (size_t)master_lds_limit() - MASTER_STATIC_LDS;
+    auto fit = [&](int nt) {
+        int S = MASTER_SMAX;
+        while (S > 0 && master_lds_bytes(N, n_out, S, KM, nt) > limit) S -= 2;
+        return S;
+    };
+    int nt = N <= 12 ? 12 : N <= 20 ? 20 : N <= 26 ? 26 : N <= 32 ? 32 : 0;
+    int S = fit(nt);
+    if (!nt) {
+        const int cand = N <= 40 ? 40 : N <= 48 ? 48 : 64;
+        const int s_reg = fit(cand);
+        if (s_reg >= std::min(S, std::min(MASTER_SMAX, N + 16))) { nt = cand; S = s_reg; }
+    }
+    if (s_max) *s_max = S;
+    return nt;
+}
+
 extern "C" int bluest_master_max_support(bluest_plan_t plan, int *s_max)
 {
     if (!plan || !s_max) return fail(BLUEST_ERR_ARG, "null pointer");
@@ -1367,10 +1430,7 @@ extern "C" int bluest_master_max_support(bluest_plan_t plan, int *s_max)
     int KM = 0;
     for (const auto &od : plan->outs) KM = std::max(KM, od.K);
     const int n_out = (int)plan->outs.size();
-    const size_t limit = (size_t)master_lds_limit() - MASTER_STATIC_LDS;
-    int S = MASTER_SMAX;
-    while (S > 0 && master_lds_bytes(plan->N, n_out, S, KM) > limit) S -= 2;
-    *s_max = S;                                            // 0: this problem does not fit the single-workgroup master
+    (void)master_choose_nt(plan->N, n_out, KM, s_max);     // 0: this problem does not fit the single-workgroup master
     return BLUEST_OK;
 }
 
@@ -1445,7 +1505,8 @@ static int master_launch(bluest_plan_t plan, int S, const int64_t *support_host,
         if (!found) return fail(BLUEST_ERR_ARG, "group %lld belongs to no output", (long long)gi);
         KM = std::max(KM, kk[j]);
     }
-    const size_t lds = master_lds_bytes(N, n_out, S, KM);
+    const int nt = master_choose_nt(N, n_out, KM, nullptr);
+    const size_t lds = master_lds_bytes(N, n_out, S, KM, nt);
     if (lds > (size_t)master_lds_limit() - MASTER_STATIC_LDS) return fail(BLUEST_ERR_ARG, "master problem needs %zu bytes of LDS (limit %d)", lds, master_lds_limit() - MASTER_STATIC_LDS);
     idx.assign((size_t)S * KM, 0);
     for (int j = 0; j < S; j++) for (int l = 0; l < kk[j]; l++) idx[(size_t)j * KM + l] = (uint8_t)members[j][l];
@@ -1505,11 +1566,16 @@ static int master_launch(bluest_plan_t plan, int S, const int64_t *support_host,
         }                                                                                                                     \
         hipLaunchKernelGGL((k_master_newton<NT>), dim3(1), dim3(MASTER_THREADS), lds, st, A);                                 \
     } while (0)
-    if (N <= 12) LAUNCH_MASTER(12);
-    else if (N <= 20) LAUNCH_MASTER(20);
-    else if (N <= 26) LAUNCH_MASTER(26);
-    else if (N <= 32) LAUNCH_MASTER(32);
-    else LAUNCH_MASTER(0);
+    switch (nt) {
+        case 12: LAUNCH_MASTER(12); break;
+        case 20: LAUNCH_MASTER(20); break;
+        case 26: LAUNCH_MASTER(26); break;
+        case 32: LAUNCH_MASTER(32); break;
+        case 40: LAUNCH_MASTER(40); break;
+        case 48: LAUNCH_MASTER(48); break;
+        case 64: LAUNCH_MASTER(64); break;
+        default: LAUNCH_MASTER(0);
+    }
 #undef LAUNCH_MASTER
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;

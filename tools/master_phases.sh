@@ -11,7 +11,8 @@ names = ["load of the support (blocks, lists)", "Phi assembly of the evaluations
          "Hessian of the Lagrangian", "elimination of the Newton system (8 wavefronts)", "K = E^T M^-1 E + the small KKT system"]
 print("# k_master_newton per phase, microseconds per SOLVE (all master calls of one warm colgen_solve), thread 0's wall clock between")
 print("# workgroup barriers, experiment build -DMASTER_TIMING (tools/master_phases.sh).  Round 3 (before): profiles/r04_master_phases_before.txt")
-for cfg in ("20 5 8", "25 6 1", "20 5 1"):
+import os
+for cfg in (os.environ.get("MASTER_PHASE_CFGS", "20 5 8,25 6 1,20 5 1").split(",")):
     out = subprocess.run([sys.executable, "tools/colgen_run.py"] + cfg.split(), capture_output=True, text=True).stdout
     line = [l for l in out.splitlines() if l.startswith("rep 2")][-1]
     ph = [float(x) for x in re.findall(r"np\.float64\(([-0-9.e+]+)\)", line.split("master_phase_us")[1].split("]")[0])]

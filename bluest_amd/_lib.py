@@ -77,6 +77,8 @@ SIGNATURES = {
     "bluest_master_newton": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp, c_f64, c_int, c_vp, c_vp],
     "bluest_master_newton_capped": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp, c_f64, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp],
     "bluest_ma_update": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp, c_vp],
+    "bluest_plan_is_identity": [c_vp, ctypes.POINTER(ctypes.c_int)],
+    "bluest_plan_eval_ma": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "bluest_support_point": [c_i64, c_int, c_vp, c_vp, c_vp, c_f64, c_vp, c_vp],
     "bluest_price": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "bluest_price_capped": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],

@@ -10,6 +10,7 @@ Everything numeric runs in hand-written kernels; the host only moves a few KB pe
 multipliers, 1024 pricing candidates) and decides which groups enter.  torch is used for buffers and the stream only.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -194,7 +195,13 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
         x_d, m_d = to_dev(xh), to_dev(cc_h * xh)
         lap("background")
         _t_ma0 = _time.perf_counter()
+        # a single output on all groups: the fused solve + gradient kernel of the evaluation applies the update itself (two launches
+        # per step instead of three, no gradient array; the same iterates bit for bit)
+        fused_ma = sharded is None and n_out == 1 and bool(getattr(plan, "identity", False)) and os.environ.get("BLUEST_MA_FUSED", "1") != "0"
         for _ in range(ma_its):
+            if fused_ma:
+                check(lib.bluest_plan_eval_ma(plan._h, m_d.data_ptr(), var.data_ptr(), status.data_ptr(), s_d.data_ptr(), cc.data_ptr(), x_d.data_ptr(), st))
+                continue
             evaluate(m_d, var)
             check(lib.bluest_ma_update(plan._h, var.data_ptr(), status.data_ptr(), grad.data_ptr(), s_d.data_ptr(), cc.data_ptr(), ma_p,
                                        x_d.data_ptr(), m_d.data_ptr(), st))

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(64 * (MF_TILE_WAVES + 1)) void k_solve_grad_mf(cons
                                                                            const RowDesc *__restrict__ rows, FoldReg reg, const double2 *__restrict__ partial,
                                                                            const int32_t *__restrict__ wg_begin, int bpo,
                                                                            double *__restrict__ var, double *__restrict__ v_ws,
-                                                                           int32_t *__restrict__ status, double *__restrict__ grad)
+                                                                           int32_t *__restrict__ status, double *__restrict__ grad, const MaTail ma)
 {
     constexpr int NTHREADS = 64 * (MF_TILE_WAVES + 1);
     __shared__ SolveLds<NT> lds;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64 * (MF_TILE_WAVES + 1)) void k_solve_grad_mf(cons
         double V = 0.0;
         int32_t st = 0;
         solve_wave<NT>(lds, N, delta, s1, s2, big, true, &V, lds.vout, &st, lane);
-        if (lane == 0) lds.status = st;
+        if (lane == 0) { lds.status = st; if (ma.x) lds.scratch[0] = V; }
         if (first) {
             if (lane == 0) { var[o] = V; status[o] = st; }
             if (lane < N) v_ws[(int64_t)o * N + lane] = lds.vout[lane];
@@ -425,7 +425,14 @@ __global__ __launch_bounds__(64 * (MF_TILE_WAVES + 1)) void k_solve_grad_mf(cons
         } break;
     switch (td.k) { MFQ(1) MFQ(2) MFQ(3) MFQ(4) MFQ(5) MFQ(6) MFQ(7) MFQ(8) default: break; }
 #undef MFQ
-    if (valid) grad[A.goff[o] + td.first + lane] = inf ? INFINITY : -q;
+    if (valid && !ma.x) grad[A.goff[o] + td.first + lane] = inf ? INFINITY : -q;
+    else if (valid && lds.status == BLUEST_EVAL_OK) {      // single output, phase 1 of the second-order finish: k_ma_update's arithmetic
+        const int64_t i = (int64_t)td.first + lane;
+        const double so = ma.s[0], cci = ma.cc[i];
+        const double xn = ma.x[i] * cci * ((1.0 / so) * q) / (lds.scratch[0] / so);
+        ma.x[i] = xn;
+        ma.m[i] = cci * xn;
+    }
 }
 
 // gradient pass alone from a given v (bluest_plan_grad on a matrix-free plan): one wavefront per tile, four per workgroup; the same
@@ -658,7 +665,7 @@ int mf_phi_record(bluest_plan_t plan, const double *m_dev, double *rec_dev, cons
 
 // solve + gradient of this plan's groups from a record (rec_dev == NULL: from the chunk partials the stored Phi pass just left):
 // (var, status, v workspace, grad)
-int mf_solve_grad(bluest_plan_t plan, const double *rec_dev, double delta, double *var_dev, int32_t *status_dev, double *grad_dev, hipStream_t st)
+int mf_solve_grad(bluest_plan_t plan, const double *rec_dev, double delta, double *var_dev, int32_t *status_dev, double *grad_dev, hipStream_t st, MaTail ma)
 {
     MfState *S = reinterpret_cast<MfState *>(plan->mf);
     if (!S) return fail(BLUEST_ERR_STATE, "matrix-free state missing");
@@ -681,7 +688,7 @@ int mf_solve_grad(bluest_plan_t plan, const double *rec_dev, double delta, doubl
     int kmax = 0;
     for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
 #define LMF2(NT, KU) hipLaunchKernelGGL((k_solve_grad_mf<NT, KU>), grid, dim3(64 * (MF_TILE_WAVES + 1)), S->lds_grad, st, A, rec_dev, delta, \
-                                        plan->d_rows, plan->fold_reg, plan->d_partial, (const int32_t *)plan->mf_wg_begin_dev, plan->mf_bpo, var_dev, plan->d_v, status_dev, grad_dev)
+                                        plan->d_rows, plan->fold_reg, plan->d_partial, (const int32_t *)plan->mf_wg_begin_dev, plan->mf_bpo, var_dev, plan->d_v, status_dev, grad_dev, ma)
 #define LMF(NT) do { if (kmax <= 5) LMF2(NT, 5); else if (kmax <= 6) LMF2(NT, 6); else LMF2(NT, 8); } while (0)
     NT_DISPATCH(plan->N, LMF);
 #undef LMF

@@ -549,7 +549,7 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
                                                     double *__restrict__ var, double *__restrict__ v_ws,
                                                     int32_t *__restrict__ status, double *__restrict__ grad,
                                                     const int32_t *__restrict__ gate, double *__restrict__ spg_state, int last_slot,
-                                                    int32_t *__restrict__ spg_enable, unsigned int *__restrict__ ticket)
+                                                    int32_t *__restrict__ spg_enable, unsigned int *__restrict__ ticket, const MaTail ma)
 {
     constexpr int FUSED_TPB = fused_tpb(NT, KU);
     constexpr int NTHREADS = 64 * (FUSED_TPB + 1);
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
         PHASE(8);
         if (BLUEST_ABLATE == 2) { if (lane < N) lds.vout[lane] = 1.0; }
         else solve_wave<NT>(lds, N, delta, s1, s2, big, true, &V, lds.vout, &st, lane);
-        if (lane == 0) lds.status = st;
+        if (lane == 0) { lds.status = st; if (ma.x) lds.scratch[0] = V; }      // (the elimination is done with its scratch)
         V_pub = V; st_pub = st;
         if (first) {   // first workgroup of this output publishes V, status, v
             if (lane == 0) { var[o] = V; status[o] = st; }
@@ -668,7 +668,16 @@ __global__ __launch_bounds__(64 * (fused_tpb(NT, KU) + 1)) void k_solve_grad(int
     const bool valid = lane < (td.n_valid & 0xffff) && (BLUEST_ABLATE != 7 || pr[0].x == 1.2345);
     const bool inf = lds.status == BLUEST_EVAL_INF;
     double *gout = grad + td.grad_off + lane;
-#define GT(KK) case KK: if (KK <= KU) { const double q = tile_form<(KK <= KU ? KK : 1)>(pr, lds.vout); if (valid) *gout = inf ? INFINITY : -q; break; }
+    // (single output, phase 1 of the second-order finish: the update itself instead of the gradient -- k_ma_update's arithmetic)
+#ifdef BLUEST_NO_MA_TAIL      // A/B build: the kernel without the tail
+    const bool MA_ON = false;
+#else
+    const bool MA_ON = ma.x != nullptr;
+#endif
+#define GT(KK) case KK: if (KK <= KU) { const double q = tile_form<(KK <= KU ? KK : 1)>(pr, lds.vout);                                          \
+        if (valid && !MA_ON) *gout = inf ? INFINITY : -q;                                                                                        \
+        else if (valid && lds.status == BLUEST_EVAL_OK) { const int64_t i = td.grad_off + lane; const double so = ma.s[0], cci = ma.cc[i];       \
+            const double xn = ma.x[i] * cci * ((1.0 / so) * q) / (lds.scratch[0] / so); ma.x[i] = xn; ma.m[i] = cci * xn; } break; }
     switch (k) {
         GT(1) GT(2) GT(3) GT(4) GT(5) GT(6) GT(7) GT(8) GT(9) GT(10) GT(11) GT(12)
         default: {
@@ -1851,7 +1860,7 @@ extern "C" int bluest_plan_grad(bluest_plan_t plan, const double *v_dev, const i
 
 static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, double delta,
                      double *var_dev, double *grad_dev, int64_t grad_stride, int32_t *status_dev, void *stream,
-                     double *dec_state, int dec_last, int32_t *dec_enable);
+                     double *dec_state, int dec_last, int32_t *dec_enable, MaTail ma = MaTail{nullptr, nullptr, nullptr, nullptr});
 
 extern "C" int bluest_plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, double delta,
                                 double *var_dev, double *grad_dev, int64_t grad_stride, int32_t *status_dev, void *stream)
@@ -1876,7 +1885,7 @@ extern "C" int bluest_plan_solve_grad(bluest_plan_t plan, const double *rec_dev,
     const dim3 grid((unsigned)(plan->n_tiles / plan->fused_tpb));
 #define LSR2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->fold_reg, plan->d_partial, \
                                         rec_dev, delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->fused_tpb, plan->tile_nt ? 1 : 0, plan->d_tvals, var_dev, plan->d_v, status_dev,  \
-                                        grad_dev, plan->gate, state_dev, last_slot, enable_dev, plan->d_ticket)
+                                        grad_dev, plan->gate, state_dev, last_slot, enable_dev, plan->d_ticket, MaTail{nullptr, nullptr, nullptr, nullptr})
 #define LSR(NT) do { if (kmax <= 5) LSR2(NT, 5); else if (kmax <= 6) LSR2(NT, 6); else if (kmax <= 8) LSR2(NT, 8); else LSR2(NT, 12); } while (0)
     NT_DISPATCH(plan->N, LSR);
 #undef LSR
@@ -1903,7 +1912,7 @@ extern "C" int bluest_plan_eval_grad_decide(bluest_plan_t plan, const double *m_
 
 static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_t m_stride, double delta,
                      double *var_dev, double *grad_dev, int64_t grad_stride, int32_t *status_dev, void *stream,
-                     double *dec_state, int dec_last, int32_t *dec_enable)
+                     double *dec_state, int dec_last, int32_t *dec_enable, MaTail ma)
 {
     int rc = plan_ready(plan, n_cand); if (rc) return rc;
     if (!m_dev || !var_dev) return fail(BLUEST_ERR_ARG, "null pointer");
@@ -1916,7 +1925,7 @@ static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_
         // matrix-free: Phi pass -> record -> (solve + gradient | solve) -- no stored inverse is read
         const double *rec = nullptr;
         if ((rc = mf_phi_record(plan, m_dev, nullptr, &rec, st))) return rc;
-        if (grad_dev) return mf_solve_grad(plan, rec, delta, var_dev, status, grad_dev, st);
+        if (grad_dev) return mf_solve_grad(plan, rec, delta, var_dev, status, grad_dev, st, ma);
 #define LSRM(NT) hipLaunchKernelGGL((k_solve_from_record<NT>), dim3(n_out, 1), dim3(64), 0, st, plan->N, n_out, rec, delta, plan->always_v ? 1 : 0, \
                                     var_dev, plan->d_v, status)
         NT_DISPATCH(plan->N, LSRM);
@@ -1926,7 +1935,7 @@ static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_
     }
     launch_chunks(plan, m_dev, n_cand, m_stride, st);
     if (plan->mf_gradient && grad_dev && n_cand == 1 && !dec_state && !plan->gate && !g_debug_solve)
-        return mf_solve_grad(plan, nullptr, delta, var_dev, status, grad_dev, st);      // stored Phi pass + fold, solve and matrix-free gradient
+        return mf_solve_grad(plan, nullptr, delta, var_dev, status, grad_dev, st, ma);  // stored Phi pass + fold, solve and matrix-free gradient
     int kmax = 0;
     for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
     // fused solve + gradient pass (2 launches per evaluation); groups larger than 12 take the generic tile code inside it
@@ -1934,7 +1943,7 @@ static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_
         const dim3 grid((unsigned)(plan->n_tiles / plan->fused_tpb));
 #define LSG2(NT, KU) hipLaunchKernelGGL((k_solve_grad<NT, KU>), grid, dim3(64 * (fused_tpb(NT, KU) + 1)), 0, st, plan->N, n_out, plan->d_rows, plan->nsym, plan->fold_reg, plan->d_partial, nullptr, \
                                         delta, plan->d_tiles, plan->n_tiles, plan->fused_bpo, plan->fused_tpb, plan->tile_nt ? 1 : 0, plan->d_tvals, var_dev, plan->d_v, status, grad_dev, plan->gate, \
-                                        dec_state, dec_last, dec_enable, plan->d_ticket)
+                                        dec_state, dec_last, dec_enable, plan->d_ticket, ma)
 #define LSG(NT) do { if (kmax <= 5) LSG2(NT, 5); else if (kmax <= 6) LSG2(NT, 6); else if (kmax <= 8) LSG2(NT, 8); else LSG2(NT, 12); } while (0)
         NT_DISPATCH(plan->N, LSG);
 #undef LSG
@@ -1952,6 +1961,29 @@ static int plan_eval(bluest_plan_t plan, const double *m_dev, int n_cand, int64_
         launch_grad(plan, plan->d_v, status, n_cand, grad_dev, grad_stride, st);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;
+}
+
+extern "C" int bluest_plan_is_identity(bluest_plan_t plan, int *yes)
+{
+    if (!plan || !yes) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
+    *yes = plan->identity ? 1 : 0;
+    return BLUEST_OK;
+}
+
+// phase 1 of the second-order finish on a single-output plan: one evaluation of m_dev whose fused solve + gradient kernel applies the
+// multiplicative update to x_dev / m_dev itself (no gradient array, no third launch); var / status as bluest_plan_eval leaves them
+extern "C" int bluest_plan_eval_ma(bluest_plan_t plan, double *m_dev, double *var_dev, int32_t *status_dev, const double *s_dev,
+                                   const double *cc_dev, double *x_dev, void *stream)
+{
+    if (!plan || !m_dev || !var_dev || !status_dev || !s_dev || !cc_dev || !x_dev) return fail(BLUEST_ERR_ARG, "null pointer");
+    if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
+    int kmax = 0;
+    for (const auto &od : plan->outs) kmax = std::max(kmax, od.K);
+    if (plan->outs.size() != 1 || !plan->identity || plan->gate || g_debug_solve || kmax > (plan->matfree ? 8 : 12))
+        return fail(BLUEST_ERR_STATE, "bluest_plan_eval_ma: one output on all groups under the identity mapping only");
+    // (the gradient pointer only selects the fused kernel: with the tail on, nothing is written through it)
+    return plan_eval(plan, m_dev, 1, 0, 0.0, var_dev, plan->d_v, plan->grad_len, status_dev, stream, nullptr, 0, nullptr, MaTail{x_dev, cc_dev, m_dev, s_dev});
 }
 
 extern "C" int bluest_plan_combine_grad(bluest_plan_t plan, const double *grad_dev, int64_t grad_stride, const double *coef_dev,

@@ -200,6 +200,10 @@ __device__ __forceinline__ void grad_tile_generic(const TileDesc &td, const doub
 }
 
 
+// single-output plans: the multiplicative update of phase 1 (newton.hip, k_ma_update) done by the fused solve + gradient kernel's
+// tile wavefronts instead of writing the gradient: x_i <- x_i cc_i (q_i / s_0) / (V / s_0), m_i = cc_i x_i (x == NULL: off)
+struct MaTail { double *x; const double *cc; double *m; const double *s; };
+
 int plan_ready(bluest_plan_t plan, int n_cand);
 // the library's device block cache (plan.hip)
 hipError_t pool_alloc(void **p, size_t bytes);
@@ -208,5 +212,6 @@ hipError_t pool_free(void *p, bool recycle = true);
 int mf_finalize(bluest_plan_t plan);
 void mf_release(bluest_plan_s *p);
 int mf_phi_record(bluest_plan_t plan, const double *m_dev, double *rec_dev, const double **rec_used, hipStream_t st);
-int mf_solve_grad(bluest_plan_t plan, const double *rec_dev, double delta, double *var_dev, int32_t *status_dev, double *grad_dev, hipStream_t st);
+int mf_solve_grad(bluest_plan_t plan, const double *rec_dev, double delta, double *var_dev, int32_t *status_dev, double *grad_dev, hipStream_t st,
+                  MaTail ma = MaTail{nullptr, nullptr, nullptr, nullptr});
 int mf_grad(bluest_plan_t plan, const double *v_dev, const int32_t *status_dev, double *grad_dev, hipStream_t st);

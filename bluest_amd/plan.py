@@ -117,6 +117,9 @@ class Plan(object):
         check(self.lib.bluest_plan_matfree(self._h, ctypes.byref(mf), ctypes.byref(mfb)))
         # single-candidate evaluations recompute the group inverses (csrc/matfree.hip): Phi and gradient (matfree), or the gradient only
         self.matfree, self.matfree_gradient, self.matfree_bytes = mf.value == 1, mf.value in (1, 2), mfb.value
+        ident = ctypes.c_int(0)
+        check(self.lib.bluest_plan_is_identity(self._h, ctypes.byref(ident)))
+        self.identity = ident.value == 1            # every output on all groups, local index = global index
 
     def restrict(self, keep, max_candidates=1):
         """a new Plan over the sub-list `keep` (sorted global group indices) of this plan's groups: allocation vectors of length

@@ -357,6 +357,12 @@ int bluest_master_newton_capped(bluest_plan_t plan, int S, const int64_t *suppor
  * for the allocation m; wgt_o ~ r_o^(p-1) (p-norm surrogate of the max) */
 int bluest_ma_update(bluest_plan_t plan, const double *var_dev, const int32_t *status_dev, const double *grad_dev,
                      const double *s_dev, const double *cc_dev, double p, double *x_dev, double *m_dev, void *stream);
+/* single-output plans on all groups (identity mapping): one step of phase 1 in TWO launches -- the evaluation of m_dev, whose fused
+ * solve + gradient kernel applies the update above to x_dev / m_dev in its tile wavefronts instead of writing the gradient.  Same
+ * iterates as bluest_plan_eval + bluest_ma_update, bit for bit.  BLUEST_ERR_STATE for any other plan. */
+int bluest_plan_is_identity(bluest_plan_t plan, int *yes);      /* every output on all groups, local index = global index */
+int bluest_plan_eval_ma(bluest_plan_t plan, double *m_dev, double *var_dev, int32_t *status_dev, const double *s_dev,
+                        const double *cc_dev, double *x_dev, void *stream);
 /* m_i = cc_i ((1 - eps) x_S[i in S] + eps / L); sup_dev ascending */
 int bluest_support_point(int64_t L, int S, const int64_t *sup_dev, const double *xs_dev, const double *cc_dev, double eps,
                          double *m_dev, void *stream);

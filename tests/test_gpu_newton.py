@@ -252,3 +252,59 @@ def test_second_order_finish_beyond_32_models(gpu, n, kmax, n_out):
     assert info["certified_gap"] <= 1e-5, info
     assert (m >= 0).all() and abs(m @ w / B - 1) < 1e-9
     assert abs(max(mos.variances(m)) / info["f"] - 1) < 1e-9
+
+
+@pytest.mark.parametrize("n,kmax,matfree", [(8, 3, "0"), (12, 12, "0"), (20, 5, "0"), (20, 5, "1"), (25, 6, "1"), (30, 3, "0")])
+def test_multiplicative_update_inside_the_fused_kernel_is_bit_identical(gpu, monkeypatch, n, kmax, matfree):
+    """single-output plans: bluest_plan_eval_ma (the tile wavefronts of the fused solve + gradient kernel apply the update) gives the
+    iterates of bluest_plan_eval + bluest_ma_update bit for bit over 25 steps -- stored and matrix-free plans, s != 1 --, leaves the
+    iterate alone when the allocation is not evaluable, and refuses plans with more than one output"""
+    torch = gpu
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from bluest_amd._lib import BluestHipError, check
+    from bluest_amd.plan import Plan, _stream
+    monkeypatch.setenv("BLUEST_MATFREE", matfree)
+    prob = synth.problem(n, kmax, 1)
+    L = prob["K_tot"]
+    plan = Plan(n, L, bench.build_outputs(prob))
+    assert plan.matfree == (matfree == "1") and plan.identity
+    dev = plan.device
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)      # noqa: E731
+    cc_h = prob["budget"] / prob["costs"]
+    cc, s_d = to_dev(cc_h), to_dev(np.array([0.37]))
+    x0 = np.random.RandomState(5).rand(L) + 0.1
+    x0 /= x0.sum()
+    res = []
+    with torch.cuda.device(dev):
+        st = _stream()
+        for fused in (False, True):
+            x_d, m_d = to_dev(x0), to_dev(cc_h * x0)
+            var = torch.empty((1, 1), dtype=torch.float64, device=dev)
+            status = torch.empty((1, 1), dtype=torch.int32, device=dev)
+            grad = torch.empty((1, plan.grad_len), dtype=torch.float64, device=dev)
+            for _ in range(25):
+                if fused:
+                    check(plan.lib.bluest_plan_eval_ma(plan._h, m_d.data_ptr(), var.data_ptr(), status.data_ptr(), s_d.data_ptr(), cc.data_ptr(), x_d.data_ptr(), st))
+                else:
+                    check(plan.lib.bluest_plan_eval(plan._h, m_d.data_ptr(), 1, L, 0.0, var.data_ptr(), grad.data_ptr(), plan.grad_len, status.data_ptr(), st))
+                    check(plan.lib.bluest_ma_update(plan._h, var.data_ptr(), status.data_ptr(), grad.data_ptr(), s_d.data_ptr(), cc.data_ptr(), 32.0,
+                                                    x_d.data_ptr(), m_d.data_ptr(), st))
+            torch.cuda.synchronize()
+            res.append((x_d.cpu().numpy(), m_d.cpu().numpy(), var.cpu().numpy(), status.cpu().numpy()))
+        (xa, ma, va, sa), (xb, mb, vb, sb) = res
+        assert (sa == 0).all() and (sb == 0).all() and abs(xa.sum() - 1) < 1e-9 and (xa > 0).all()
+        assert np.array_equal(va, vb) and np.array_equal(xa, xb) and np.array_equal(ma, mb)
+        # not evaluable (model 0 unsampled): status says so, x and m stay as they were
+        x1 = x0.copy()
+        x1[np.asarray([0 in g for gk in prob["groups"] for g in gk])] = 0.0
+        x_d, m_d = to_dev(x1), to_dev(cc_h * x1)
+        check(plan.lib.bluest_plan_eval_ma(plan._h, m_d.data_ptr(), var.data_ptr(), status.data_ptr(), s_d.data_ptr(), cc.data_ptr(), x_d.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert int(status.cpu()[0, 0]) != 0 and np.array_equal(x_d.cpu().numpy(), x1) and np.array_equal(m_d.cpu().numpy(), cc_h * x1)
+        two = synth.problem(8, 3, 2)
+        p2 = Plan(8, two["K_tot"], bench.build_outputs(two))
+        with pytest.raises(BluestHipError):
+            check(p2.lib.bluest_plan_eval_ma(p2._h, m_d.data_ptr(), var.data_ptr(), status.data_ptr(), s_d.data_ptr(), cc.data_ptr(), x_d.data_ptr(), st))

@@ -26,6 +26,14 @@
 #define MASTER_MCAP 4      // sample caps (max_model_samples rows) that can be in the step as equality rows at once
 #define MASTER_NE (MASTER_PACT + MASTER_MCAP + 1)      // columns of E: active outputs, active caps, the simplex row
 #define MASTER_OUT 16      // doubles in front of r[] in the result record
+#ifndef MASTER_DAMP_DOWN
+#define MASTER_DAMP_DOWN 0.3   // damping after a step whose decrease was more than half of the predicted one.  x0.1 (until round 4) made
+                               // the masters oscillate -- accepted, x0.1, the next step too long and rejected, x10, accepted ... : 45 of 116
+                               // factorisations of a headline solve ended in a rejected step; profiles/r04_damp_ab.txt (tools/damp_ab.sh)
+#endif
+#ifndef MASTER_DAMP_UP
+#define MASTER_DAMP_UP 10.0    // ... after a rejected step
+#endif
 #define MASTER_STATIC_LDS 2048   // room kept for the kernel's static LDS (the small KKT system: 1.5 KB) next to the dynamic part
 
 struct MasterArgs {
@@ -1042,6 +1050,9 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
             TSTAMP(7);                                  // 7: K + small system
             if (!L.istate[IS_OK]) {              // M not positive definite (or singular small system): more damping
                 __syncthreads();
+#ifdef MASTER_COUNTS
+                if (tid == 0) L.scal[200] += 1.0;
+#endif
                 if (tid == 0) L.scal[SC_DAMP] *= 10.0;
                 __syncthreads();
                 if (L.scal[SC_DAMP] > 1.0e12) break;
@@ -1104,6 +1115,9 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
             if (attempt == 0) pred0 = pred;
             if (pred < -0.5 * F) {               // the model promises more than half of a positive objective: shorter step
                 __syncthreads();
+#ifdef MASTER_COUNTS
+                if (tid == 0) L.scal[201] += 1.0;
+#endif
                 if (tid == 0) L.scal[SC_DAMP] *= 10.0;
                 __syncthreads();
                 if (L.scal[SC_DAMP] > 1.0e12) break;
@@ -1141,7 +1155,7 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
                     const bool noise = pred > -1.0e-11 * F && fmax(L.scal[SC_KKT], L.scal[SC_SPREAD]) <= 1.0e-4 && L.scal[SC_DAMP] <= 1.0e-2;      // (a tiny step of a heavily damped system is not noise)
                     if (isfinite(Ft) && (actual <= 1.0e-4 * fmin(pred, 0.0) + 1.0e-15 * F || (noise && actual <= 1.0e-11 * F))) {
                         const double ratio = (pred < 0.0 && !noise) ? actual / pred : 1.0;      // a step taken on trust counts as a good one
-                        if (ratio > 0.5) L.scal[SC_DAMP] = fmax(L.scal[SC_DAMP] * 0.1, 1.0e-14);
+                        if (ratio > 0.5) L.scal[SC_DAMP] = fmax(L.scal[SC_DAMP] * MASTER_DAMP_DOWN, 1.0e-14);
                         else if (ratio < 0.1) L.scal[SC_DAMP] *= 10.0;
                         L.istate[IS_ACCEPT] = 1;
                         L.scal[SC_FT] = Ft;
@@ -1149,8 +1163,15 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
                     } else if (pass == 0 && isfinite(Ft) && L.istate[IS_NALIVE] > 1) {
                         for (int a = 0; a < L.istate[IS_NACT0]; a++) L.scal[SQT + a] = -1.0 / L.rt[L.act[a + MASTER_PACT]];
                         L.istate[IS_OK] = 1;
+#ifdef MASTER_COUNTS
+                        L.scal[202] += 1.0;
+#endif
                     } else {
-                        L.scal[SC_DAMP] *= 10.0;
+                        L.scal[SC_DAMP] *= MASTER_DAMP_UP;
+#ifdef MASTER_COUNTS
+                        L.scal[203] += 1.0; if (!isfinite(Ft)) L.scal[204] += 1.0;
+                        if (isfinite(Ft) && pred < 0.0) { const double rr = actual / pred; if (rr > -1.0) L.scal[205] += 1.0; }
+#endif
                     }
                 }
                 __syncthreads();
@@ -1225,6 +1246,10 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
         A.out[0] = L.scal[SC_F]; A.out[1] = L.scal[SC_LAM]; A.out[2] = L.scal[SC_KKT]; A.out[3] = L.scal[SC_SPREAD];
         A.out[4] = L.istate[IS_IT]; A.out[5] = L.istate[IS_EVALS]; A.out[6] = L.istate[IS_SOLVES]; A.out[7] = L.istate[IS_STATUS];
         A.out[8] = L.scal[SC_DAMP]; A.out[9] = L.scal[SC_LAMX];
+#ifdef MASTER_COUNTS
+        printf("COUNTS S %d it %d solves %d evals %d | notPD %g modelTooBig %g soc %g rejected %g (inf %g, mild %g) status %d\n", S, L.istate[IS_IT], L.istate[IS_SOLVES], L.istate[IS_EVALS],
+               L.scal[200], L.scal[201], L.scal[202], L.scal[203], L.scal[204], L.scal[205], L.istate[IS_STATUS]);
+#endif
 #ifdef MASTER_TIMING
         for (int k = 0; k < 8; k++) A.out[8 + k] = (double)reinterpret_cast<long long *>(L.scal + 240)[k] * 0.01;      // microseconds
 #ifdef MASTER_TIMING_FINE

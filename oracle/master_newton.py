@@ -299,7 +299,7 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-3, floo
                 if noise:
                     ratio = 1.0                                    # a step taken on trust counts as a good one
                 if ratio > 0.5:
-                    damp = max(damp * 0.1, 1.0e-14)
+                    damp = max(damp * 0.3, 1.0e-14)      # (x0.1 made every other step a rejected one: profiles/r04_damp_ab.txt)
                 elif ratio < 0.1:
                     damp *= 10.0
                 noise_next = noise

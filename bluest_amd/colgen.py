@@ -50,6 +50,28 @@ class _Buffers(object):
         v[:len(values)] = values
         self.buf[o:o + n] = torch.from_numpy(v)          # small H2D copy (slice assignment from a CPU tensor: a memcpy)
 
+    def put_xs_mu(self, xs, mu):
+        """the master's two inputs in ONE copy (they are neighbours in the buffer)"""
+        (o, n), (o2, n2) = self.off["xs"], self.off["mu"]
+        assert o2 == o + n
+        v = np.zeros(n + n2)
+        v[:len(xs)] = xs
+        v[n:n + len(mu)] = mu
+        self.buf[o:o + n + n2] = torch.from_numpy(v)
+
+
+def top_candidates(topv, topi, k):
+    """the k best pricing candidates, largest reduced cost first, ties by index -- the head of np.lexsort((topi, -topv)) without sorting
+    all 1024 (56 us and two 1024-entry tolist() per round on the host while the GPU waits)"""
+    if k < len(topv):
+        head = np.argpartition(-topv, k)[:k]
+        kth = topv[head].min()
+        head = np.flatnonzero(topv >= kth)                        # every tie of the k-th value comes along: same head as the full sort
+    else:
+        head = np.arange(len(topv))
+    o = np.lexsort((topi[head], -topv[head]))
+    return topi[head][o].tolist(), topv[head][o].tolist()
+
 
 def master_max_support(plan):
     s = ctypes.c_int(0)
@@ -184,9 +206,7 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
         rec_u = plan.phi(u_m)
         if sharded is not None:
             sharded.reduce_records(rec_u)
-        rec_u = rec_u.cpu().numpy()[0]                           # (n_out, N*N + 2N + 1): the sums come first
-        phi_u = np.ascontiguousarray(rec_u[:, :N * N])
-        info["full_evals"] += 1
+        info["full_evals"] += 1                                  # (fetched after phase 1: its launches do not wait for this round trip)
         # ---- phase 1: multiplicative algorithm from the uniform point (or x0) ------------------------------------------------
         xh = np.full(L, 1.0 / L) if x0 is None else np.maximum(np.asarray(x0, dtype=np.float64), 0.0)
         xh = xh / xh.sum()
@@ -208,6 +228,8 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
         info["full_evals"] += ma_its
         lap("ma launches")
         xh = x_d.cpu().numpy()
+        rec_u = rec_u.cpu().numpy()[0]                           # (n_out, N*N + 2N + 1): the sums come first
+        phi_u = np.ascontiguousarray(rec_u[:, :N * N])
         lap("ma wait + fetch")
         info["t_ma_ms"] = (_time.perf_counter() - _t_ma0) * 1e3
         _t_r0 = _time.perf_counter()
@@ -269,8 +291,7 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
                             xs = cap_feasible_start(xs, Acap_S, b_eps)
                             if xs is None:
                                 return None, "no allocation on the support respects the sample caps"
-                    bufs.put("xs", xs)
-                    bufs.put("mu", mu)
+                    bufs.put_xs_mu(xs, mu)
                     keep_h = np.ascontiguousarray(keep, dtype=np.int64)
                     cc_keep = np.ascontiguousarray(cc_h[keep])
                     mplan, msup = master_plan(keep_h)
@@ -335,12 +356,11 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
                             cert["cap_multipliers"] = float(out[0]) ** 2 * nu_h
                     gap = 1.0 - best_lb / F
                     level = float(h["csup"][:S][pos] @ xs[pos]) / float(xs[pos].sum())
-                    order = np.lexsort((h["topi"], -h["topv"]))       # largest first, ties by index
-                    cand_i, cand_v = h["topi"][order], h["topv"][order]
                     in_pos = set(keep[pos].tolist())
                     enter = []
                     room = s_max - int(pos.sum())
-                    for i, v in zip(cand_i.tolist(), cand_v.tolist()):
+                    cand_i, cand_v = top_candidates(h["topv"], h["topi"], min(enter_per, room) + len(in_pos) + 1)      # largest first, ties by index
+                    for i, v in zip(cand_i, cand_v):
                         if len(enter) >= min(enter_per, room) or i < 0 or v / level - 1.0 <= enter_tol:
                             break
                         if i not in in_pos:

@@ -195,7 +195,7 @@ def colgen_solve(plan, costs, s, B, x0=None, prm=None, log=None, caps=None):
     def evaluate(m_t, var_t):
         """V and grad V of the allocation m_t for every output into (var_t, grad, status), on the stream"""
         if sharded is None:
-            check(lib.bluest_plan_eval(plan._h, m_t.data_ptr(), 1, L, 0.0, var_t.data_ptr(), grad.data_ptr(), plan.grad_len, status.data_ptr(), _stream()))
+            check(lib.bluest_plan_eval(plan._h, m_t.data_ptr(), 1, L, 0.0, var_t.data_ptr(), grad.data_ptr(), plan.grad_len, status.data_ptr(), st))
         else:
             sharded.eval(m_t, rec=rec, out=(var_t, grad, status))       # Phi of the shard -> record exchange -> redundant solve + shard gradient
 

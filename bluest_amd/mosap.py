@@ -202,9 +202,11 @@ class MOSAP(object):
         self.mappings = build_mappings(groups, multi_groups, self.cumsizes, self.N)  # m[mappings[n]] = m_n
 
         outs = []
+        self._identity_map = []                                   # output n lives on all groups in the global order
         for n in range(self.n_outputs):
             mg = multi_groups[n]
             ident = len(self.mappings[n]) == self.L and (self.mappings[n] == np.arange(self.L)).all()
+            self._identity_map.append(bool(ident))
             outs.append({"K": Ks[n], "sizes": [len(g) for g in mg], "groups": mg, "C": np.asarray(C[n], dtype=np.float64),
                          "mapping": None if ident else self.mappings[n]})
         clock.tick("mappings")
@@ -407,8 +409,13 @@ class MOSAP(object):
             if eps is None: print("Minimizing statistical error for fixed cost...\n")
             else:           print("Minimizing cost given statistical error tolerance...\n")
 
-        es = []
+        es, e_all = [], None
         for n in range(self.n_outputs):
+            if self._identity_map[n]:                             # (the usual case: one vector for all outputs, no gather / scatter)
+                if e_all is None:
+                    e_all = np.asarray(self.e, dtype=np.float64)
+                es.append(e_all)
+                continue
             ee = np.zeros((self.L,))
             ee[self.mappings[n]] = self.e[self.mappings[n]]
             es.append(ee)
@@ -423,7 +430,7 @@ class MOSAP(object):
             if self.verbose: print(str(err))
             self.samples = None
             return None
-        if any(samples @ ee < 1.0 - 1.0e-9 for ee in es):
+        if any(samples @ ee < 1.0 - 1.0e-9 for ee in {id(ee): ee for ee in es}.values()):
             if self.verbose: print("SPG solution samples model 0 less than once for some output; infeasible.")
             self.samples = None
             return None
@@ -442,5 +449,5 @@ class MOSAP(object):
         self.eps = eps
         self.tot_cost = samples @ self.costs
         for n in range(self.n_outputs):
-            self.SAPS[n].samples = samples[self.mappings[n]]
+            self.SAPS[n].samples = samples.copy() if self._identity_map[n] else samples[self.mappings[n]]
         return samples

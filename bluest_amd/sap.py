@@ -261,10 +261,11 @@ class SpgAllocator(object):
         p_list = prm["smoothing_p"] if isinstance(prm["smoothing_p"], (list, tuple)) else [prm["smoothing_p"]]
         p_list = [float(q) for q in p_list] if n_out > 1 else [np.inf]
         scale_h = B / w                                            # m = scale * x
-        scale = to_dev(scale_h)
+        scale = None                                               # (device copy: the first-order loop makes it when it runs)
         floor = float(prm["scaling_floor"])
         x = np.full(L, 1.0 / L) if x0 is None else np.asarray(x0, dtype=np.float64) * w / B
-        x = simplex_project(to_dev(x), want_d=False)[0].cpu().numpy()
+        if x0 is not None:                                         # (the uniform start is on the simplex already)
+            x = simplex_project(to_dev(x), want_d=False)[0].cpu().numpy()
         if not np.isfinite(ratios(plan, scale_h * x)):
             raise BLUESTError("SPG: the initial allocation does not sample model 0 / is infeasible")
         tot = {"it": 0, "count": 0}
@@ -345,6 +346,8 @@ class SpgAllocator(object):
                     f_prev = f_abs
             return out
 
+        if scale is None:
+            scale = to_dev(scale_h)
         res = run_stages(plan, scale_h, scale, x, p_list, True)
         x = res["x"]
         xs = x

@@ -4,7 +4,7 @@
 trap 'env -u BLUEST_EXTRA_HIPCC_FLAGS python -m bluest_amd.build --force > /dev/null 2>&1' EXIT
 for v in "$@"; do
   set -- $v
-  BLUEST_EXTRA_HIPCC_FLAGS="-DMASTER_DAMP_DOWN=$1 -DMASTER_DAMP_UP=$2" python -m bluest_amd.build --force > /dev/null 2>&1 || { echo "build failed for $v"; continue; }
-  echo "== down x$1, up x$2"
+  BLUEST_EXTRA_HIPCC_FLAGS="-DMASTER_DAMP_DOWN=$1 -DMASTER_DAMP_UP=$2 -DMASTER_DAMP_HOLD=${3:-0}" python -m bluest_amd.build --force > /dev/null 2>&1 || { echo "build failed for $v"; continue; }
+  echo "== down x$1, up x$2, hold ${3:-0}"
   python tools/gap_table.py 2>&1 | grep -v "amdgpu\|^#" | cut -c1-64
 done

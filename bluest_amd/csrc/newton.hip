@@ -1311,9 +1311,20 @@ __global__ __launch_bounds__(256) void k_ma_update(int64_t L, int n_out, const d
     __syncthreads();
     if (i >= L || !sok) return;                            // not evaluable: the iterate is left alone (uniform across the grid)
     double num = 0.0;
-    for (int o = 0; o < n_out; o++) {
-        const int32_t li = invmap ? invmap[(int64_t)o * L + i] : (int32_t)i;
-        if (li >= 0) num = fma(wgt[o], -grad[sgo[o] + li], num);
+    if (!invmap) {
+        // identity mapping: the n_out gradient entries are independent loads -- issued eight at a time, then summed in output order
+        for (int o0 = 0; o0 < n_out; o0 += 8) {
+            double g[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) g[q] = (o0 + q < n_out) ? grad[sgo[o0 + q] + i] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) if (o0 + q < n_out) num = fma(wgt[o0 + q], -g[q], num);
+        }
+    } else {
+        for (int o = 0; o < n_out; o++) {
+            const int32_t li = invmap[(int64_t)o * L + i];
+            if (li >= 0) num = fma(wgt[o], -grad[sgo[o] + li], num);
+        }
     }
     // (over-relaxed steps x * ratio^delta, delta 1.5 .. 3, alternating with plain ones: fewer iterations of this phase, up to 2.7x more
     // Newton iterations afterwards at the headline size -- profiles/r04_ma_power_negative_result.txt)
@@ -1618,7 +1629,8 @@ extern "C" int bluest_ma_update(bluest_plan_t plan, const double *var_dev, const
     if (!plan->finalized) return fail(BLUEST_ERR_STATE, "plan not finalized");
     const int n_out = (int)plan->outs.size();
     if (n_out > 64) return fail(BLUEST_ERR_ARG, "bluest_ma_update: more than 64 outputs");
-    hipLaunchKernelGGL(k_ma_update, dim3((unsigned)((plan->L + 255) / 256)), dim3(256), 0, (hipStream_t)stream, plan->L, n_out, var_dev,
+    hipLaunchKernelGGL(k_ma_update, dim3((unsigned)((plan->L + 255) / 256)), dim3(256), 0,      // (64 / 128 threads per workgroup: no difference)
+                       (hipStream_t)stream, plan->L, n_out, var_dev,
                        status_dev, grad_dev, plan->d_goff, plan->identity ? nullptr : plan->d_invmap, s_dev, cc_dev, p, x_dev, m_dev);
     HIP_TRY(hipGetLastError());
     return BLUEST_OK;

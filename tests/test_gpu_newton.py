@@ -254,7 +254,7 @@ def test_second_order_finish_beyond_32_models(gpu, n, kmax, n_out):
     assert abs(max(mos.variances(m)) / info["f"] - 1) < 1e-9
 
 
-@pytest.mark.parametrize("n,kmax,matfree", [(8, 3, "0"), (12, 12, "0"), (20, 5, "0"), (20, 5, "1"), (25, 6, "1"), (30, 3, "0")])
+@pytest.mark.parametrize("n,kmax,matfree", [(8, 3, "0"), (12, 12, "0"), (20, 5, "0"), (20, 5, "1"), (25, 6, "1"), (30, 3, "0"), (20, 5, "2"), (40, 2, "0")])
 def test_multiplicative_update_inside_the_fused_kernel_is_bit_identical(gpu, monkeypatch, n, kmax, matfree):
     """single-output plans: bluest_plan_eval_ma (the tile wavefronts of the fused solve + gradient kernel apply the update) gives the
     iterates of bluest_plan_eval + bluest_ma_update bit for bit over 25 steps -- stored and matrix-free plans, s != 1 --, leaves the
@@ -270,7 +270,7 @@ def test_multiplicative_update_inside_the_fused_kernel_is_bit_identical(gpu, mon
     prob = synth.problem(n, kmax, 1)
     L = prob["K_tot"]
     plan = Plan(n, L, bench.build_outputs(prob))
-    assert plan.matfree == (matfree == "1") and plan.identity
+    assert plan.matfree == (matfree == "1") and plan.matfree_gradient == (matfree in ("1", "2")) and plan.identity      # ("2": stored Phi pass, matrix-free gradient)
     dev = plan.device
     to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)      # noqa: E731
     cc_h = prob["budget"] / prob["costs"]

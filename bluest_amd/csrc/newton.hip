@@ -1571,9 +1571,10 @@ static int master_launch(bluest_plan_t plan, int S, const int64_t *support_host,
     }
     DeviceScopeN scope(plan->device);
     if (plan->master_bytes < total) {
-        if (plan->d_master) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(plan->d_master); plan->d_master = nullptr; }
+        // from the library's block cache (plan.hip): a hipMalloc here cost every NEW problem's first master launch 0.1-0.3 ms
+        if (plan->d_master) { (void)hipStreamSynchronize((hipStream_t)stream); (void)pool_free(plan->d_master); plan->d_master = nullptr; }
         const size_t want = std::max<size_t>(total * 2, 64u << 10);
-        HIP_TRY(hipMalloc(&plan->d_master, want));
+        HIP_TRY(pool_alloc(&plan->d_master, want));
         plan->master_bytes = want;
     }
     hipStream_t st = (hipStream_t)stream;

@@ -805,7 +805,7 @@ static void plan_free_device(bluest_plan_s *p)
     mf_release(p);
     if (p->d_arena) (void)pool_free(p->d_arena);
     if (p->d_scratch) (void)pool_free(p->d_scratch);
-    if (p->d_master) (void)hipFree(p->d_master);
+    if (p->d_master) (void)pool_free(p->d_master);
     p->d_arena = p->d_scratch = p->d_master = nullptr;
     p->master_bytes = 0;
     for (auto &od : p->outs) {

@@ -70,7 +70,7 @@ __host__ __device__ constexpr int master_phi_doubles(int N, int nt) { return nt 
 
 struct MasterLds {                     // carved out of dynamic LDS by master_carve()
     double *PHI, *TACT, *BLK, *M, *AAC, *GQ;
-    double *x, *xt, *xp, *d, *cc, *Dm, *glv, *mvec, *r, *rt, *rp, *mu, *mup, *muh, *scal, *capb, *capslack, *nu;
+    double *x, *xt, *xp, *d, *cc, *Dm, *glv, *mvec, *hd, *r, *rt, *rp, *mu, *mup, *muh, *scal, *capb, *capslack, *nu;      // hd: undamped diagonal of the iteration's Hessian (free-set order)
     double *fcol;                      // [2][72]: multiplier column + pivot of the factorisation's current step (double-buffered)
     int *kk, *fi, *act, *istate, *capmodel, *actc;
     signed char *pos;
@@ -85,7 +85,7 @@ __host__ __device__ inline size_t master_lds_bytes(int N, int n_out, int S, int 
     const size_t LDN = N + 1, LDM = (S + MASTER_NE + 1) | 1, KE = (size_t)KM * (KM + 1) / 2, ND = (size_t)N * (N + 1) / 2;
     const size_t PA = n_out < MASTER_PACT ? n_out : MASTER_PACT;      // active outputs there can be: T and the a_{o,j} are kept for those only
     size_t d = (size_t)n_out * master_phi_doubles(N, nt) + PA * N * LDN + (size_t)S * n_out * KE + (size_t)S * LDM +
-               PA * S * KM + (size_t)S * MASTER_PACT + 8 * (size_t)S + 6 * (size_t)n_out + 256 + 3 * 64 + (size_t)N + 2 * 72;
+               PA * S * KM + (size_t)S * MASTER_PACT + 9 * (size_t)S + 6 * (size_t)n_out + 256 + 3 * 64 + (size_t)N + 2 * 72;
     size_t bytes = d * sizeof(double) + (3 * (size_t)S + 2 * MASTER_PACT + 48 + 64 + 2 * MASTER_MCAP) * sizeof(int) + (size_t)S * N + (size_t)S * KM + 64;
     bytes = (bytes + 7) & ~(size_t)7;
     bytes += (2 * ND + 2 + (size_t)S * KE + 8) * sizeof(unsigned short);
@@ -103,7 +103,7 @@ __device__ inline void master_carve(MasterLds &L, unsigned char *base, int N, in
     L.M = p;    p += (size_t)S * L.LDM;
     L.AAC = p;  p += PA * S * KM;
     L.GQ = p;   p += (size_t)S * MASTER_PACT;
-    L.x = p; p += S; L.xt = p; p += S; L.xp = p; p += S; L.d = p; p += S; L.cc = p; p += S; L.Dm = p; p += S; L.glv = p; p += S; L.mvec = p; p += S;
+    L.x = p; p += S; L.xt = p; p += S; L.xp = p; p += S; L.d = p; p += S; L.cc = p; p += S; L.Dm = p; p += S; L.glv = p; p += S; L.mvec = p; p += S; L.hd = p; p += S;
     L.r = p; p += n_out; L.rt = p; p += n_out; L.rp = p; p += n_out; L.mu = p; p += n_out; L.mup = p; p += n_out; L.muh = p; p += n_out;
     L.scal = p; p += 256;
     L.capb = p; p += 64; L.capslack = p; p += 64; L.nu = p; p += 64;
@@ -447,12 +447,20 @@ __device__ void master_eval(const MasterArgs &A, MasterLds &L, const double *xv,
 }
 
 // Hessian of the Lagrangian in reciprocal form + damping into M (free x free, compressed), E columns appended -- all threads
-__device__ void master_build_system(const MasterArgs &A, MasterLds &L, int tid)
+// (reuse: a further attempt of the same iteration -- the Hessian is the same, only the damping on the diagonal changed; the
+// elimination works in registers and leaves the S x S block of L.M as it was, so the diagonal is restored from L.hd and damped anew)
+__device__ void master_build_system(const MasterArgs &A, MasterLds &L, int tid, bool reuse)
 {
     const int N = A.N, S = A.S, KM = A.KM, LDN = L.LDN, LDM = L.LDM;
     const int nf = L.istate[IS_NF], nact = L.istate[IS_NACT], nact0 = L.istate[IS_NACT0];
     const double dl = L.scal[SC_DAMP] * fabs(L.scal[SC_LAMEST]);
-    for (int t = tid; t < nf * nf; t += MASTER_THREADS) {
+    if (reuse)
+        for (int fa = tid; fa < nf; fa += MASTER_THREADS) {
+            double h = L.hd[fa];
+            h += dl * L.Dm[L.fi[fa]];
+            L.M[fa * LDM + fa] = h;
+        }
+    for (int t = tid; t < (reuse ? 0 : nf * nf); t += MASTER_THREADS) {
         const int fa = t / nf, fb = t % nf;
         if (fa > fb) continue;
         const int i = L.fi[fa], j = L.fi[fb];
@@ -474,7 +482,7 @@ __device__ void master_build_system(const MasterArgs &A, MasterLds &L, int tid)
             const double gi = L.GQ[i * MASTER_PACT + a], gj = L.GQ[j * MASTER_PACT + a];
             h += L.muh[o] * ((2.0 / A.s[o]) * cci * ccj * acc / (ro * ro) - 2.0 * gi * gj * ro);
         }
-        if (fa == fb) h += dl * L.Dm[i];
+        if (fa == fb) { L.hd[fa] = h; h += dl * L.Dm[i]; }
         L.M[fa * LDM + fb] = h;
         L.M[fb * LDM + fa] = h;
     }
@@ -1041,7 +1049,7 @@ __global__ __launch_bounds__(MASTER_THREADS) void k_master_newton(MasterArgs A)
             if (tid < MASTER_PACT) L.act[tid] = L.act[tid + MASTER_PACT];
             __syncthreads();
             TSTAMP(4);                                  // 4: free set, KKT bookkeeping, step formation
-            master_build_system(A, L, tid);
+            master_build_system(A, L, tid, attempt > 0);
             TSTAMP(5);                                  // 5: Hessian / system assembly
             master_factor_all(A, L, tid);
 #ifdef MASTER_TIMING_FINE

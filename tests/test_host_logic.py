@@ -289,3 +289,22 @@ def test_blue_fn_sums_and_refusals():
     assert bluest_amd.blue_fn(ls, 4, Problem(), No=2, verbose=False)[2] == 10.0
     with pytest.raises(bluest_amd.BLUESTError):
         bluest_amd.blue_fn(ls, 4, Problem(), No=2, filename="x.npz")
+
+
+def test_head_of_the_candidate_list_equals_the_full_sort():
+    """colgen.top_candidates (the pricing round's host side: a partition + a sort of the head instead of np.lexsort over all 1024
+    candidates) returns exactly the head of the full (largest value first, ties by smaller index) order -- with ties across the cut,
+    empty slots (index -1), and k beyond the list"""
+    from bluest_amd.colgen import top_candidates
+    rng = np.random.RandomState(7)
+    for trial in range(300):
+        n = int(rng.choice([16, 64, 1024]))
+        topv = np.round(rng.rand(n), int(rng.choice([1, 2, 6])))          # coarse rounding: many ties
+        topi = rng.randint(-1, 4 * n, n).astype(np.int64)
+        if trial % 7 == 0:
+            topv[rng.rand(n) < 0.5] = -np.inf
+        k = int(rng.randint(1, n + 40))
+        order = np.lexsort((topi, -topv))
+        ci, cv = top_candidates(topv, topi, k)
+        m = min(k, n)
+        assert ci[:m] == topi[order][:m].tolist() and cv[:m] == topv[order][:m].tolist(), (trial, n, k)

@@ -1278,7 +1278,11 @@ extern "C" int bluest_plan_finalize(bluest_plan_t plan, int max_candidates)
         // of threading
         std::vector<std::vector<int64_t>> counts(n_struct, std::vector<int64_t>(nsym, 0));
         int64_t max_row = 0;
-        const int S = std::max(1, host_threads() / n_struct);      // slices per structure
+        // slices per structure: as many as there are threads for them, but no slice below ~250 k (j, l) pairs -- spawning and joining
+        // 16 threads costs more than counting the headline problem's 326 k pairs on one (the layout does not depend on S)
+        int64_t pairs0 = 0;
+        for (int k = 1; k <= plan->outs[0].K; k++) pairs0 += plan->outs[0].sizes[k - 1] * (int64_t)(k * (k + 1) / 2);
+        const int S = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads() / n_struct, pairs0 / 250000));
         std::vector<std::vector<int64_t>> slice_cnt((size_t)n_struct * S, std::vector<int64_t>(nsym, 0));
         auto for_groups_of_slice = [&](int o, int slice, auto &&body) {
             const OutputDesc &od = plan->outs[o];

@@ -203,11 +203,17 @@ class MOSAP(object):
 
         outs = []
         self._identity_map = []                                   # output n lives on all groups in the global order
+        flat_global = None                                        # ... and such outputs hand the plan ONE flattened copy of the global list
         for n in range(self.n_outputs):
             mg = multi_groups[n]
             ident = len(self.mappings[n]) == self.L and (self.mappings[n] == np.arange(self.L)).all()
             self._identity_map.append(bool(ident))
-            outs.append({"K": Ks[n], "sizes": [len(g) for g in mg], "groups": mg, "C": np.asarray(C[n], dtype=np.float64),
+            gl = mg
+            if ident and Ks[n] == K:
+                if flat_global is None:
+                    flat_global = np.ascontiguousarray(np.concatenate([np.asarray(g, dtype=np.int64).ravel() for g in groups]))
+                gl = flat_global
+            outs.append({"K": Ks[n], "sizes": [len(g) for g in mg], "groups": gl, "C": np.asarray(C[n], dtype=np.float64),
                          "mapping": None if ident else self.mappings[n]})
         clock.tick("mappings")
         self.plan = Plan(self.N, self.L, outs, max_candidates=max_candidates, device=device)

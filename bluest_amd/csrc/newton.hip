@@ -22,7 +22,12 @@
 #endif
 #define MASTER_THREADS 512
 #define MASTER_SMAX 64
-#define MASTER_PACT 6      // candidate outputs (within act_tol of the maximum) of one step of the master
+#ifndef MASTER_PACT
+#define MASTER_PACT 8      // candidate outputs (within act_tol of the maximum) of one step of the master.  6 until round 4: with 7 or 8
+                           // outputs tied at the optimum (headline shape, other covariance seeds) the step cannot equalise them and the
+                           // master ends at a KKT measure of 3e-5, certified gap 1.4e-5 -- profiles/r04_seed_sweep.txt.  The scal[] blocks
+                           // SQ / SQT / SMU (8 slots each) and the 16-lane KKT system (8 + MASTER_MCAP + 2 rows) are sized for 8
+#endif
 #define MASTER_MCAP 4      // sample caps (max_model_samples rows) that can be in the step as equality rows at once
 #define MASTER_NE (MASTER_PACT + MASTER_MCAP + 1)      // columns of E: active outputs, active caps, the simplex row
 #define MASTER_OUT 16      // doubles in front of r[] in the result record

@@ -106,7 +106,7 @@ def master_newton(prob, x0, mu0=None, tol=1.0e-9, maxit=60, act_tol=1.0e-3, floo
     bcap = np.zeros(0) if caps is None else np.asarray(caps[1], dtype=np.float64)
     ncap = len(bcap)
     nu = np.zeros(ncap) if nu0 is None else np.maximum(np.asarray(nu0, dtype=np.float64), 0.0)
-    MCAP, PACT = 4, 6
+    MCAP, PACT = 4, 8
     if fb is None:
         fb = 0.0 if prob.eps_bg > 0.0 else 0.9     # without the background V has kinks where a model drops out: stay inside the face
     x = np.maximum(np.asarray(x0, dtype=np.float64), 0.0)

@@ -3,7 +3,7 @@
 # barriers; the product build is restored on exit):  tools/master_phases.sh out.txt
 out=${1:-gpurun_out/master_phases.txt}
 trap 'env -u BLUEST_EXTRA_HIPCC_FLAGS python -m bluest_amd.build --force > /dev/null 2>&1' EXIT
-BLUEST_EXTRA_HIPCC_FLAGS="-DMASTER_TIMING" python -m bluest_amd.build --force > /dev/null 2>&1 || { echo "timing build failed" > $out; exit 1; }
+BLUEST_EXTRA_HIPCC_FLAGS="-DMASTER_TIMING $MASTER_PHASE_FLAGS" python -m bluest_amd.build --force > /dev/null 2>&1 || { echo "timing build failed" > $out; exit 1; }
 python - > $out <<'PY'
 import re, subprocess, sys
 names = ["load of the support (blocks, lists)", "Phi assembly of the evaluations", "elimination of the evaluations (V only, DPP)",
